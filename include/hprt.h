@@ -1,0 +1,232 @@
+/* hprt — C ABI of the MI355X-native wavefront path-tracing core.
+ *
+ * Drop-in boundary for ONE hot path of the pbrt-v3 thesis fork
+ * (jhoobergs/Thesis-pbrt-v3):
+ *   SamplerIntegrator::Render  ->  PathIntegrator::Li  ->
+ *   BVHAccel::Intersect/IntersectP  ->  Triangle::Intersect/IntersectP.
+ * Plain pointers and sizes only; no C++ or torch types cross this header.
+ * Every entry point names the reference interface it stands in for
+ * (paths relative to the reference's src/).  All functions return 0 on success
+ * or a negative HPRT_E_* code; hprt_last_error() returns the message of the last
+ * failure on the calling thread.  No exception crosses the boundary.
+ *
+ * Device entry points (hprt_scene_*, hprt_intersect, hprt_occluded, hprt_render,
+ * hprt_film_*) require a gfx950 GPU and fail with HPRT_E_NO_DEVICE otherwise:
+ * there is no CPU fallback behind this ABI.
+ */
+#ifndef HPRT_H
+#define HPRT_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPRT_OK 0
+#define HPRT_E_INVALID (-1)     /* bad argument / malformed description */
+#define HPRT_E_IO (-2)          /* file could not be read or written     */
+#define HPRT_E_PARSE (-3)       /* scene description rejected            */
+#define HPRT_E_NO_DEVICE (-4)   /* no usable HIP device                  */
+#define HPRT_E_DEVICE (-5)      /* HIP runtime error                     */
+#define HPRT_E_UNSUPPORTED (-6) /* feature outside the hot-path scope    */
+
+const char *hprt_last_error(void);
+/* Compile-time identity of the library: "hprt <ver> gfx950 ..." */
+const char *hprt_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* Host front-end: the parsed scene ("model").                               */
+/* Stands in for pbrtParseFile + the pbrt* API state machine                 */
+/* (core/parser.cpp:786-1092, core/api.cpp:1103-1874) up to, but excluding,  */
+/* MakeScene()/Render().                                                     */
+/* ------------------------------------------------------------------------ */
+typedef struct HprtModel HprtModel;
+
+typedef struct HprtRenderOptions {
+    int32_t xres, yres;            /* Film "xresolution"/"yresolution" (core/film.cpp:322-323) */
+    float crop[4];                 /* cropwindow x0 x1 y0 y1 (core/film.cpp:326-341)           */
+    float filter_radius[2];        /* box filter half-widths (filters/box.cpp:43-47)            */
+    float film_scale, max_sample_luminance;
+    float fov, lens_radius, focal_distance;      /* cameras/perspective.cpp:224-271 */
+    float screen_window[4];        /* x0 x1 y0 y1 */
+    float camera_to_world[16], world_to_camera[16]; /* row-major Transform::m / mInv */
+    int32_t spp;                   /* Sampler "pixelsamples" (samplers/halton.cpp:135)          */
+    int32_t sample_pixel_center;
+    int32_t max_depth;             /* Integrator "maxdepth" (integrators/path.cpp:209)          */
+    float rr_threshold;            /* integrators/path.cpp:224                                   */
+    int32_t light_strategy;        /* 0 uniform, 1 power, 2 spatial (core/lightdistrib.cpp:47-66)*/
+    int32_t max_node_prims, isect_cost, trav_cost; /* accelerators/bvh.cpp:529-535 */
+} HprtRenderOptions;
+
+/* Parse a .pbrt file.  `subst` holds n_subst {key,value} string pairs that
+ * replace the fork's template tokens ($acc -> "bvh", $accnr -> 0, ... as
+ * scripts/render_simple.sh:23-29 does with sed) and, for keys that end in '/',
+ * path prefixes of Include/plymesh file names. */
+int hprt_model_parse(const char *pbrt_path, const char *const *subst, int n_subst, HprtModel **out);
+/* Baked scene container (post-parse, world-space; DESIGN.md "Baked scene"). */
+int hprt_model_load(const char *baked_path, HprtModel **out);
+int hprt_model_save(const HprtModel *m, const char *baked_path);
+void hprt_model_destroy(HprtModel *m);
+int hprt_model_get_options(const HprtModel *m, HprtRenderOptions *out);
+int hprt_model_set_options(HprtModel *m, const HprtRenderOptions *in);
+/* counts[0..5] = shapes, primitives, triangles, spheres, materials, lights */
+int hprt_model_counts(const HprtModel *m, uint64_t counts[6]);
+/* Front-end warnings (out-of-scope features that were substituted), '\n' separated. */
+const char *hprt_model_warnings(const HprtModel *m);
+
+/* ------------------------------------------------------------------------ */
+/* Accelerator build.  Stands in for BVHAccel::BVHAccel + iterativeBuild +   */
+/* flattenBVHTree (accelerators/bvh.cpp:155-185, 196-333, 335-350) and       */
+/* CreateBVHAccelerator (:529-535).  Host side; the node array is            */
+/* byte-identical to the reference's LinearBVHNode[] (:123-152).             */
+/* ------------------------------------------------------------------------ */
+typedef struct HprtBvh HprtBvh;
+int hprt_bvh_build(const HprtModel *m, HprtBvh **out);
+void hprt_bvh_destroy(HprtBvh *b);
+/* info[0..3] = nodes, primitives, leaves, max depth; bounds6 = root pMin,pMax
+ * (BVHAccel::WorldBound, accelerators/bvh.cpp:187-189) */
+int hprt_bvh_info(const HprtBvh *b, uint32_t info[4], float bounds6[6]);
+/* nodes32: n_nodes*32 bytes; prim_order: n_prims uint32 (ordered -> creation number) */
+int hprt_bvh_copy(const HprtBvh *b, void *nodes32, uint32_t *prim_order);
+
+/* ------------------------------------------------------------------------ */
+/* Device scene.  Upload step that follows the BVH build: stands in for the  */
+/* `primitives`/`nodes` members BVHAccel keeps (accelerators/bvh.h:69-79) and */
+/* the Scene object (core/scene.h:50-80).  The library copies everything to   */
+/* HBM and owns that memory until hprt_scene_destroy.                         */
+/* ------------------------------------------------------------------------ */
+typedef struct HprtScene HprtScene;
+
+typedef struct HprtShapeDesc {       /* one Shape directive (core/api.cpp:1561-1651) */
+    int32_t kind;                    /* 0 triangle mesh, 1 sphere */
+    int32_t material;                /* index into materials */
+    int32_t area_light;              /* index into lights or -1 (GeometricPrimitive::areaLight) */
+    int32_t reverse_orientation, transform_swaps_handedness; /* core/shape.h:79-80 */
+    /* mesh: world-space arrays as TriangleMesh holds them (shapes/triangle.cpp:54-92) */
+    uint32_t n_tris, n_verts;
+    const int32_t *indices;          /* 3*n_tris */
+    const float *P;                  /* 3*n_verts */
+    const float *N;                  /* 3*n_verts or NULL */
+    const float *UV;                 /* 2*n_verts or NULL */
+    const float *S;                  /* 3*n_verts or NULL */
+    /* sphere (shapes/sphere.h:50-59) */
+    float object_to_world[16], world_to_object[16];
+    float radius, z_min, z_max, theta_min, theta_max, phi_max;
+} HprtShapeDesc;
+
+typedef struct HprtMaterialDesc {    /* materials/matte.cpp:64-72, materials/plastic.cpp:72-84 */
+    int32_t type;                    /* 0 matte, 1 plastic */
+    float Kd[3], sigma, Ks[3], roughness;
+    int32_t remap_roughness;
+} HprtMaterialDesc;
+
+typedef struct HprtLightDesc {       /* lights/point.cpp, lights/distant.cpp, lights/diffuse.cpp */
+    int32_t type;                    /* 0 point, 1 distant, 2 diffuse area */
+    float pos[3];                    /* point: pLight (world); distant: wLight (world, normalised) */
+    float I[3];                      /* I / L / Lemit */
+    int32_t shape;                   /* area light: shape index */
+    int32_t two_sided;
+} HprtLightDesc;
+
+typedef struct HprtSceneDesc {
+    const void *nodes;               /* n_nodes * 32 B, LinearBVHNode layout */
+    uint32_t n_nodes;
+    const uint32_t *prim_order;      /* n_prims: ordered position -> creation-order primitive number */
+    uint32_t n_prims;
+    const HprtShapeDesc *shapes; uint32_t n_shapes;   /* creation order */
+    const HprtMaterialDesc *materials; uint32_t n_materials;
+    const HprtLightDesc *lights; uint32_t n_lights;
+    int32_t light_strategy;
+} HprtSceneDesc;
+
+/* device < 0 selects the current HIP device. */
+int hprt_scene_create(const HprtSceneDesc *desc, int device, HprtScene **out);
+/* Convenience: the same from a parsed model and its BVH. */
+int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int device, HprtScene **out);
+void hprt_scene_destroy(HprtScene *s);
+
+/* ------------------------------------------------------------------------ */
+/* Batched Aggregate interface.  Stand in for                                */
+/*   bool BVHAccel::Intersect(const Ray&, SurfaceInteraction*) const         */
+/*        (accelerators/bvh.cpp:354-396, core/primitive.h:57-61)             */
+/*   bool BVHAccel::IntersectP(const Ray&) const (accelerators/bvh.cpp:398-437) */
+/* over n rays held in host memory (SoA-of-arrays: o and d are 3*n floats,   */
+/* xyz interleaved per ray).  Closest hit writes the shrunken tMax (unchanged */
+/* on a miss), the ORDERED primitive index (-1 on a miss) and b0,b1,b2        */
+/* (triangles; 0 for spheres).  counters (may be NULL) receives               */
+/* [0] BVH nodes fetched (traversal-loop iterations), [1] nodes entered (the   */
+/* reference's "BVH node traversals" counter), [2] triangle tests, [3] sphere  */
+/* tests — the figures SURVEY.md §8(d)'s byte model is built from.            */
+/* ------------------------------------------------------------------------ */
+int hprt_intersect(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, float *t_out,
+                   int32_t *prim_out, float *bary_out, uint64_t counters[4]);
+int hprt_occluded(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, uint8_t *occluded_out,
+                  uint64_t counters[4]);
+/* Same with rays/hits already resident in HBM (device pointers, SoA planes:
+ * ox,oy,oz,dx,dy,dz,tmax each n floats).  `stream` is a hipStream_t or NULL.
+ * Timed by bench.py's kernel microbenchmarks. */
+int hprt_intersect_device(HprtScene *s, size_t n, const float *d_rays7, float *d_t, int32_t *d_prim, float *d_bary3,
+                          void *stream);
+int hprt_occluded_device(HprtScene *s, size_t n, const float *d_rays7, uint8_t *d_occ, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Integrator.  Stands in for SamplerIntegrator::Render(const Scene&)        */
+/* (core/integrator.cpp:230-360) with PathIntegrator::Li                     */
+/* (integrators/path.cpp:64-204) as the radiance estimator, the Halton        */
+/* sampler (samplers/halton.cpp) and the box-filtered Film                    */
+/* (core/film.h:130-170, core/film.cpp:118-132).                              */
+/* ------------------------------------------------------------------------ */
+typedef struct HprtRenderDesc {
+    HprtRenderOptions opt;
+    /* 16x16 image tiles [tile_begin, tile_end) of the row-major tile grid
+     * (core/integrator.cpp:237-244) are rendered; tile_stride > 1 takes every
+     * tile_stride-th tile starting at tile_begin (round-robin sharding across
+     * GPUs).  tile_end <= 0 means "all tiles". */
+    int32_t tile_begin, tile_end, tile_stride;
+    int32_t spp_chunk;             /* samples per pixel per wavefront batch; <= 0: automatic */
+    int32_t flags;                 /* HPRT_RENDER_* */
+} HprtRenderDesc;
+#define HPRT_RENDER_COUNT_WORK 1   /* collect node/triangle counters (slower) */
+
+typedef struct HprtRenderStats {
+    uint64_t camera_rays;          /* nCameraRays, core/integrator.cpp:48,293 */
+    uint64_t rays;                 /* "Regular ray intersection tests", core/scene.cpp:40,47 */
+    uint64_t shadow_rays;          /* "Shadow ray intersection tests",  core/scene.cpp:42,53 */
+    uint64_t nodes_fetched, nodes_fetched_p;   /* traversal-loop iterations (closest / any hit) */
+    uint64_t nodes_entered, nodes_entered_p;   /* nbNodeTraversals / nbNodeTraversalsP, bvh.cpp:48-49 */
+    uint64_t tri_tests, tri_tests_p;           /* nTests / nTestsP, shapes/triangle.cpp:43-44 */
+    uint64_t sphere_tests, sphere_tests_p;
+    double render_seconds;         /* the reference's Timings/Rendertime span: tile loop only */
+    double extend_seconds, occluded_seconds;  /* HIP-event time inside the traversal kernels */
+    uint64_t extend_launches, occluded_launches;
+    uint64_t extend_rays, occluded_rays;
+} HprtRenderStats;
+
+/* Renders into the scene's film.  d_film_xyzw, if not NULL, is a caller-owned
+ * DEVICE buffer of 4*W*H floats (W,H = cropped pixel bounds) that receives the
+ * merged film state (xyz, filterWeightSum) of the rendered tiles and zeros
+ * elsewhere — what Film::MergeFilmTile leaves in Film::pixels.  Summing such
+ * buffers over GPUs (RCCL reduce) reproduces the single-GPU film exactly. */
+int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, void *stream, HprtRenderStats *stats);
+/* Film::WriteImage arithmetic (core/film.cpp:266-303) on a host copy of a film
+ * state: rgb_out = 3*W*H floats, top row first. */
+int hprt_film_resolve(const float *xyzw, size_t n_pixels, float film_scale, float *rgb_out);
+/* Film state of the last hprt_render on this scene, copied to the host. */
+int hprt_film_read(HprtScene *s, float *xyzw_out, size_t n_pixels);
+/* imageio.cpp:437+ : PFM writer (bottom row first, little endian). */
+int hprt_write_pfm(const char *path, const float *rgb, int width, int height);
+
+/* Radiance of individual camera samples (pixel x, y, sample index), after the
+ * NaN/negative/inf guards of core/integrator.cpp:300-321; L_out = 3*n floats.
+ * Test hook for per-sample parity. */
+int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, const int32_t *px, const int32_t *py,
+                         const int64_t *sample, float *L_out);
+
+/* Halton sampler tables (host): ComputeRadicalInversePermutations
+ * (core/lowdiscrepancy.cpp:2490-2504) with the default-seeded PCG32. */
+int hprt_halton_permutations(uint16_t *out, size_t max_entries, size_t *n_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPRT_H */

@@ -1,0 +1,188 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).
+// C entry points for tests/ (ctypes), __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg.  Nothing under thesis-pbrt-v3_amd/ links this.
+#include <cstdio>
+#include <string>
+#include "orc_integrator.h"
+
+namespace orc { bool g_use_libm = false; }
+using namespace orc;
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char *orc_last_error() { return g_err.c_str(); }
+void orc_set_libm(int on) { g_use_libm = on != 0; }
+
+void *orc_scene_load(const char *path) {
+    Renderer *r = new Renderer();
+    std::string err;
+    if (!LoadScene(path, &r->scene, &err) || !r->Setup(&err)) { g_err = err; delete r; return nullptr; }
+    return r;
+}
+void orc_scene_free(void *h) { delete (Renderer *)h; }
+
+// Override film/sampler parameters after load (crop in pixels fractions as in the scene file)
+int orc_set_film(void *h, int xres, int yres, const float *crop4, int spp, int maxDepth) {
+    Renderer *r = (Renderer *)h;
+    if (xres > 0) r->scene.prm.xres = xres;
+    if (yres > 0) r->scene.prm.yres = yres;
+    if (crop4) for (int i = 0; i < 4; ++i) r->scene.prm.crop[i] = crop4[i];
+    if (spp > 0) r->scene.prm.spp = spp;
+    if (maxDepth >= 0) r->scene.prm.maxDepth = maxDepth;
+    r->camera.Init(r->scene.prm);
+    r->film.Init(r->scene.prm);
+    return 0;
+}
+void orc_film_bounds(void *h, int *out4) {
+    Renderer *r = (Renderer *)h;
+    out4[0] = r->film.cx0; out4[1] = r->film.cy0; out4[2] = r->film.cx1; out4[3] = r->film.cy1;
+}
+
+void orc_bvh_info(void *h, int *nNodes, int *nPrims, int *nLeaves, int *maxDepth, float *bounds6) {
+    Renderer *r = (Renderer *)h;
+    *nNodes = (int)r->bvh.nodes.size(); *nPrims = (int)r->bvh.primOrder.size();
+    *nLeaves = r->bvh.nLeaves; *maxDepth = r->bvh.maxDepth;
+    B3 b = r->bvh.WorldBound();
+    bounds6[0] = b.pMin.x; bounds6[1] = b.pMin.y; bounds6[2] = b.pMin.z;
+    bounds6[3] = b.pMax.x; bounds6[4] = b.pMax.y; bounds6[5] = b.pMax.z;
+}
+void orc_bvh_copy(void *h, void *nodes, uint32_t *primOrder) {
+    Renderer *r = (Renderer *)h;
+    memcpy(nodes, r->bvh.nodes.data(), r->bvh.nodes.size() * sizeof(LinearBVHNode));
+    memcpy(primOrder, r->bvh.primOrder.data(), r->bvh.primOrder.size() * 4);
+}
+
+// counters: [0]nodesFetched [1]nodesFetchedP [2]nodesEntered [3]nodesEnteredP [4]triTests [5]triTestsP
+//           [6]triHits [7]triHitsP [8]sphereTests [9]sphereTestsP [10]rays [11]shadowRays [12]cameraRays
+static void export_counters(const Counters &c, uint64_t *o) {
+    o[0] = c.nodesFetched; o[1] = c.nodesFetchedP; o[2] = c.nodesEntered; o[3] = c.nodesEnteredP;
+    o[4] = c.triTests; o[5] = c.triTestsP; o[6] = c.triHits; o[7] = c.triHitsP;
+    o[8] = c.sphereTests; o[9] = c.sphereTestsP; o[10] = c.rays; o[11] = c.shadowRays; o[12] = c.cameraRays;
+}
+
+// Closest hit for n rays (BVHAccel::Intersect).  prim = index into the ORDERED
+// primitive list (-1 on a miss), t = shrunken tMax (unchanged tMax on a miss).
+void orc_intersect(void *h, size_t n, const float *o, const float *d, const float *tmax, float *t, int32_t *prim,
+                   float *bary, uint64_t *counters13) {
+    Renderer *r = (Renderer *)h;
+    Counters ctr;
+    for (size_t i = 0; i < n; ++i) {
+        Ray ray(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]);
+        SurfaceInteraction si; int ordered = -1;
+        bool hit = r->bvh.Intersect(ray, &si, ctr, &ordered);
+        t[i] = ray.tMax; prim[i] = hit ? ordered : -1;
+        bary[3 * i] = hit ? si.b0 : 0; bary[3 * i + 1] = hit ? si.b1 : 0; bary[3 * i + 2] = hit ? si.b2 : 0;
+    }
+    if (counters13) export_counters(ctr, counters13);
+}
+// Same, also returning the SurfaceInteraction fill (p, pError, n, shading.n, shading.dpdu)
+void orc_intersect_full(void *h, size_t n, const float *o, const float *d, const float *tmax, float *t,
+                        int32_t *prim, float *si15) {
+    Renderer *r = (Renderer *)h;
+    Counters ctr;
+    for (size_t i = 0; i < n; ++i) {
+        Ray ray(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]);
+        SurfaceInteraction si; int ordered = -1;
+        bool hit = r->bvh.Intersect(ray, &si, ctr, &ordered);
+        t[i] = ray.tMax; prim[i] = hit ? ordered : -1;
+        float *q = si15 + 15 * i;
+        if (hit) {
+            V3 v[5] = {si.p, si.pError, si.n, si.shading.n, si.shading.dpdu};
+            for (int k = 0; k < 5; ++k) { q[3 * k] = v[k].x; q[3 * k + 1] = v[k].y; q[3 * k + 2] = v[k].z; }
+        } else for (int k = 0; k < 15; ++k) q[k] = 0;
+    }
+}
+void orc_occluded(void *h, size_t n, const float *o, const float *d, const float *tmax, uint8_t *occ,
+                  uint64_t *counters13) {
+    Renderer *r = (Renderer *)h;
+    Counters ctr;
+    for (size_t i = 0; i < n; ++i) {
+        Ray ray(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]);
+        occ[i] = r->bvh.IntersectP(ray, ctr) ? 1 : 0;
+    }
+    if (counters13) export_counters(ctr, counters13);
+}
+
+// Sampler known answers
+void orc_pcg32(int n, uint32_t *out) { RNG rng; for (int i = 0; i < n; ++i) out[i] = rng.UniformUInt32(); }
+int orc_perm_table(uint16_t *out, int maxEntries) {
+    const std::vector<uint16_t> &p = HaltonSampler::Permutations();
+    int n = (int)p.size();
+    for (int i = 0; i < n && i < maxEntries; ++i) out[i] = p[i];
+    return n;
+}
+float orc_radical_inverse(int baseIndex, uint64_t a) { return RadicalInverse(baseIndex, a); }
+float orc_scrambled_radical_inverse(int baseIndex, uint64_t a) {
+    return ScrambledRadicalInverse(baseIndex, a, &HaltonSampler::Permutations()[PrimeSums()[baseIndex]]);
+}
+// dims [dim0, dim0+nd) of sample `sampleNum` at pixel (px,py) for a sampler over [sx0,sx1)x[sy0,sy1)
+int64_t orc_halton(int sx0, int sy0, int sx1, int sy1, int px, int py, int64_t sampleNum, int dim0, int nd,
+                   float *out) {
+    HaltonSampler s(1 << 30, sx0, sy0, sx1, sy1);
+    s.StartPixel(px, py);
+    s.SetSampleNumber(sampleNum);
+    for (int i = 0; i < nd; ++i) out[i] = s.SampleDimension(s.intervalSampleIndex, dim0 + i);
+    return s.intervalSampleIndex;
+}
+
+// Camera rays for (px,py,sampleNum) triples
+void orc_camera_rays(void *h, size_t n, const int *px, const int *py, const int64_t *sn, float *o, float *d) {
+    Renderer *r = (Renderer *)h;
+    int sx0, sy0, sx1, sy1; r->film.GetSampleBounds(&sx0, &sy0, &sx1, &sy1);
+    HaltonSampler s(1 << 30, sx0, sy0, sx1, sy1, r->scene.prm.samplePixelCenter != 0);
+    for (size_t i = 0; i < n; ++i) {
+        s.StartPixel(px[i], py[i]); s.SetSampleNumber(sn[i]);
+        P2 u = s.Get2D(); s.Get1D(); P2 pl = s.Get2D();
+        Ray ray; r->camera.GenerateRay(P2((Float)px[i] + u.x, (Float)py[i] + u.y), pl, &ray);
+        o[3 * i] = ray.o.x; o[3 * i + 1] = ray.o.y; o[3 * i + 2] = ray.o.z;
+        d[3 * i] = ray.d.x; d[3 * i + 1] = ray.d.y; d[3 * i + 2] = ray.d.z;
+    }
+}
+// Radiance of individual camera samples (after the NaN/negative/inf guards)
+void orc_sample_radiance(void *h, size_t n, const int *px, const int *py, const int64_t *sn, float *L3) {
+    Renderer *r = (Renderer *)h;
+    int sx0, sy0, sx1, sy1; r->film.GetSampleBounds(&sx0, &sy0, &sx1, &sy1);
+    HaltonSampler s(1 << 30, sx0, sy0, sx1, sy1, r->scene.prm.samplePixelCenter != 0);
+    Counters ctr;
+    for (size_t i = 0; i < n; ++i) {
+        s.StartPixel(px[i], py[i]); s.SetSampleNumber(sn[i]);
+        P2 pf; Float w;
+        Spec L = r->RenderSample(s, px[i], py[i], &pf, &w, ctr);
+        L3[3 * i] = L.c[0]; L3[3 * i + 1] = L.c[1]; L3[3 * i + 2] = L.c[2];
+    }
+}
+
+// Full render.  rgb: 3*W*H floats, top row first (W,H = cropped pixel bounds).
+int orc_render(void *h, int spp, int nThreads, float *rgb, uint64_t *counters13, double *seconds) {
+    Renderer *r = (Renderer *)h;
+    r->nThreads = nThreads > 0 ? nThreads : (int)std::thread::hardware_concurrency();
+    r->Render(spp);
+    if (rgb) {
+        std::vector<Float> out;
+        FilmToRGB(&r->film, &out);
+        memcpy(rgb, out.data(), out.size() * sizeof(Float));
+    }
+    if (counters13) export_counters(r->total, counters13);
+    if (seconds) *seconds = r->renderSeconds;
+    return r->nThreads;
+}
+// Raw film state (xyz + weight per pixel) for exact film comparisons
+void orc_film_raw(void *h, float *xyzw) {
+    Renderer *r = (Renderer *)h;
+    for (size_t i = 0; i < r->film.pixels.size(); ++i) {
+        xyzw[4 * i] = r->film.pixels[i].xyz[0]; xyzw[4 * i + 1] = r->film.pixels[i].xyz[1];
+        xyzw[4 * i + 2] = r->film.pixels[i].xyz[2]; xyzw[4 * i + 3] = r->film.pixels[i].filterWeightSum;
+    }
+}
+
+// detmath probes
+float orc_det_sinf(float x) { return (float)det::sin_d((double)x); }
+float orc_det_cosf(float x) { return (float)det::cos_d((double)x); }
+double orc_det_sin(double x) { return det::sin_d(x); }
+double orc_det_cos(double x) { return det::cos_d(x); }
+float orc_det_atan2f(float y, float x) { return (float)det::atan2_d((double)y, (double)x); }
+float orc_det_acosf(float x) { return (float)det::acos_d((double)x); }
+
+}  // extern "C"

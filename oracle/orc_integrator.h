@@ -1,0 +1,524 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).
+// Camera, film, PathIntegrator::Li and the SamplerIntegrator::Render tile loop:
+// cameras/perspective.cpp, core/camera.h, core/film.{h,cpp}, core/integrator.cpp,
+// integrators/path.cpp, core/light.cpp, core/lightdistrib.cpp, core/sampling.h.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
+#include "orc_sampler.h"
+#include "orc_shading.h"
+
+namespace orc {
+
+// ---- 4x4 helpers for the camera (core/transform.cpp) ----------------------
+inline M44 MatMul(const M44 &a, const M44 &b) {   // Matrix4x4::Mul, transform.h:83-91
+    M44 r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j] + a.m[i][3] * b.m[3][j];
+    return r;
+}
+inline M44 MatIdentity() { M44 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[i][j] = (i == j) ? 1.f : 0.f; return r; }
+// core/transform.cpp:82-139 (Gauss-Jordan with full pivoting)
+inline M44 MatInverse(const M44 &m) {
+    int indxc[4], indxr[4];
+    int ipiv[4] = {0, 0, 0, 0};
+    Float minv[4][4];
+    memcpy(minv, m.m, 4 * 4 * sizeof(Float));
+    for (int i = 0; i < 4; i++) {
+        int irow = 0, icol = 0;
+        Float big = 0.f;
+        for (int j = 0; j < 4; j++) {
+            if (ipiv[j] != 1) {
+                for (int k = 0; k < 4; k++) {
+                    if (ipiv[k] == 0) {
+                        if (std::abs(minv[j][k]) >= big) { big = Float(std::abs(minv[j][k])); irow = j; icol = k; }
+                    }
+                }
+            }
+        }
+        ++ipiv[icol];
+        if (irow != icol) for (int k = 0; k < 4; ++k) std::swap(minv[irow][k], minv[icol][k]);
+        indxr[i] = irow; indxc[i] = icol;
+        Float pivinv = 1. / minv[icol][icol];
+        minv[icol][icol] = 1.;
+        for (int j = 0; j < 4; j++) minv[icol][j] *= pivinv;
+        for (int j = 0; j < 4; j++) {
+            if (j != icol) {
+                Float save = minv[j][icol];
+                minv[j][icol] = 0;
+                for (int k = 0; k < 4; k++) minv[j][k] -= minv[icol][k] * save;
+            }
+        }
+    }
+    for (int j = 3; j >= 0; j--) {
+        if (indxr[j] != indxc[j]) for (int k = 0; k < 4; k++) std::swap(minv[k][indxr[j]], minv[k][indxc[j]]);
+    }
+    M44 r; memcpy(r.m, minv, sizeof(minv)); return r;
+}
+struct Xf { M44 m, mInv; };
+inline Xf XfMul(const Xf &a, const Xf &b) { return Xf{MatMul(a.m, b.m), MatMul(b.mInv, a.mInv)}; }   // transform.cpp:251-253
+inline Xf XfInverse(const Xf &a) { return Xf{a.mInv, a.m}; }
+inline Xf XfTranslate(const V3 &d) {      // transform.cpp:141-147
+    Xf t; t.m = MatIdentity(); t.mInv = MatIdentity();
+    t.m.m[0][3] = d.x; t.m.m[1][3] = d.y; t.m.m[2][3] = d.z;
+    t.mInv.m[0][3] = -d.x; t.mInv.m[1][3] = -d.y; t.mInv.m[2][3] = -d.z;
+    return t;
+}
+inline Xf XfScale(Float x, Float y, Float z) {   // transform.cpp:149-153
+    Xf t; t.m = MatIdentity(); t.mInv = MatIdentity();
+    t.m.m[0][0] = x; t.m.m[1][1] = y; t.m.m[2][2] = z;
+    t.mInv.m[0][0] = 1 / x; t.mInv.m[1][1] = 1 / y; t.mInv.m[2][2] = 1 / z;
+    return t;
+}
+// transform.cpp:303-311.  std::tan(float) is glibc tanf (host-side, once).
+inline Xf XfPerspective(Float fov, Float n, Float f) {
+    M44 persp = MatIdentity();
+    persp.m[2][2] = f / (f - n); persp.m[2][3] = -f * n / (f - n);
+    persp.m[3][2] = 1; persp.m[3][3] = 0;
+    Float invTanAng = 1 / std::tan(Radians(fov) / 2);
+    Xf p{persp, MatInverse(persp)};
+    return XfMul(XfScale(invTanAng, invTanAng, 1), p);
+}
+
+// ---- Camera (core/camera.h:84-115, cameras/perspective.cpp:45-144) --------
+struct Camera {
+    Xf rasterToCamera;
+    M44 camToWorld;
+    Float lensRadius, focalDistance;
+    void Init(const SceneParams &p) {
+        Xf camToScreen = XfPerspective(p.fov, 1e-2f, 1000.f);
+        const Float *sw = p.screenWindow;   // pMin.x pMax.x pMin.y pMax.y
+        Xf screenToRaster = XfMul(XfMul(XfScale((Float)p.xres, (Float)p.yres, 1),
+                                        XfScale(1 / (sw[1] - sw[0]), 1 / (sw[2] - sw[3]), 1)),
+                                  XfTranslate(V3(-sw[0], -sw[3], 0)));
+        Xf rasterToScreen = XfInverse(screenToRaster);
+        rasterToCamera = XfMul(XfInverse(camToScreen), rasterToScreen);
+        camToWorld = p.camToWorld;
+        lensRadius = p.lensRadius; focalDistance = p.focalDistance;
+    }
+    // GenerateRayDifferential :95-144; differentials themselves only feed
+    // texture filtering (constant textures here), so only the main ray is kept.
+    Float GenerateRay(const P2 &pFilmS, const P2 &pLensS, Ray *ray) const {
+        V3 pFilm(pFilmS.x, pFilmS.y, 0);
+        V3 pCamera = XfPoint(rasterToCamera.m, pFilm);
+        V3 dir = Normalize(V3(pCamera.x, pCamera.y, pCamera.z));
+        Ray r(V3(0, 0, 0), dir);
+        if (lensRadius > 0) {
+            P2 c = ConcentricSampleDisk(pLensS);
+            P2 pLens(lensRadius * c.x, lensRadius * c.y);
+            Float ft = focalDistance / r.d.z;
+            V3 pFocus = r(ft);
+            r.o = V3(pLens.x, pLens.y, 0);
+            r.d = Normalize(pFocus - r.o);
+        }
+        // CameraToWorld(ray): Transform::operator()(const Ray&), transform.h:245-259
+        V3 oError;
+        V3 o = XfPointErr(camToWorld, r.o, &oError);
+        V3 d = XfVector(camToWorld, r.d);
+        Float lengthSquared = d.LengthSquared();
+        Float tMax = r.tMax;
+        if (lengthSquared > 0) {
+            Float dt = Dot(Abs(d), oError) / lengthSquared;
+            o += d * dt;
+            tMax -= dt;
+        }
+        *ray = Ray(o, d, tMax);
+        return 1;
+    }
+};
+
+// ---- Film (core/film.{h,cpp}; box filter) ----------------------------------
+struct FilmPixel { Float xyz[3] = {0, 0, 0}; Float filterWeightSum = 0; };
+struct FilmTilePixel { Spec contribSum = 0.f; Float filterWeightSum = 0.f; };
+struct Film {
+    int xres, yres;
+    int cx0, cy0, cx1, cy1;          // croppedPixelBounds
+    Float radius[2], scale, maxSampleLuminance;
+    static const int filterTableWidth = 16;
+    Float filterTable[filterTableWidth * filterTableWidth];
+    std::vector<FilmPixel> pixels;
+    std::mutex mutex;
+    void Init(const SceneParams &p) {
+        xres = p.xres; yres = p.yres;
+        cx0 = (int)std::ceil(xres * p.crop[0]); cx1 = (int)std::ceil(xres * p.crop[1]);   // film.cpp:56-60
+        cy0 = (int)std::ceil(yres * p.crop[2]); cy1 = (int)std::ceil(yres * p.crop[3]);
+        radius[0] = p.filterRadius[0]; radius[1] = p.filterRadius[1];
+        scale = p.filmScale; maxSampleLuminance = p.maxSampleLuminance;
+        for (int i = 0; i < filterTableWidth * filterTableWidth; ++i) filterTable[i] = 1.f;   // BoxFilter::Evaluate
+        pixels.assign((size_t)smax(0, (cx1 - cx0) * (cy1 - cy0)), FilmPixel());
+    }
+    void GetSampleBounds(int *x0, int *y0, int *x1, int *y1) const {   // film.cpp:81-87
+        *x0 = (int)std::floor((Float)cx0 + 0.5f - radius[0]);
+        *y0 = (int)std::floor((Float)cy0 + 0.5f - radius[1]);
+        *x1 = (int)std::ceil((Float)cx1 - 0.5f + radius[0]);
+        *y1 = (int)std::ceil((Float)cy1 - 0.5f + radius[1]);
+    }
+    FilmPixel &GetPixel(int x, int y) { return pixels[(size_t)(x - cx0) + (size_t)(y - cy0) * (cx1 - cx0)]; }
+};
+struct FilmTile {
+    int bx0, by0, bx1, by1;
+    const Film *film;
+    std::vector<FilmTilePixel> pixels;
+    FilmTile(const Film *f, int sx0, int sy0, int sx1, int sy1) : film(f) {   // film.cpp:96-107
+        int p0x = (int)std::ceil((Float)sx0 - 0.5f - f->radius[0]);
+        int p0y = (int)std::ceil((Float)sy0 - 0.5f - f->radius[1]);
+        int p1x = (int)std::floor((Float)sx1 - 0.5f + f->radius[0]) + 1;
+        int p1y = (int)std::floor((Float)sy1 - 0.5f + f->radius[1]) + 1;
+        bx0 = smax(p0x, f->cx0); by0 = smax(p0y, f->cy0);
+        bx1 = smin(p1x, f->cx1); by1 = smin(p1y, f->cy1);
+        pixels.assign((size_t)smax(0, (bx1 - bx0) * (by1 - by0)), FilmTilePixel());
+    }
+    FilmTilePixel &GetPixel(int x, int y) { return pixels[(size_t)(x - bx0) + (size_t)(y - by0) * (bx1 - bx0)]; }
+    void AddSample(const P2 &pFilm, Spec L, Float sampleWeight) {   // film.h:130-170
+        if (L.y() > film->maxSampleLuminance) L *= film->maxSampleLuminance / L.y();
+        P2 pFilmDiscrete(pFilm.x - 0.5f, pFilm.y - 0.5f);
+        int p0x = (int)std::ceil(pFilmDiscrete.x - film->radius[0]);
+        int p0y = (int)std::ceil(pFilmDiscrete.y - film->radius[1]);
+        int p1x = (int)std::floor(pFilmDiscrete.x + film->radius[0]) + 1;
+        int p1y = (int)std::floor(pFilmDiscrete.y + film->radius[1]) + 1;
+        p0x = smax(p0x, bx0); p0y = smax(p0y, by0);
+        p1x = smin(p1x, bx1); p1y = smin(p1y, by1);
+        const int W = Film::filterTableWidth;
+        Float invRx = 1 / film->radius[0], invRy = 1 / film->radius[1];
+        for (int y = p0y; y < p1y; ++y) {
+            Float fy = std::abs((y - pFilmDiscrete.y) * invRy * W);
+            int iy = smin((int)std::floor(fy), W - 1);
+            for (int x = p0x; x < p1x; ++x) {
+                Float fx = std::abs((x - pFilmDiscrete.x) * invRx * W);
+                int ix = smin((int)std::floor(fx), W - 1);
+                Float filterWeight = film->filterTable[iy * W + ix];
+                FilmTilePixel &pixel = GetPixel(x, y);
+                pixel.contribSum += L * sampleWeight * filterWeight;
+                pixel.filterWeightSum += filterWeight;
+            }
+        }
+    }
+};
+inline void MergeFilmTile(Film *film, FilmTile &tile) {   // film.cpp:118-132
+    std::lock_guard<std::mutex> lock(film->mutex);
+    for (int y = tile.by0; y < tile.by1; ++y)
+        for (int x = tile.bx0; x < tile.bx1; ++x) {
+            const FilmTilePixel &tp = tile.GetPixel(x, y);
+            FilmPixel &mp = film->GetPixel(x, y);
+            Float xyz[3];
+            RGBToXYZ(tp.contribSum.c, xyz);
+            for (int i = 0; i < 3; ++i) mp.xyz[i] += xyz[i];
+            mp.filterWeightSum += tp.filterWeightSum;
+        }
+}
+// Film::WriteImage arithmetic, film.cpp:266-303 (no splats); rgb is top-to-bottom
+inline void FilmToRGB(Film *film, std::vector<Float> *rgb) {
+    size_t n = film->pixels.size();
+    rgb->assign(3 * n, 0.f);
+    for (size_t i = 0; i < n; ++i) {
+        FilmPixel &pixel = film->pixels[i];
+        Float *o = &(*rgb)[3 * i];
+        XYZToRGB(pixel.xyz, o);
+        Float filterWeightSum = pixel.filterWeightSum;
+        if (filterWeightSum != 0) {
+            Float invWt = (Float)1 / filterWeightSum;
+            o[0] = smax((Float)0, o[0] * invWt);
+            o[1] = smax((Float)0, o[1] * invWt);
+            o[2] = smax((Float)0, o[2] * invWt);
+        }
+        Float splatRGB[3]; Float splatXYZ[3] = {0, 0, 0};
+        XYZToRGB(splatXYZ, splatRGB);
+        o[0] += 1.f * splatRGB[0]; o[1] += 1.f * splatRGB[1]; o[2] += 1.f * splatRGB[2];
+        o[0] *= film->scale; o[1] *= film->scale; o[2] *= film->scale;
+    }
+}
+
+// core/sampling.h:55-109 (uniform light distribution, lightdistrib.cpp:68-75)
+struct Distribution1D {
+    std::vector<Float> func, cdf; Float funcInt;
+    void Init(const Float *f, int n) {
+        func.assign(f, f + n); cdf.assign(n + 1, 0.f);
+        cdf[0] = 0;
+        for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / n;
+        funcInt = cdf[n];
+        if (funcInt == 0) for (int i = 1; i < n + 1; ++i) cdf[i] = Float(i) / Float(n);
+        else for (int i = 1; i < n + 1; ++i) cdf[i] /= funcInt;
+    }
+    int Count() const { return (int)func.size(); }
+    int SampleDiscrete(Float u, Float *pdf) const {
+        int size = (int)cdf.size();
+        int first = 0, len = size;    // FindInterval, pbrt.h:403-415
+        while (len > 0) {
+            int half = len >> 1, middle = first + half;
+            if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+            else len = half;
+        }
+        int offset = Clamp(first - 1, 0, size - 2);
+        if (pdf) *pdf = (funcInt > 0) ? func[offset] / (funcInt * Count()) : 0;
+        return offset;
+    }
+};
+
+struct Renderer {
+    Scene scene;
+    BVH bvh;
+    Camera camera;
+    Film film;
+    Distribution1D lightDistrib;
+    Float worldRadius = 0; V3 worldCenter;
+    int nThreads = 1;
+    Counters total;
+    double renderSeconds = 0;
+
+    bool Setup(std::string *err) {
+        if (scene.prm.filterType != 0) { *err = "only the box filter is in scope"; return false; }
+        for (const Light &l : scene.lights)
+            if (l.type == LIGHT_AREA && scene.shapes[l.shape].kind != SHAPE_SPHERE) {
+                *err = "area lights are supported on spheres only"; return false;
+            }
+        bvh.Build(&scene);
+        camera.Init(scene.prm);
+        film.Init(scene.prm);
+        if (scene.lights.size() > 1 && scene.prm.lightStrategy == 2) {
+            *err = "spatial light distribution with >1 light is out of scope (SURVEY.md §2)"; return false;
+        }
+        std::vector<Float> prob(smax<size_t>(1, scene.lights.size()), Float(1));
+        lightDistrib.Init(prob.data(), (int)scene.lights.size());
+        // Scene ctor + Light::Preprocess (core/scene.h:56-66, lights/distant.h:57-59)
+        B3 wb = bvh.WorldBound();
+        worldCenter = (wb.pMin + wb.pMax) / 2;
+        bool inside = worldCenter.x >= wb.pMin.x && worldCenter.x <= wb.pMax.x && worldCenter.y >= wb.pMin.y &&
+                      worldCenter.y <= wb.pMax.y && worldCenter.z >= wb.pMin.z && worldCenter.z <= wb.pMax.z;
+        worldRadius = inside ? Distance(worldCenter, wb.pMax) : 0;
+        return true;
+    }
+
+    bool SceneIntersect(const Ray &ray, SurfaceInteraction *isect, Counters &ctr) const {   // core/scene.cpp:45-49
+        ++ctr.rays;
+        return bvh.Intersect(ray, isect, ctr);
+    }
+    bool SceneIntersectP(const Ray &ray, Counters &ctr) const {                             // core/scene.cpp:51-55
+        ++ctr.shadowRays;
+        return bvh.IntersectP(ray, ctr);
+    }
+    // DiffuseAreaLight::L, lights/diffuse.h:56-58
+    static Spec AreaL(const Light &l, const V3 &n, const V3 &w) {
+        return (l.twoSided || Dot(n, w) > 0) ? l.I : Spec(0.f);
+    }
+    // SurfaceInteraction::Le, core/interaction.cpp:151-154
+    Spec Le(const SurfaceInteraction &isect, const V3 &w) const {
+        int al = scene.shapes[isect.shape].areaLight;
+        return al >= 0 ? AreaL(scene.lights[al], isect.n, w) : Spec(0.f);
+    }
+    // Light::Sample_Li for the three light types
+    Spec Sample_Li(const Light &l, const Interaction &ref, const P2 &u, V3 *wi, Float *pdf, Interaction *pLight) const {
+        if (l.type == LIGHT_POINT) {          // lights/point.cpp:44-53
+            *wi = Normalize(l.pos - ref.p);
+            *pdf = 1.f;
+            pLight->p = l.pos; pLight->pError = V3(); pLight->n = V3();
+            return l.I / DistanceSquared(l.pos, ref.p);
+        } else if (l.type == LIGHT_DISTANT) { // lights/distant.cpp:49-59
+            *wi = l.pos;
+            *pdf = 1;
+            V3 pOutside = ref.p + l.pos * (2 * worldRadius);
+            pLight->p = pOutside; pLight->pError = V3(); pLight->n = V3();
+            return l.I;
+        } else {                              // lights/diffuse.cpp:68-81
+            const ShapeRec &sh = scene.shapes[l.shape];
+            Interaction pShape = SphereSample(scene.spheres[sh.sphereIndex], sh.reverseOrientation != 0, ref, u, pdf);
+            if (*pdf == 0 || (pShape.p - ref.p).LengthSquared() == 0) { *pdf = 0; return 0.f; }
+            *wi = Normalize(pShape.p - ref.p);
+            *pLight = pShape;
+            return AreaL(l, pShape.n, -*wi);
+        }
+    }
+    // Light::Pdf_Li: point/distant 0; area -> Sphere::Pdf (shapes/sphere.cpp:294-306)
+    Float Pdf_Li(const Light &l, const Interaction &ref, const V3 &wi, Counters &ctr) const {
+        if (l.type != LIGHT_AREA) return 0;
+        const ShapeRec &sh = scene.shapes[l.shape];
+        const Sphere &s = scene.spheres[sh.sphereIndex];
+        V3 pCenter = XfPoint(s.o2w, V3(0, 0, 0));
+        V3 pOrigin = OffsetRayOrigin(ref.p, ref.pError, ref.n, pCenter - ref.p);
+        if (DistanceSquared(pOrigin, pCenter) <= s.radius * s.radius) {
+            // Shape::Pdf, core/shape.cpp:72-88
+            Ray ray = SpawnRay(ref.p, ref.pError, ref.n, wi);
+            Float tHit; SurfaceInteraction isectLight;
+            bool flip = (sh.reverseOrientation != 0) ^ (sh.swapsHandedness != 0);
+            if (!SphereIntersect(s, flip, ray, &tHit, &isectLight, ctr)) return 0;
+            Float area = s.phiMax * s.radius * (s.zMax - s.zMin);
+            Float pdf = DistanceSquared(ref.p, isectLight.p) / (AbsDot(isectLight.n, -wi) * area);
+            if (std::isinf(pdf)) pdf = 0.f;
+            return pdf;
+        }
+        Float sinThetaMax2 = s.radius * s.radius / DistanceSquared(ref.p, pCenter);
+        Float cosThetaMax = std::sqrt(smax((Float)0, 1 - sinThetaMax2));
+        return UniformConePdf(cosThetaMax);
+    }
+
+    // core/integrator.cpp:109-217 (surface interactions, handleMedia=false, specular=false)
+    Spec EstimateDirect(const SurfaceInteraction &isect, const BSDF &bsdf, const P2 &uScattering, int lightNum,
+                        const P2 &uLight, Counters &ctr) const {
+        const Light &light = scene.lights[lightNum];
+        const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
+        Spec Ld(0.f);
+        V3 wi;
+        Float lightPdf = 0, scatteringPdf = 0;
+        Interaction it{isect.p, isect.pError, isect.n};
+        Interaction pLight;
+        Spec Li = Sample_Li(light, it, uLight, &wi, &lightPdf, &pLight);
+        bool isDelta = (light.type == LIGHT_POINT || light.type == LIGHT_DISTANT);
+        if (lightPdf > 0 && !Li.IsBlack()) {
+            Spec f = bsdf.f(isect.wo, wi, bsdfFlags) * AbsDot(wi, isect.shading.n);
+            scatteringPdf = bsdf.Pdf(isect.wo, wi, bsdfFlags);
+            if (!f.IsBlack()) {
+                Ray r = SpawnRayTo(it, pLight);     // VisibilityTester::Unoccluded, core/light.cpp:59-64
+                if (SceneIntersectP(r, ctr)) Li = Spec(0.f);
+                if (!Li.IsBlack()) {
+                    if (isDelta) Ld += f * Li / lightPdf;
+                    else {
+                        Float weight = PowerHeuristic(1, lightPdf, 1, scatteringPdf);
+                        Ld += f * Li * weight / lightPdf;
+                    }
+                }
+            }
+        }
+        if (!isDelta) {
+            Spec f;
+            int sampledType = 0;
+            f = bsdf.Sample_f(isect.wo, &wi, uScattering, &scatteringPdf, bsdfFlags, &sampledType);
+            f *= AbsDot(wi, isect.shading.n);
+            bool sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
+            if (!f.IsBlack() && scatteringPdf > 0) {
+                Float weight = 1;
+                if (!sampledSpecular) {
+                    lightPdf = Pdf_Li(light, it, wi, ctr);
+                    if (lightPdf == 0) return Ld;
+                    weight = PowerHeuristic(1, scatteringPdf, 1, lightPdf);
+                }
+                SurfaceInteraction lightIsect;
+                Ray ray = SpawnRay(isect.p, isect.pError, isect.n, wi);
+                bool found = SceneIntersect(ray, &lightIsect, ctr);
+                Spec Li2(0.f);
+                if (found) {
+                    if (scene.shapes[lightIsect.shape].areaLight == lightNum) Li2 = Le(lightIsect, -wi);
+                }   // else light.Le(ray) == 0 for area lights (core/light.cpp:66)
+                if (!Li2.IsBlack()) Ld += f * Li2 * Spec(1.f) * weight / scatteringPdf;
+            }
+        }
+        return Ld;
+    }
+    // core/integrator.cpp:86-107
+    Spec UniformSampleOneLight(const SurfaceInteraction &isect, const BSDF &bsdf, HaltonSampler &sampler,
+                               Counters &ctr) const {
+        int nLights = (int)scene.lights.size();
+        if (nLights == 0) return Spec(0.f);
+        Float lightPdf;
+        int lightNum = lightDistrib.SampleDiscrete(sampler.Get1D(), &lightPdf);
+        if (lightPdf == 0) return Spec(0.f);
+        P2 uLight = sampler.Get2D();
+        P2 uScattering = sampler.Get2D();
+        return EstimateDirect(isect, bsdf, uScattering, lightNum, uLight, ctr) / lightPdf;
+    }
+    // integrators/path.cpp:64-204 (no media, no BSSRDF; every material has a BSDF)
+    Spec Li(const Ray &r, HaltonSampler &sampler, Counters &ctr, int *pathLen = nullptr) const {
+        Spec L(0.f), beta(1.f);
+        Ray ray(r);
+        bool specularBounce = false;
+        int bounces;
+        Float etaScale = 1;
+        const int maxDepth = scene.prm.maxDepth;
+        const Float rrThreshold = scene.prm.rrThreshold;
+        for (bounces = 0;; ++bounces) {
+            SurfaceInteraction isect;
+            bool foundIntersection = SceneIntersect(ray, &isect, ctr);
+            if (bounces == 0 || specularBounce) {
+                if (foundIntersection) L += beta * Le(isect, -ray.d);
+            }
+            if (!foundIntersection || bounces >= maxDepth) break;
+            BSDF bsdf;
+            ComputeScatteringFunctions(scene.materials[scene.shapes[isect.shape].material], isect, &bsdf);
+            if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
+                Spec Ld = beta * UniformSampleOneLight(isect, bsdf, sampler, ctr);
+                L += Ld;
+            }
+            V3 wo = -ray.d, wi;
+            Float pdf = 0;
+            int flags = 0;
+            Spec f = bsdf.Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_ALL, &flags);
+            if (f.IsBlack() || pdf == 0.f) break;
+            beta *= f * AbsDot(wi, isect.shading.n) / pdf;
+            specularBounce = (flags & BSDF_SPECULAR) != 0;
+            ray = SpawnRay(isect.p, isect.pError, isect.n, wi);
+            Spec rrBeta = beta * etaScale;
+            if (rrBeta.MaxComponentValue() < rrThreshold && bounces > 3) {
+                Float q = smax((Float).05, 1 - rrBeta.MaxComponentValue());
+                if (sampler.Get1D() < q) break;
+                beta /= 1 - q;
+            }
+        }
+        if (pathLen) *pathLen = bounces;
+        return L;
+    }
+
+    // One camera sample: core/integrator.cpp:281-333 (minus the film add)
+    Spec RenderSample(HaltonSampler &sampler, int px, int py, P2 *pFilmOut, Float *rayWeightOut, Counters &ctr) const {
+        P2 u = sampler.Get2D();                       // Sampler::GetCameraSample, core/sampler.cpp:46-52
+        P2 pFilm((Float)px + u.x, (Float)py + u.y);
+        Float time = sampler.Get1D(); (void)time;
+        P2 pLens = sampler.Get2D();
+        Ray ray;
+        Float rayWeight = camera.GenerateRay(pFilm, pLens, &ray);
+        ++ctr.cameraRays;
+        Spec L(0.f);
+        if (rayWeight > 0) L = Li(ray, sampler, ctr);
+        if (L.HasNaNs()) L = Spec(0.f);
+        else if (L.y() < -1e-5) L = Spec(0.f);
+        else if (std::isinf(L.y())) L = Spec(0.f);
+        *pFilmOut = pFilm; *rayWeightOut = rayWeight;
+        return L;
+    }
+
+    // SamplerIntegrator::Render, core/integrator.cpp:230-360.  spp<=0 uses the scene's.
+    void Render(int sppOverride = 0) {
+        int spp = sppOverride > 0 ? sppOverride : scene.prm.spp;
+        int sx0, sy0, sx1, sy1;
+        film.GetSampleBounds(&sx0, &sy0, &sx1, &sy1);
+        for (auto &p : film.pixels) p = FilmPixel();
+        const int tileSize = 16;
+        int ntx = (sx1 - sx0 + tileSize - 1) / tileSize, nty = (sy1 - sy0 + tileSize - 1) / tileSize;
+        std::atomic<int> next(0);
+        total = Counters();
+        std::mutex cmutex;
+        auto t0 = std::chrono::high_resolution_clock::now();
+        auto worker = [&]() {
+            Counters ctr;
+            HaltonSampler sampler(spp, sx0, sy0, sx1, sy1, scene.prm.samplePixelCenter != 0);
+            while (true) {
+                int t = next.fetch_add(1);
+                if (t >= ntx * nty) break;
+                int tx = t % ntx, ty = t / ntx;
+                int x0 = sx0 + tx * tileSize, x1 = smin(x0 + tileSize, sx1);
+                int y0 = sy0 + ty * tileSize, y1 = smin(y0 + tileSize, sy1);
+                FilmTile tile(&film, x0, y0, x1, y1);
+                for (int y = y0; y < y1; ++y)
+                    for (int x = x0; x < x1; ++x) {
+                        sampler.StartPixel(x, y);
+                        // pixelBounds == sample bounds for PathIntegrator without "pixelbounds" (path.cpp:212)
+                        do {
+                            P2 pFilm; Float w;
+                            Spec L = RenderSample(sampler, x, y, &pFilm, &w, ctr);
+                            tile.AddSample(pFilm, L, w);
+                        } while (sampler.StartNextSample());
+                    }
+                MergeFilmTile(&film, tile);
+            }
+            std::lock_guard<std::mutex> lk(cmutex);
+            total.add(ctr);
+        };
+        std::vector<std::thread> th;
+        for (int i = 1; i < nThreads; ++i) th.emplace_back(worker);
+        worker();
+        for (auto &t : th) t.join();
+        renderSeconds = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    }
+};
+
+}  // namespace orc

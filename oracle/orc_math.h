@@ -1,0 +1,403 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+// CPU restatement of the reference's arithmetic for the hot path
+// (SamplerIntegrator::Render -> PathIntegrator::Li -> BVHAccel::Intersect ->
+// Triangle::Intersect).  Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may build, link or call anything in this directory.  The
+// product (thesis-pbrt-v3_amd/) never includes these files.
+//
+// Each function cites the reference file:line it follows
+// (paths relative to /root/reference/src).
+//
+// Floating-point contract: built with g++ -O2 -ffp-contract=off, x86-64 SSE2
+// (no FMA), so every +,-,*,/ and sqrt is a single IEEE-754 rounding, exactly
+// like the reference's own g++ build.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+
+namespace orc {
+
+typedef float Float;
+
+// core/pbrt.h:193-210
+static const Float Infinity = std::numeric_limits<Float>::infinity();
+static const Float MachineEpsilon = std::numeric_limits<Float>::epsilon() * 0.5;
+static const Float ShadowEpsilon = 0.0001f;
+static const Float Pi = 3.14159265358979323846;
+static const Float InvPi = 0.31830988618379067154;
+static const Float Inv2Pi = 0.15915494309189533577;
+static const Float Inv4Pi = 0.07957747154594766788;
+static const Float PiOver2 = 1.57079632679489661923;
+static const Float PiOver4 = 0.78539816339744830961;
+static const Float Sqrt2 = 1.41421356237309504880;
+// core/rng.h:49-58
+static const Float OneMinusEpsilon = 0x1.fffffep-1;
+
+// std::min / std::max with libstdc++ semantics (b<a ? b : a / a<b ? b : a);
+// NaN behaviour must match, so no fminf/fmaxf.
+template <typename T> inline T smin(T a, T b) { return (b < a) ? b : a; }
+template <typename T> inline T smax(T a, T b) { return (a < b) ? b : a; }
+
+// core/pbrt.h:289-291
+inline Float gamma(int n) { return (n * MachineEpsilon) / (1 - n * MachineEpsilon); }
+
+// core/pbrt.h:213-239
+inline uint32_t FloatToBits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float BitsToFloat(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+// core/pbrt.h:241-265
+inline float NextFloatUp(float v) {
+    if (std::isinf(v) && v > 0.) return v;
+    if (v == -0.f) v = 0.f;
+    uint32_t ui = FloatToBits(v);
+    if (v >= 0) ++ui; else --ui;
+    return BitsToFloat(ui);
+}
+inline float NextFloatDown(float v) {
+    if (std::isinf(v) && v < 0.) return v;
+    if (v == 0.f) v = -0.f;
+    uint32_t ui = FloatToBits(v);
+    if (v > 0) --ui; else ++ui;
+    return BitsToFloat(ui);
+}
+// core/pbrt.h Clamp
+template <typename T, typename U, typename V>
+inline T Clamp(T val, U low, V high) {
+    if (val < low) return low;
+    else if (val > high) return high;
+    else return val;
+}
+inline Float Radians(Float deg) { return (Pi / 180) * deg; }
+inline Float Lerp(Float t, Float v1, Float v2) { return (1 - t) * v1 + t * v2; }
+
+// ---------------------------------------------------------------------------
+// Deterministic transcendental functions ("detmath").
+// The reference calls glibc's sinf/cosf/atan2f/acosf (float) and sin/cos
+// (double).  libm results cannot be reproduced bit-for-bit on the GPU, so the
+// oracle offers two modes: g_use_libm=true follows the reference literally
+// (glibc), false uses these functions, which are built from IEEE-exact double
+// operations only and are restated operation for operation in the HIP path.
+// The float versions are (float)det_xxx((double)x): correctly rounded except
+// for ~1e-8 of arguments.
+// ---------------------------------------------------------------------------
+extern bool g_use_libm;
+
+namespace det {
+// pi/2 split into three parts with 33 significant bits each, so k*PIO2_x is
+// exact in double for |k| < 2^20.
+static const double PIO2_1 = 1.57079632673412561417e+00;   // 0x3FF921FB54400000
+static const double PIO2_2 = 6.07710050630396597660e-11;   // 0x3DD0B4611A600000
+static const double PIO2_3 = 2.02226624871116645580e-21;   // 0x3BA3198A2E000000
+static const double PIO2_3T = 8.47842766036889956997e-32;  // 0x397B839A252049C1
+static const double INV_PIO2 = 6.36619772367581382433e-01; // 0x3FE45F306DC9C883
+
+// sin(r), |r| <= pi/4 (+slack): odd Taylor polynomial through r^19.
+inline double ksin(double r) {
+    double z = r * r;
+    double p = -8.22063524662432971696e-18;                 // -1/19!
+    p = p * z + 2.81145725434552076320e-15;                  //  1/17!
+    p = p * z + -7.64716373181981647590e-13;                 // -1/15!
+    p = p * z + 1.60590438368216145994e-10;                  //  1/13!
+    p = p * z + -2.50521083854417187751e-08;                 // -1/11!
+    p = p * z + 2.75573192239858906526e-06;                  //  1/9!
+    p = p * z + -1.98412698412698412698e-04;                 // -1/7!
+    p = p * z + 8.33333333333333333333e-03;                  //  1/5!
+    p = p * z + -1.66666666666666666667e-01;                 // -1/3!
+    return r + r * (z * p);
+}
+// cos(r), |r| <= pi/4 (+slack): even Taylor polynomial through r^20.
+inline double kcos(double r) {
+    double z = r * r;
+    double p = 4.11031762331216485848e-19;                   //  1/20!
+    p = p * z + -1.56192069685862264622e-16;                 // -1/18!
+    p = p * z + 4.77947733238738529744e-14;                  //  1/16!
+    p = p * z + -1.14707455977297247139e-11;                 // -1/14!
+    p = p * z + 2.08767569878680989792e-09;                  //  1/12!
+    p = p * z + -2.75573192239858906526e-07;                 // -1/10!
+    p = p * z + 2.48015873015873015873e-05;                  //  1/8!
+    p = p * z + -1.38888888888888888889e-03;                 // -1/6!
+    p = p * z + 4.16666666666666666667e-02;                  //  1/4!
+    p = p * z + -5.00000000000000000000e-01;                 // -1/2!
+    return 1.0 + z * p;
+}
+// Argument reduction: x = k*pi/2 + r, valid for |x| < ~1e6.
+inline int reduce(double x, double *r) {
+    double fk = x * INV_PIO2;
+    long long k = (long long)(fk + (fk >= 0 ? 0.5 : -0.5));
+    double dk = (double)k;
+    double t = x - dk * PIO2_1;
+    t = t - dk * PIO2_2;
+    t = t - dk * PIO2_3;
+    t = t - dk * PIO2_3T;
+    *r = t;
+    return (int)(k & 3);
+}
+inline double sin_d(double x) {
+    double r; int q = reduce(x, &r);
+    switch (q) {
+    case 0: return ksin(r);
+    case 1: return kcos(r);
+    case 2: return -ksin(r);
+    default: return -kcos(r);
+    }
+}
+inline double cos_d(double x) {
+    double r; int q = reduce(x, &r);
+    switch (q) {
+    case 0: return kcos(r);
+    case 1: return -ksin(r);
+    case 2: return -kcos(r);
+    default: return ksin(r);
+    }
+}
+// atan(t) for 0 <= t: two-step range reduction + odd Taylor series.
+inline double atan_pos(double t) {
+    const double PIO2 = 1.57079632679489661923, PIO4 = 0.78539816339744830962;
+    double base = 0.0; bool inv = false;
+    if (t > 1.0) { t = 1.0 / t; inv = true; }
+    if (t > 0.41421356237309504880) { base = PIO4; t = (t - 1.0) / (t + 1.0); }
+    double z = t * t;
+    // atan(t)/t = sum_{n=0}^{22} (-z)^n/(2n+1), Horner from the top:
+    // p_22 = 1/45, p_n = 1/(2n+1) - z*p_{n+1}
+    double p = 1.0 / 45.0;
+    for (int n = 21; n >= 0; --n) {
+        double c = 1.0 / (double)(2 * n + 1);
+        p = c - z * p;
+    }
+    double a = base + t * p;
+    return inv ? (PIO2 - a) : a;
+}
+inline double atan2_d(double y, double x) {
+    const double PI = 3.14159265358979323846, PIO2 = 1.57079632679489661923;
+    if (x == 0.0) {
+        if (y == 0.0) return 0.0;
+        return y > 0 ? PIO2 : -PIO2;
+    }
+    double a = atan_pos(std::fabs(y) / std::fabs(x));
+    if (x < 0) a = PI - a;
+    return (y < 0) ? -a : a;
+}
+inline double acos_d(double x) {
+    // acos(x) = 2*atan( sqrt((1-x)/(1+x)) ), x in (-1,1]
+    const double PI = 3.14159265358979323846;
+    if (x <= -1.0) return PI;
+    if (x >= 1.0) return 0.0;
+    return 2.0 * atan_pos(std::sqrt((1.0 - x) / (1.0 + x)));
+}
+}  // namespace det
+
+// float-argument versions, as std::sin(float) etc. in the reference.
+inline float m_sinf(float x) { return g_use_libm ? std::sin(x) : (float)det::sin_d((double)x); }
+inline float m_cosf(float x) { return g_use_libm ? std::cos(x) : (float)det::cos_d((double)x); }
+inline float m_atan2f(float y, float x) { return g_use_libm ? std::atan2(y, x) : (float)det::atan2_d((double)y, (double)x); }
+inline float m_acosf(float x) { return g_use_libm ? std::acos(x) : (float)det::acos_d((double)x); }
+// double-argument versions: unqualified sin()/cos() in core/microfacet.cpp:241-246
+// resolve to ::sin(double)/::cos(double) under libstdc++ <cmath>.
+inline double m_sin(double x) { return g_use_libm ? ::sin(x) : det::sin_d(x); }
+inline double m_cos(double x) { return g_use_libm ? ::cos(x) : det::cos_d(x); }
+
+// ---------------------------------------------------------------------------
+// Vectors (core/geometry.h).  One struct serves Vector3f/Point3f/Normal3f:
+// the reference's three classes have identical arithmetic for the operations
+// used here.
+// ---------------------------------------------------------------------------
+struct V3 {
+    Float x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    V3(Float x, Float y, Float z) : x(x), y(y), z(z) {}
+    Float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+    Float &operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }
+    V3 operator+(const V3 &v) const { return V3(x + v.x, y + v.y, z + v.z); }
+    V3 &operator+=(const V3 &v) { x += v.x; y += v.y; z += v.z; return *this; }
+    V3 operator-(const V3 &v) const { return V3(x - v.x, y - v.y, z - v.z); }
+    V3 operator-() const { return V3(-x, -y, -z); }
+    V3 operator*(Float s) const { return V3(s * x, s * y, s * z); }
+    V3 &operator*=(Float s) { x *= s; y *= s; z *= s; return *this; }
+    // geometry.h:281-286: division multiplies by a float reciprocal
+    V3 operator/(Float f) const { Float inv = (Float)1 / f; return V3(x * inv, y * inv, z * inv); }
+    V3 &operator/=(Float f) { Float inv = (Float)1 / f; x *= inv; y *= inv; z *= inv; return *this; }
+    Float LengthSquared() const { return x * x + y * y + z * z; }
+    Float Length() const { return std::sqrt(LengthSquared()); }
+    bool operator==(const V3 &v) const { return x == v.x && y == v.y && z == v.z; }
+};
+inline V3 operator*(Float s, const V3 &v) { return v * s; }
+inline Float Dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline Float AbsDot(const V3 &a, const V3 &b) { return std::abs(Dot(a, b)); }
+inline V3 Abs(const V3 &v) { return V3(std::abs(v.x), std::abs(v.y), std::abs(v.z)); }
+// geometry.h:1287-1321: Cross in double, one rounding to float
+inline V3 Cross(const V3 &v1, const V3 &v2) {
+    double v1x = v1.x, v1y = v1.y, v1z = v1.z;
+    double v2x = v2.x, v2y = v2.y, v2z = v2.z;
+    return V3((Float)((v1y * v2z) - (v1z * v2y)), (Float)((v1z * v2x) - (v1x * v2z)),
+              (Float)((v1x * v2y) - (v1y * v2x)));
+}
+inline V3 Normalize(const V3 &v) { return v / v.Length(); }
+inline Float Distance(const V3 &a, const V3 &b) { return (a - b).Length(); }
+inline Float DistanceSquared(const V3 &a, const V3 &b) { return (a - b).LengthSquared(); }
+inline Float MaxComponent(const V3 &v) { return smax(v.x, smax(v.y, v.z)); }
+inline int MaxDimension(const V3 &v) {
+    return (v.x > v.y) ? ((v.x > v.z) ? 0 : 2) : ((v.y > v.z) ? 1 : 2);
+}
+inline V3 Permute(const V3 &v, int x, int y, int z) { return V3(v[x], v[y], v[z]); }
+inline V3 Min(const V3 &a, const V3 &b) { return V3(smin(a.x, b.x), smin(a.y, b.y), smin(a.z, b.z)); }
+inline V3 Max(const V3 &a, const V3 &b) { return V3(smax(a.x, b.x), smax(a.y, b.y), smax(a.z, b.z)); }
+inline V3 Faceforward(const V3 &n, const V3 &v) { return (Dot(n, v) < 0.f) ? -n : n; }
+// geometry.h:1360-1367
+inline void CoordinateSystem(const V3 &v1, V3 *v2, V3 *v3) {
+    if (std::abs(v1.x) > std::abs(v1.y))
+        *v2 = V3(-v1.z, 0, v1.x) / std::sqrt(v1.x * v1.x + v1.z * v1.z);
+    else
+        *v2 = V3(0, v1.z, -v1.y) / std::sqrt(v1.y * v1.y + v1.z * v1.z);
+    *v3 = Cross(v1, *v2);
+}
+// geometry.h:1782-1802
+inline V3 OffsetRayOrigin(const V3 &p, const V3 &pError, const V3 &n, const V3 &w) {
+    Float d = Dot(Abs(n), pError);
+    V3 offset = d * n;
+    if (Dot(w, n) < 0) offset = -offset;
+    V3 po = p + offset;
+    for (int i = 0; i < 3; ++i) {
+        if (offset[i] > 0) po[i] = NextFloatUp(po[i]);
+        else if (offset[i] < 0) po[i] = NextFloatDown(po[i]);
+    }
+    return po;
+}
+// geometry.h:1804-1814
+inline V3 SphericalDirection(Float sinTheta, Float cosTheta, Float phi) {
+    return V3(sinTheta * m_cosf(phi), sinTheta * m_sinf(phi), cosTheta);
+}
+inline V3 SphericalDirection(Float sinTheta, Float cosTheta, Float phi, const V3 &x,
+                             const V3 &y, const V3 &z) {
+    return sinTheta * m_cosf(phi) * x + sinTheta * m_sinf(phi) * y + cosTheta * z;
+}
+
+struct P2 { Float x, y; P2() : x(0), y(0) {} P2(Float x, Float y) : x(x), y(y) {} };
+
+// RGBSpectrum (core/spectrum.h:430-466)
+struct Spec {
+    Float c[3];
+    Spec(Float v = 0.f) { c[0] = c[1] = c[2] = v; }
+    Spec(Float r, Float g, Float b) { c[0] = r; c[1] = g; c[2] = b; }
+    Spec operator+(const Spec &s) const { return Spec(c[0] + s.c[0], c[1] + s.c[1], c[2] + s.c[2]); }
+    Spec &operator+=(const Spec &s) { c[0] += s.c[0]; c[1] += s.c[1]; c[2] += s.c[2]; return *this; }
+    Spec operator*(const Spec &s) const { return Spec(c[0] * s.c[0], c[1] * s.c[1], c[2] * s.c[2]); }
+    Spec &operator*=(const Spec &s) { c[0] *= s.c[0]; c[1] *= s.c[1]; c[2] *= s.c[2]; return *this; }
+    Spec operator*(Float a) const { return Spec(c[0] * a, c[1] * a, c[2] * a); }
+    Spec &operator*=(Float a) { c[0] *= a; c[1] *= a; c[2] *= a; return *this; }
+    // spectrum.h:181-193: true division per channel
+    Spec operator/(Float a) const { return Spec(c[0] / a, c[1] / a, c[2] / a); }
+    Spec &operator/=(Float a) { c[0] /= a; c[1] /= a; c[2] /= a; return *this; }
+    bool IsBlack() const { return c[0] == 0 && c[1] == 0 && c[2] == 0; }
+    bool HasNaNs() const { return std::isnan(c[0]) || std::isnan(c[1]) || std::isnan(c[2]); }
+    Float MaxComponentValue() const { Float m = c[0]; for (int i = 1; i < 3; ++i) m = smax(m, c[i]); return m; }
+    Float y() const { return 0.212671f * c[0] + 0.715160f * c[1] + 0.072169f * c[2]; }
+    Spec Clamp(Float low = 0, Float high = Infinity) const {
+        return Spec(orc::Clamp(c[0], low, high), orc::Clamp(c[1], low, high), orc::Clamp(c[2], low, high));
+    }
+};
+inline Spec operator*(Float a, const Spec &s) { return s * a; }
+// spectrum.h:56-66
+inline void XYZToRGB(const Float xyz[3], Float rgb[3]) {
+    rgb[0] = 3.240479f * xyz[0] - 1.537150f * xyz[1] - 0.498535f * xyz[2];
+    rgb[1] = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
+    rgb[2] = 0.055648f * xyz[0] - 0.204043f * xyz[1] + 1.057311f * xyz[2];
+}
+inline void RGBToXYZ(const Float rgb[3], Float xyz[3]) {
+    xyz[0] = 0.412453f * rgb[0] + 0.357580f * rgb[1] + 0.180423f * rgb[2];
+    xyz[1] = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];
+    xyz[2] = 0.019334f * rgb[0] + 0.119193f * rgb[1] + 0.950227f * rgb[2];
+}
+
+// Bounds3f (core/geometry.h:905-1000)
+struct B3 {
+    V3 pMin, pMax;
+    B3() {
+        Float minNum = std::numeric_limits<Float>::lowest();
+        Float maxNum = std::numeric_limits<Float>::max();
+        pMin = V3(maxNum, maxNum, maxNum);
+        pMax = V3(minNum, minNum, minNum);
+    }
+    B3(const V3 &p1, const V3 &p2) : pMin(Min(p1, p2)), pMax(Max(p1, p2)) {}
+    const V3 &operator[](int i) const { return i == 0 ? pMin : pMax; }
+    V3 Diagonal() const { return pMax - pMin; }
+    Float SurfaceArea() const { V3 d = Diagonal(); return 2 * (d.x * d.y + d.x * d.z + d.y * d.z); }
+};
+inline B3 Union(const B3 &b, const V3 &p) { B3 r; r.pMin = Min(b.pMin, p); r.pMax = Max(b.pMax, p); return r; }
+inline B3 Union(const B3 &a, const B3 &b) { B3 r; r.pMin = Min(a.pMin, b.pMin); r.pMax = Max(a.pMax, b.pMax); return r; }
+
+// 4x4 transform applied as in core/transform.h:220-262
+struct M44 { Float m[4][4]; };
+inline V3 XfPoint(const M44 &M, const V3 &p) {
+    Float x = p.x, y = p.y, z = p.z;
+    Float xp = M.m[0][0] * x + M.m[0][1] * y + M.m[0][2] * z + M.m[0][3];
+    Float yp = M.m[1][0] * x + M.m[1][1] * y + M.m[1][2] * z + M.m[1][3];
+    Float zp = M.m[2][0] * x + M.m[2][1] * y + M.m[2][2] * z + M.m[2][3];
+    Float wp = M.m[3][0] * x + M.m[3][1] * y + M.m[3][2] * z + M.m[3][3];
+    if (wp == 1) return V3(xp, yp, zp);
+    else return V3(xp, yp, zp) / wp;
+}
+inline V3 XfVector(const M44 &M, const V3 &v) {
+    Float x = v.x, y = v.y, z = v.z;
+    return V3(M.m[0][0] * x + M.m[0][1] * y + M.m[0][2] * z,
+              M.m[1][0] * x + M.m[1][1] * y + M.m[1][2] * z,
+              M.m[2][0] * x + M.m[2][1] * y + M.m[2][2] * z);
+}
+// Normal transform uses the inverse's transpose (transform.h:237-243)
+inline V3 XfNormal(const M44 &Minv, const V3 &n) {
+    Float x = n.x, y = n.y, z = n.z;
+    return V3(Minv.m[0][0] * x + Minv.m[1][0] * y + Minv.m[2][0] * z,
+              Minv.m[0][1] * x + Minv.m[1][1] * y + Minv.m[2][1] * z,
+              Minv.m[0][2] * x + Minv.m[1][2] * y + Minv.m[2][2] * z);
+}
+// transform.h:277-296
+inline V3 XfPointErr(const M44 &M, const V3 &p, V3 *pError) {
+    Float x = p.x, y = p.y, z = p.z;
+    Float xp = M.m[0][0] * x + M.m[0][1] * y + M.m[0][2] * z + M.m[0][3];
+    Float yp = M.m[1][0] * x + M.m[1][1] * y + M.m[1][2] * z + M.m[1][3];
+    Float zp = M.m[2][0] * x + M.m[2][1] * y + M.m[2][2] * z + M.m[2][3];
+    Float wp = M.m[3][0] * x + M.m[3][1] * y + M.m[3][2] * z + M.m[3][3];
+    Float xAbsSum = (std::abs(M.m[0][0] * x) + std::abs(M.m[0][1] * y) + std::abs(M.m[0][2] * z) + std::abs(M.m[0][3]));
+    Float yAbsSum = (std::abs(M.m[1][0] * x) + std::abs(M.m[1][1] * y) + std::abs(M.m[1][2] * z) + std::abs(M.m[1][3]));
+    Float zAbsSum = (std::abs(M.m[2][0] * x) + std::abs(M.m[2][1] * y) + std::abs(M.m[2][2] * z) + std::abs(M.m[2][3]));
+    *pError = gamma(3) * V3(xAbsSum, yAbsSum, zAbsSum);
+    if (wp == 1) return V3(xp, yp, zp);
+    else return V3(xp, yp, zp) / wp;
+}
+// transform.h:298-328 (point with incoming error)
+inline V3 XfPointErr2(const M44 &M, const V3 &pt, const V3 &ptError, V3 *absError) {
+    Float x = pt.x, y = pt.y, z = pt.z;
+    Float xp = M.m[0][0] * x + M.m[0][1] * y + M.m[0][2] * z + M.m[0][3];
+    Float yp = M.m[1][0] * x + M.m[1][1] * y + M.m[1][2] * z + M.m[1][3];
+    Float zp = M.m[2][0] * x + M.m[2][1] * y + M.m[2][2] * z + M.m[2][3];
+    Float wp = M.m[3][0] * x + M.m[3][1] * y + M.m[3][2] * z + M.m[3][3];
+    absError->x = (gamma(3) + (Float)1) * (std::abs(M.m[0][0]) * ptError.x + std::abs(M.m[0][1]) * ptError.y + std::abs(M.m[0][2]) * ptError.z) +
+                  gamma(3) * (std::abs(M.m[0][0] * x) + std::abs(M.m[0][1] * y) + std::abs(M.m[0][2] * z) + std::abs(M.m[0][3]));
+    absError->y = (gamma(3) + (Float)1) * (std::abs(M.m[1][0]) * ptError.x + std::abs(M.m[1][1]) * ptError.y + std::abs(M.m[1][2]) * ptError.z) +
+                  gamma(3) * (std::abs(M.m[1][0] * x) + std::abs(M.m[1][1] * y) + std::abs(M.m[1][2] * z) + std::abs(M.m[1][3]));
+    absError->z = (gamma(3) + (Float)1) * (std::abs(M.m[2][0]) * ptError.x + std::abs(M.m[2][1]) * ptError.y + std::abs(M.m[2][2]) * ptError.z) +
+                  gamma(3) * (std::abs(M.m[2][0] * x) + std::abs(M.m[2][1] * y) + std::abs(M.m[2][2] * z) + std::abs(M.m[2][3]));
+    if (wp == 1.) return V3(xp, yp, zp);
+    else return V3(xp, yp, zp) / wp;
+}
+// transform.h:330-347
+inline V3 XfVectorErr(const M44 &M, const V3 &v, V3 *absError) {
+    Float x = v.x, y = v.y, z = v.z;
+    absError->x = gamma(3) * (std::abs(M.m[0][0] * v.x) + std::abs(M.m[0][1] * v.y) + std::abs(M.m[0][2] * v.z));
+    absError->y = gamma(3) * (std::abs(M.m[1][0] * v.x) + std::abs(M.m[1][1] * v.y) + std::abs(M.m[1][2] * v.z));
+    absError->z = gamma(3) * (std::abs(M.m[2][0] * v.x) + std::abs(M.m[2][1] * v.y) + std::abs(M.m[2][2] * v.z));
+    return V3(M.m[0][0] * x + M.m[0][1] * y + M.m[0][2] * z,
+              M.m[1][0] * x + M.m[1][1] * y + M.m[1][2] * z,
+              M.m[2][0] * x + M.m[2][1] * y + M.m[2][2] * z);
+}
+
+// Ray (core/geometry.h:1176-1203): tMax is mutable in the reference.
+struct Ray {
+    V3 o, d;
+    mutable Float tMax;
+    Ray() : tMax(Infinity) {}
+    Ray(const V3 &o, const V3 &d, Float tMax = Infinity) : o(o), d(d), tMax(tMax) {}
+    V3 operator()(Float t) const { return o + d * t; }
+};
+
+}  // namespace orc

@@ -1,0 +1,152 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).
+// In-memory scene + reader for the baked scene container ("HPRTSCN1", layout
+// documented in DESIGN.md §Baked scene).  The container holds the post-parse,
+// world-space scene exactly as the reference's MakeScene() would hand it to
+// BVHAccel (core/api.cpp:1883-1892): shapes in creation order, world-space
+// mesh vertices (shapes/triangle.cpp:72-88), materials, lights, camera.
+#pragma once
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "orc_math.h"
+
+namespace orc {
+
+enum { MAT_MATTE = 0, MAT_PLASTIC = 1 };
+enum { LIGHT_POINT = 0, LIGHT_DISTANT = 1, LIGHT_AREA = 2 };
+enum { SHAPE_MESH = 0, SHAPE_SPHERE = 1 };
+
+struct Material {
+    int type;
+    Float Kd[3]; Float sigma; Float Ks[3]; Float roughness; int remap;
+};
+struct Mesh {
+    uint32_t nTris, nVerts;
+    bool hasN, hasUV, hasS;
+    std::vector<int> idx;
+    std::vector<V3> p, n, s;
+    std::vector<P2> uv;
+};
+struct Sphere {
+    M44 o2w, w2o;
+    Float radius, zMin, zMax, thetaMin, thetaMax, phiMax;
+};
+struct ShapeRec {
+    int kind, material, areaLight, reverseOrientation, swapsHandedness;
+    int meshIndex, sphereIndex;   // into Scene::meshes / spheres
+    uint32_t firstPrim, nPrims;   // range in creation-order primitive numbering
+};
+struct Light {
+    int type;
+    V3 pos;      // point: pLight (world); distant: wLight (normalised, world)
+    Spec I;      // point: I; distant: L; area: Lemit
+    int shape;   // area: shape index
+    int twoSided;
+};
+struct SceneParams {
+    int xres, yres;
+    Float crop[4];            // x0 x1 y0 y1
+    Float filterRadius[2]; int filterType;
+    Float filmScale, maxSampleLuminance;
+    Float fov, lensRadius, focalDistance, screenWindow[4], shutterOpen, shutterClose;
+    M44 camToWorld, worldToCam;
+    int spp, samplePixelCenter;
+    int maxDepth; Float rrThreshold; int lightStrategy;
+    int maxNodePrims, isectCost, travCost;
+};
+// One entry per primitive in creation order (what the reference's
+// renderOptions->primitives holds, core/api.cpp:1641-1649)
+struct PrimRef { int shape; int local; };
+
+struct Scene {
+    SceneParams prm;
+    std::vector<Material> materials;
+    std::vector<ShapeRec> shapes;
+    std::vector<Mesh> meshes;
+    std::vector<Sphere> spheres;
+    std::vector<Light> lights;
+    std::vector<PrimRef> prims;
+};
+
+struct Reader {
+    FILE *f; bool ok;
+    explicit Reader(const char *path) : f(fopen(path, "rb")), ok(f != nullptr) {}
+    ~Reader() { if (f) fclose(f); }
+    void raw(void *dst, size_t n) { if (ok && fread(dst, 1, n, f) != n) ok = false; }
+    int32_t i32() { int32_t v = 0; raw(&v, 4); return v; }
+    uint32_t u32() { uint32_t v = 0; raw(&v, 4); return v; }
+    float f32() { float v = 0; raw(&v, 4); return v; }
+};
+
+inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
+    Reader r(path);
+    if (!r.ok) { *err = std::string("cannot open ") + path; return false; }
+    char magic[8]; r.raw(magic, 8);
+    if (!r.ok || memcmp(magic, "HPRTSCN1", 8) != 0) { *err = "bad magic"; return false; }
+    uint32_t version = r.u32();
+    if (version != 1) { *err = "bad version"; return false; }
+    SceneParams &p = sc->prm;
+    p.xres = r.i32(); p.yres = r.i32();
+    for (int i = 0; i < 4; ++i) p.crop[i] = r.f32();
+    p.filterRadius[0] = r.f32(); p.filterRadius[1] = r.f32(); p.filterType = r.i32();
+    p.filmScale = r.f32(); p.maxSampleLuminance = r.f32();
+    p.fov = r.f32(); p.lensRadius = r.f32(); p.focalDistance = r.f32();
+    for (int i = 0; i < 4; ++i) p.screenWindow[i] = r.f32();
+    p.shutterOpen = r.f32(); p.shutterClose = r.f32();
+    r.raw(p.camToWorld.m, 64); r.raw(p.worldToCam.m, 64);
+    p.spp = r.i32(); p.samplePixelCenter = r.i32();
+    p.maxDepth = r.i32(); p.rrThreshold = r.f32(); p.lightStrategy = r.i32();
+    p.maxNodePrims = r.i32(); p.isectCost = r.i32(); p.travCost = r.i32();
+    uint32_t nMat = r.u32(), nShapes = r.u32(), nLights = r.u32();
+    if (!r.ok) { *err = "truncated header"; return false; }
+    sc->materials.resize(nMat);
+    for (auto &m : sc->materials) {
+        m.type = r.i32(); r.raw(m.Kd, 12); m.sigma = r.f32(); r.raw(m.Ks, 12);
+        m.roughness = r.f32(); m.remap = r.i32();
+    }
+    sc->shapes.resize(nShapes);
+    uint32_t primCount = 0;
+    for (uint32_t si = 0; si < nShapes; ++si) {
+        ShapeRec &s = sc->shapes[si];
+        s.kind = r.i32(); s.material = r.i32(); s.areaLight = r.i32();
+        s.reverseOrientation = r.i32(); s.swapsHandedness = r.i32();
+        s.meshIndex = s.sphereIndex = -1;
+        s.firstPrim = primCount;
+        if (s.kind == SHAPE_MESH) {
+            Mesh m;
+            m.nTris = r.u32(); m.nVerts = r.u32();
+            uint32_t flags = r.u32();
+            m.hasN = flags & 1; m.hasUV = flags & 2; m.hasS = flags & 4;
+            if (!r.ok || m.nTris > (1u << 28) || m.nVerts > (1u << 28)) { *err = "bad mesh"; return false; }
+            m.idx.resize(3 * (size_t)m.nTris); r.raw(m.idx.data(), 12 * (size_t)m.nTris);
+            m.p.resize(m.nVerts); r.raw(m.p.data(), 12 * (size_t)m.nVerts);
+            if (m.hasN) { m.n.resize(m.nVerts); r.raw(m.n.data(), 12 * (size_t)m.nVerts); }
+            if (m.hasUV) { m.uv.resize(m.nVerts); r.raw(m.uv.data(), 8 * (size_t)m.nVerts); }
+            if (m.hasS) { m.s.resize(m.nVerts); r.raw(m.s.data(), 12 * (size_t)m.nVerts); }
+            s.meshIndex = (int)sc->meshes.size();
+            s.nPrims = m.nTris;
+            sc->meshes.push_back(std::move(m));
+        } else if (s.kind == SHAPE_SPHERE) {
+            Sphere sp;
+            r.raw(sp.o2w.m, 64); r.raw(sp.w2o.m, 64);
+            sp.radius = r.f32(); sp.zMin = r.f32(); sp.zMax = r.f32();
+            sp.thetaMin = r.f32(); sp.thetaMax = r.f32(); sp.phiMax = r.f32();
+            s.sphereIndex = (int)sc->spheres.size();
+            s.nPrims = 1;
+            sc->spheres.push_back(sp);
+        } else { *err = "bad shape kind"; return false; }
+        for (uint32_t k = 0; k < s.nPrims; ++k) sc->prims.push_back(PrimRef{(int)si, (int)k});
+        primCount += s.nPrims;
+    }
+    sc->lights.resize(nLights);
+    for (auto &l : sc->lights) {
+        l.type = r.i32();
+        float a[3]; r.raw(a, 12); l.pos = V3(a[0], a[1], a[2]);
+        float b[3]; r.raw(b, 12); l.I = Spec(b[0], b[1], b[2]);
+        l.shape = r.i32(); l.twoSided = r.i32();
+    }
+    if (!r.ok) { *err = "truncated file"; return false; }
+    return true;
+}
+
+}  // namespace orc

@@ -1,0 +1,365 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).
+// BSDFs, materials and lights of the bundled scenes:
+// core/reflection.{h,cpp}, core/microfacet.{h,cpp}, materials/{matte,plastic}.cpp,
+// lights/{point,distant,diffuse}.cpp, shapes/sphere.cpp (sampling), core/sampling.{h,cpp}.
+#pragma once
+#include "orc_accel.h"
+
+namespace orc {
+
+// core/sampling.cpp:113-130
+inline P2 ConcentricSampleDisk(const P2 &u) {
+    P2 uOffset(2.f * u.x - 1, 2.f * u.y - 1);
+    if (uOffset.x == 0 && uOffset.y == 0) return P2(0, 0);
+    Float theta, r;
+    if (std::abs(uOffset.x) > std::abs(uOffset.y)) {
+        r = uOffset.x;
+        theta = PiOver4 * (uOffset.y / uOffset.x);
+    } else {
+        r = uOffset.y;
+        theta = PiOver2 - PiOver4 * (uOffset.x / uOffset.y);
+    }
+    return P2(r * m_cosf(theta), r * m_sinf(theta));
+}
+// core/sampling.h:159-163
+inline V3 CosineSampleHemisphere(const P2 &u) {
+    P2 d = ConcentricSampleDisk(u);
+    Float z = std::sqrt(smax((Float)0, 1 - d.x * d.x - d.y * d.y));
+    return V3(d.x, d.y, z);
+}
+// core/sampling.cpp:98-103
+inline V3 UniformSampleSphere(const P2 &u) {
+    Float z = 1 - 2 * u.x;
+    Float r = std::sqrt(smax((Float)0, (Float)1 - z * z));
+    Float phi = 2 * Pi * u.y;
+    return V3(r * m_cosf(phi), r * m_sinf(phi), z);
+}
+inline Float UniformConePdf(Float cosThetaMax) { return 1 / (2 * Pi * (1 - cosThetaMax)); }
+// core/sampling.h:171-174
+inline Float PowerHeuristic(int nf, Float fPdf, int ng, Float gPdf) {
+    Float f = nf * fPdf, g = ng * gPdf;
+    return (f * f) / (f * f + g * g);
+}
+
+// core/reflection.h:56-122
+inline Float CosTheta(const V3 &w) { return w.z; }
+inline Float Cos2Theta(const V3 &w) { return w.z * w.z; }
+inline Float AbsCosTheta(const V3 &w) { return std::abs(w.z); }
+inline Float Sin2Theta(const V3 &w) { return smax((Float)0, (Float)1 - Cos2Theta(w)); }
+inline Float SinTheta(const V3 &w) { return std::sqrt(Sin2Theta(w)); }
+inline Float TanTheta(const V3 &w) { return SinTheta(w) / CosTheta(w); }
+inline Float Tan2Theta(const V3 &w) { return Sin2Theta(w) / Cos2Theta(w); }
+inline Float CosPhi(const V3 &w) { Float s = SinTheta(w); return (s == 0) ? 1 : Clamp(w.x / s, -1, 1); }
+inline Float SinPhi(const V3 &w) { Float s = SinTheta(w); return (s == 0) ? 0 : Clamp(w.y / s, -1, 1); }
+inline Float Cos2Phi(const V3 &w) { return CosPhi(w) * CosPhi(w); }
+inline Float Sin2Phi(const V3 &w) { return SinPhi(w) * SinPhi(w); }
+inline V3 Reflect(const V3 &wo, const V3 &n) { return -wo + 2 * Dot(wo, n) * n; }
+inline bool SameHemisphere(const V3 &w, const V3 &wp) { return w.z * wp.z > 0; }
+
+// core/reflection.cpp:47-68
+inline Float FrDielectric(Float cosThetaI, Float etaI, Float etaT) {
+    cosThetaI = Clamp(cosThetaI, -1, 1);
+    bool entering = cosThetaI > 0.f;
+    if (!entering) { std::swap(etaI, etaT); cosThetaI = std::abs(cosThetaI); }
+    Float sinThetaI = std::sqrt(smax((Float)0, 1 - cosThetaI * cosThetaI));
+    Float sinThetaT = etaI / etaT * sinThetaI;
+    if (sinThetaT >= 1) return 1;
+    Float cosThetaT = std::sqrt(smax((Float)0, 1 - sinThetaT * sinThetaT));
+    Float Rparl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
+    Float Rperp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+    return (Rparl * Rparl + Rperp * Rperp) / 2;
+}
+
+// core/microfacet.h:123-128.  std::log(float) is glibc logf in the reference;
+// constant textures make this a per-material constant, evaluated on the host.
+inline Float RoughnessToAlpha(Float roughness) {
+    roughness = smax(roughness, (Float)1e-3);
+    Float x = std::log(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+
+// TrowbridgeReitzDistribution, sampleVisibleArea = true (core/microfacet.cpp)
+struct TRDist {
+    Float alphax, alphay;
+    Float D(const V3 &wh) const {                 // :163-171
+        Float tan2Theta = Tan2Theta(wh);
+        if (std::isinf(tan2Theta)) return 0.;
+        const Float cos4Theta = Cos2Theta(wh) * Cos2Theta(wh);
+        Float e = (Cos2Phi(wh) / (alphax * alphax) + Sin2Phi(wh) / (alphay * alphay)) * tan2Theta;
+        return 1 / (Pi * alphax * alphay * cos4Theta * (1 + e) * (1 + e));
+    }
+    Float Lambda(const V3 &w) const {             // :185-193
+        Float absTanTheta = std::abs(TanTheta(w));
+        if (std::isinf(absTanTheta)) return 0.;
+        Float alpha = std::sqrt(Cos2Phi(w) * alphax * alphax + Sin2Phi(w) * alphay * alphay);
+        Float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
+        return (-1 + std::sqrt(1.f + alpha2Tan2Theta)) / 2;
+    }
+    Float G1(const V3 &w) const { return 1 / (1 + Lambda(w)); }                  // microfacet.h:54-57
+    Float G(const V3 &wo, const V3 &wi) const { return 1 / (1 + Lambda(wo) + Lambda(wi)); }
+    Float Pdf(const V3 &wo, const V3 &wh) const {  // :338-344
+        return D(wh) * G1(wo) * AbsDot(wo, wh) / AbsCosTheta(wo);
+    }
+    // :238-280
+    static void Sample11(Float cosTheta, Float U1, Float U2, Float *slope_x, Float *slope_y) {
+        if (cosTheta > .9999) {
+            Float r = std::sqrt(U1 / (1 - U1));
+            Float phi = 6.28318530718 * U2;
+            *slope_x = r * m_cos(phi);   // float * double -> double -> Float
+            *slope_y = r * m_sin(phi);
+            return;
+        }
+        Float sinTheta = std::sqrt(smax((Float)0, (Float)1 - cosTheta * cosTheta));
+        Float tanTheta = sinTheta / cosTheta;
+        Float a = 1 / tanTheta;
+        Float G1 = 2 / (1 + std::sqrt(1.f + 1.f / (a * a)));
+        Float A = 2 * U1 / G1 - 1;
+        Float tmp = 1.f / (A * A - 1.f);
+        if (tmp > 1e10) tmp = 1e10;
+        Float B = tanTheta;
+        Float D = std::sqrt(smax(Float(B * B * tmp * tmp - (A * A - B * B) * tmp), Float(0)));
+        Float slope_x_1 = B * tmp - D;
+        Float slope_x_2 = B * tmp + D;
+        *slope_x = (A < 0 || slope_x_2 > 1.f / tanTheta) ? slope_x_1 : slope_x_2;
+        Float S;
+        if (U2 > 0.5f) { S = 1.f; U2 = 2.f * (U2 - .5f); }
+        else { S = -1.f; U2 = 2.f * (.5f - U2); }
+        Float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) /
+                  (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+        *slope_y = S * z * std::sqrt(1.f + *slope_x * *slope_x);
+    }
+    // :282-305
+    static V3 Sample(const V3 &wi, Float alpha_x, Float alpha_y, Float U1, Float U2) {
+        V3 wiStretched = Normalize(V3(alpha_x * wi.x, alpha_y * wi.y, wi.z));
+        Float slope_x, slope_y;
+        Sample11(CosTheta(wiStretched), U1, U2, &slope_x, &slope_y);
+        Float tmp = CosPhi(wiStretched) * slope_x - SinPhi(wiStretched) * slope_y;
+        slope_y = SinPhi(wiStretched) * slope_x + CosPhi(wiStretched) * slope_y;
+        slope_x = tmp;
+        slope_x = alpha_x * slope_x;
+        slope_y = alpha_y * slope_y;
+        return Normalize(V3(-slope_x, -slope_y, 1.));
+    }
+    V3 Sample_wh(const V3 &wo, const P2 &u) const {   // :307-336, visible-area branch
+        bool flip = wo.z < 0;
+        V3 wh = Sample(flip ? -wo : wo, alphax, alphay, u.x, u.y);
+        if (flip) wh = -wh;
+        return wh;
+    }
+};
+
+enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16,
+       BSDF_ALL = 31 };
+enum { BXDF_LAMBERT = 0, BXDF_MICROFACET = 1 };
+
+struct BxDF {
+    int kind; int type;
+    Spec R;
+    TRDist dist;   // microfacet only; Fresnel is FresnelDielectric(1.5, 1) (plastic.cpp:56)
+    bool MatchesFlags(int t) const { return (type & t) == type; }
+    Spec f(const V3 &wo, const V3 &wi) const {
+        if (kind == BXDF_LAMBERT) return R * InvPi;       // reflection.cpp:178-180
+        // reflection.cpp:226-236
+        Float cosThetaO = AbsCosTheta(wo), cosThetaI = AbsCosTheta(wi);
+        V3 wh = wi + wo;
+        if (cosThetaI == 0 || cosThetaO == 0) return Spec(0.);
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0.);
+        wh = Normalize(wh);
+        Spec F(FrDielectric(Dot(wi, wh), 1.5f, 1.f));
+        return R * dist.D(wh) * dist.G(wo, wi) * F / (4 * cosThetaI * cosThetaO);
+    }
+    Float Pdf(const V3 &wo, const V3 &wi) const {
+        if (kind == BXDF_LAMBERT) return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * InvPi : 0;   // :387-389
+        if (!SameHemisphere(wo, wi)) return 0;                                                   // :416-420
+        V3 wh = Normalize(wo + wi);
+        return dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
+    }
+    Spec Sample_f(const V3 &wo, V3 *wi, const P2 &u, Float *pdf) const {
+        if (kind == BXDF_LAMBERT) {                        // :378-385
+            *wi = CosineSampleHemisphere(u);
+            if (wo.z < 0) wi->z *= -1;
+            *pdf = Pdf(wo, *wi);
+            return f(wo, *wi);
+        }
+        // :402-414
+        if (wo.z == 0) return 0.;
+        V3 wh = dist.Sample_wh(wo, u);
+        *wi = Reflect(wo, wh);
+        if (!SameHemisphere(wo, *wi)) return Spec(0.f);
+        *pdf = dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
+        return f(wo, *wi);
+    }
+};
+
+// core/reflection.h:153-202, reflection.cpp:670-785
+struct BSDF {
+    V3 ns, ng, ss, ts;
+    int nBxDFs = 0;
+    BxDF bxdfs[2];
+    void Init(const SurfaceInteraction &si) {
+        ns = si.shading.n; ng = si.n;
+        ss = Normalize(si.shading.dpdu);
+        ts = Cross(ns, ss);
+        nBxDFs = 0;
+    }
+    int NumComponents(int flags) const {
+        int num = 0;
+        for (int i = 0; i < nBxDFs; ++i) if (bxdfs[i].MatchesFlags(flags)) ++num;
+        return num;
+    }
+    V3 WorldToLocal(const V3 &v) const { return V3(Dot(v, ss), Dot(v, ts), Dot(v, ns)); }
+    V3 LocalToWorld(const V3 &v) const {
+        return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z,
+                  ss.z * v.x + ts.z * v.y + ns.z * v.z);
+    }
+    Spec f(const V3 &woW, const V3 &wiW, int flags) const {
+        V3 wi = WorldToLocal(wiW), wo = WorldToLocal(woW);
+        if (wo.z == 0) return 0.;
+        bool reflect = Dot(wiW, ng) * Dot(woW, ng) > 0;
+        Spec f(0.f);
+        for (int i = 0; i < nBxDFs; ++i)
+            if (bxdfs[i].MatchesFlags(flags) &&
+                ((reflect && (bxdfs[i].type & BSDF_REFLECTION)) || (!reflect && (bxdfs[i].type & BSDF_TRANSMISSION))))
+                f += bxdfs[i].f(wo, wi);
+        return f;
+    }
+    Float Pdf(const V3 &woWorld, const V3 &wiWorld, int flags) const {
+        if (nBxDFs == 0.f) return 0.f;
+        V3 wo = WorldToLocal(woWorld), wi = WorldToLocal(wiWorld);
+        if (wo.z == 0) return 0.;
+        Float pdf = 0.f;
+        int matchingComps = 0;
+        for (int i = 0; i < nBxDFs; ++i)
+            if (bxdfs[i].MatchesFlags(flags)) { ++matchingComps; pdf += bxdfs[i].Pdf(wo, wi); }
+        Float v = matchingComps > 0 ? pdf / matchingComps : 0.f;
+        return v;
+    }
+    // *pdf is deliberately left untouched on the early "wo.z == 0" return, as
+    // in the reference (:729-730); callers initialise it as the reference does.
+    Spec Sample_f(const V3 &woWorld, V3 *wiWorld, const P2 &u, Float *pdf, int type, int *sampledType) const {
+        int matchingComps = NumComponents(type);
+        if (matchingComps == 0) { *pdf = 0; if (sampledType) *sampledType = 0; return Spec(0); }
+        int comp = smin((int)std::floor(u.x * matchingComps), matchingComps - 1);
+        const BxDF *bxdf = nullptr;
+        int count = comp;
+        for (int i = 0; i < nBxDFs; ++i)
+            if (bxdfs[i].MatchesFlags(type) && count-- == 0) { bxdf = &bxdfs[i]; break; }
+        P2 uRemapped(smin(u.x * matchingComps - comp, OneMinusEpsilon), u.y);
+        V3 wi, wo = WorldToLocal(woWorld);
+        if (wo.z == 0) return 0.;
+        *pdf = 0;
+        if (sampledType) *sampledType = bxdf->type;
+        Spec f = bxdf->Sample_f(wo, &wi, uRemapped, pdf);
+        if (*pdf == 0) { if (sampledType) *sampledType = 0; return 0; }
+        *wiWorld = LocalToWorld(wi);
+        if (!(bxdf->type & BSDF_SPECULAR) && matchingComps > 1)
+            for (int i = 0; i < nBxDFs; ++i)
+                if (&bxdfs[i] != bxdf && bxdfs[i].MatchesFlags(type)) *pdf += bxdfs[i].Pdf(wo, wi);
+        if (matchingComps > 1) *pdf /= matchingComps;
+        if (!(bxdf->type & BSDF_SPECULAR)) {
+            bool reflect = Dot(*wiWorld, ng) * Dot(woWorld, ng) > 0;
+            f = 0.;
+            for (int i = 0; i < nBxDFs; ++i)
+                if (bxdfs[i].MatchesFlags(type) &&
+                    ((reflect && (bxdfs[i].type & BSDF_REFLECTION)) ||
+                     (!reflect && (bxdfs[i].type & BSDF_TRANSMISSION))))
+                    f += bxdfs[i].f(wo, wi);
+        }
+        return f;
+    }
+};
+
+// materials/matte.cpp:45-62, materials/plastic.cpp:45-70 (constant textures;
+// sigma != 0 (OrenNayar) is outside the hot-path scope)
+inline void ComputeScatteringFunctions(const Material &m, const SurfaceInteraction &si, BSDF *bsdf) {
+    bsdf->Init(si);
+    if (m.type == MAT_MATTE) {
+        Spec r = Spec(m.Kd[0], m.Kd[1], m.Kd[2]).Clamp();
+        if (!r.IsBlack()) {
+            BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+            b.kind = BXDF_LAMBERT; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.R = r;
+        }
+    } else {
+        Spec kd = Spec(m.Kd[0], m.Kd[1], m.Kd[2]).Clamp();
+        if (!kd.IsBlack()) {
+            BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+            b.kind = BXDF_LAMBERT; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.R = kd;
+        }
+        Spec ks = Spec(m.Ks[0], m.Ks[1], m.Ks[2]).Clamp();
+        if (!ks.IsBlack()) {
+            Float rough = m.roughness;
+            if (m.remap) rough = RoughnessToAlpha(rough);
+            BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+            b.kind = BXDF_MICROFACET; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.R = ks;
+            b.dist.alphax = rough; b.dist.alphay = rough;
+        }
+    }
+}
+
+// Interaction subset used by lights (core/interaction.h:51-104)
+struct Interaction { V3 p, pError, n; };
+
+// Interaction::SpawnRay / SpawnRayTo, core/interaction.h:64-78
+inline Ray SpawnRay(const V3 &p, const V3 &pError, const V3 &n, const V3 &d) {
+    V3 o = OffsetRayOrigin(p, pError, n, d);
+    return Ray(o, d, Infinity);
+}
+inline Ray SpawnRayTo(const Interaction &a, const Interaction &it) {
+    V3 origin = OffsetRayOrigin(a.p, a.pError, a.n, it.p - a.p);
+    V3 target = OffsetRayOrigin(it.p, it.pError, it.n, origin - it.p);
+    V3 d = target - origin;
+    return Ray(origin, d, 1 - ShadowEpsilon);
+}
+
+// Sphere::Sample(u), shapes/sphere.cpp:217-230
+inline Interaction SphereSampleArea(const Sphere &s, bool reverseOrientation, const P2 &u, Float *pdf) {
+    V3 pObj = V3(0, 0, 0) + s.radius * UniformSampleSphere(u);
+    Interaction it;
+    it.n = Normalize(XfNormal(s.w2o, V3(pObj.x, pObj.y, pObj.z)));
+    if (reverseOrientation) it.n *= -1;
+    pObj *= s.radius / Distance(pObj, V3(0, 0, 0));
+    V3 pObjError = gamma(5) * Abs(pObj);
+    it.p = XfPointErr2(s.o2w, pObj, pObjError, &it.pError);
+    *pdf = 1 / (s.phiMax * s.radius * (s.zMax - s.zMin));   // 1/Area(), :215
+    return it;
+}
+// Sphere::Sample(ref,u), shapes/sphere.cpp:232-292
+inline Interaction SphereSample(const Sphere &s, bool reverseOrientation, const Interaction &ref, const P2 &u,
+                                Float *pdf) {
+    V3 pCenter = XfPoint(s.o2w, V3(0, 0, 0));
+    V3 pOrigin = OffsetRayOrigin(ref.p, ref.pError, ref.n, pCenter - ref.p);
+    if (DistanceSquared(pOrigin, pCenter) <= s.radius * s.radius) {
+        Interaction intr = SphereSampleArea(s, reverseOrientation, u, pdf);
+        V3 wi = intr.p - ref.p;
+        if (wi.LengthSquared() == 0) *pdf = 0;
+        else {
+            wi = Normalize(wi);
+            *pdf *= DistanceSquared(ref.p, intr.p) / AbsDot(intr.n, -wi);
+        }
+        if (std::isinf(*pdf)) *pdf = 0.f;
+        return intr;
+    }
+    V3 wc = Normalize(pCenter - ref.p);
+    V3 wcX, wcY;
+    CoordinateSystem(wc, &wcX, &wcY);
+    Float sinThetaMax2 = s.radius * s.radius / DistanceSquared(ref.p, pCenter);
+    Float cosThetaMax = std::sqrt(smax((Float)0, 1 - sinThetaMax2));
+    Float cosTheta = (1 - u.x) + u.x * cosThetaMax;
+    Float sinTheta = std::sqrt(smax((Float)0, 1 - cosTheta * cosTheta));
+    Float phi = u.y * 2 * Pi;
+    Float dc = Distance(ref.p, pCenter);
+    Float ds = dc * cosTheta - std::sqrt(smax((Float)0, s.radius * s.radius - dc * dc * sinTheta * sinTheta));
+    Float cosAlpha = (dc * dc + s.radius * s.radius - ds * ds) / (2 * dc * s.radius);
+    Float sinAlpha = std::sqrt(smax((Float)0, 1 - cosAlpha * cosAlpha));
+    V3 nWorld = SphericalDirection(sinAlpha, cosAlpha, phi, -wcX, -wcY, -wc);
+    V3 pWorld = pCenter + s.radius * V3(nWorld.x, nWorld.y, nWorld.z);
+    Interaction it;
+    it.p = pWorld;
+    it.pError = gamma(5) * Abs(pWorld);
+    it.n = nWorld;
+    if (reverseOrientation) it.n *= -1;
+    *pdf = 1 / (2 * Pi * (1 - cosThetaMax));
+    return it;
+}
+
+}  // namespace orc

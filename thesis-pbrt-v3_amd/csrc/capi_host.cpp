@@ -1,0 +1,168 @@
+// hprt — host half of the C ABI (include/hprt.h): scene front-end, baked scenes,
+// BVH build, Halton tables, film resolve, PFM writer.  No HIP calls here; the
+// device half lives in capi_device.hip.
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include "../../include/hprt.h"
+#include "bvh_builder.h"
+#include "halton_tables.h"
+#include "hprt_internal.h"
+#include "scene_model.h"
+
+using namespace hprt;
+
+namespace hprt {
+thread_local std::string g_lastError;
+int SetError(int code, const std::string &msg) { g_lastError = msg; return code; }
+}  // namespace hprt
+
+extern "C" {
+
+const char *hprt_last_error(void) { return g_lastError.c_str(); }
+const char *hprt_version(void) { return "hprt 0.1 gfx950 (HIP, wave64) host+device"; }
+
+int hprt_model_parse(const char *pbrt_path, const char *const *subst, int n_subst, HprtModel **out) {
+    if (!pbrt_path || !out) return SetError(HPRT_E_INVALID, "hprt_model_parse: null argument");
+    std::map<std::string, std::string> sm;
+    sm["$acc"] = "\"bvh\"";
+    for (int i = 0; i + 1 < 2 * n_subst; i += 2) if (subst && subst[i] && subst[i + 1]) sm[subst[i]] = subst[i + 1];
+    HprtModel *m = new HprtModel();
+    std::string err;
+    if (!ParsePbrtFile(pbrt_path, sm, &m->sc, &err)) { delete m; return SetError(HPRT_E_PARSE, err); }
+    if (m->sc.opt.accelerator != "bvh") m->sc.warnings.push_back("Accelerator \"" + m->sc.opt.accelerator + "\" is outside the hot-path scope; \"bvh\" used");
+    if (m->sc.opt.integrator != "path") m->sc.warnings.push_back("Integrator \"" + m->sc.opt.integrator + "\" is outside the hot-path scope; \"path\" used");
+    if (m->sc.opt.sampler != "halton") m->sc.warnings.push_back("Sampler \"" + m->sc.opt.sampler + "\" is outside the hot-path scope; \"halton\" used");
+    *out = m;
+    return HPRT_OK;
+}
+int hprt_model_load(const char *baked_path, HprtModel **out) {
+    if (!baked_path || !out) return SetError(HPRT_E_INVALID, "hprt_model_load: null argument");
+    HprtModel *m = new HprtModel();
+    std::string err;
+    if (!LoadBakedScene(baked_path, &m->sc, &err)) { delete m; return SetError(HPRT_E_IO, err); }
+    *out = m;
+    return HPRT_OK;
+}
+int hprt_model_save(const HprtModel *m, const char *baked_path) {
+    if (!m || !baked_path) return SetError(HPRT_E_INVALID, "hprt_model_save: null argument");
+    std::string err;
+    if (!SaveBakedScene(m->sc, baked_path, &err)) return SetError(HPRT_E_IO, err);
+    return HPRT_OK;
+}
+void hprt_model_destroy(HprtModel *m) { delete m; }
+
+int hprt_model_get_options(const HprtModel *m, HprtRenderOptions *o) {
+    if (!m || !o) return SetError(HPRT_E_INVALID, "hprt_model_get_options: null argument");
+    const RenderOptions &p = m->sc.opt;
+    o->xres = p.xres; o->yres = p.yres;
+    memcpy(o->crop, p.crop, 16);
+    memcpy(o->filter_radius, p.filterRadius, 8);
+    o->film_scale = p.filmScale; o->max_sample_luminance = p.maxSampleLuminance;
+    o->fov = p.fov; o->lens_radius = p.lensRadius; o->focal_distance = p.focalDistance;
+    memcpy(o->screen_window, p.screenWindow, 16);
+    memcpy(o->camera_to_world, p.cameraToWorld.m, 64); memcpy(o->world_to_camera, p.worldToCamera.m, 64);
+    o->spp = p.spp; o->sample_pixel_center = p.samplePixelCenter;
+    o->max_depth = p.maxDepth; o->rr_threshold = p.rrThreshold; o->light_strategy = p.lightStrategy;
+    o->max_node_prims = p.maxNodePrims; o->isect_cost = p.isectCost; o->trav_cost = p.travCost;
+    return HPRT_OK;
+}
+int hprt_model_set_options(HprtModel *m, const HprtRenderOptions *o) {
+    if (!m || !o) return SetError(HPRT_E_INVALID, "hprt_model_set_options: null argument");
+    if (o->xres <= 0 || o->yres <= 0 || o->spp <= 0) return SetError(HPRT_E_INVALID, "resolution and spp must be positive");
+    RenderOptions &p = m->sc.opt;
+    p.xres = o->xres; p.yres = o->yres;
+    memcpy(p.crop, o->crop, 16);
+    memcpy(p.filterRadius, o->filter_radius, 8);
+    p.filmScale = o->film_scale; p.maxSampleLuminance = o->max_sample_luminance;
+    p.fov = o->fov; p.lensRadius = o->lens_radius; p.focalDistance = o->focal_distance;
+    memcpy(p.screenWindow, o->screen_window, 16);
+    memcpy(p.cameraToWorld.m, o->camera_to_world, 64); memcpy(p.worldToCamera.m, o->world_to_camera, 64);
+    p.spp = o->spp; p.samplePixelCenter = o->sample_pixel_center;
+    p.maxDepth = o->max_depth; p.rrThreshold = o->rr_threshold; p.lightStrategy = o->light_strategy;
+    p.maxNodePrims = o->max_node_prims; p.isectCost = o->isect_cost; p.travCost = o->trav_cost;
+    return HPRT_OK;
+}
+int hprt_model_counts(const HprtModel *m, uint64_t c[6]) {
+    if (!m || !c) return SetError(HPRT_E_INVALID, "hprt_model_counts: null argument");
+    uint64_t tris = 0, spheres = 0;
+    for (const ShapeDesc &s : m->sc.shapes) { if (s.kind == kTriangleMesh) tris += s.mesh.nTris(); else ++spheres; }
+    c[0] = m->sc.shapes.size(); c[1] = tris + spheres; c[2] = tris; c[3] = spheres;
+    c[4] = m->sc.materials.size(); c[5] = m->sc.lights.size();
+    return HPRT_OK;
+}
+const char *hprt_model_warnings(const HprtModel *m) {
+    static thread_local std::string buf;
+    buf.clear();
+    if (m) for (const std::string &w : m->sc.warnings) { buf += w; buf += '\n'; }
+    return buf.c_str();
+}
+
+int hprt_bvh_build(const HprtModel *m, HprtBvh **out) {
+    if (!m || !out) return SetError(HPRT_E_INVALID, "hprt_bvh_build: null argument");
+    std::vector<float> lo, hi;
+    ComputePrimBounds(m->sc, &lo, &hi);
+    HprtBvh *b = new HprtBvh();
+    BuildBvh(lo.size() / 3, lo.data(), hi.data(), m->sc.opt.maxNodePrims, m->sc.opt.isectCost, m->sc.opt.travCost, &b->tree);
+    *out = b;
+    return HPRT_OK;
+}
+void hprt_bvh_destroy(HprtBvh *b) { delete b; }
+int hprt_bvh_info(const HprtBvh *b, uint32_t info[4], float bounds6[6]) {
+    if (!b || !info) return SetError(HPRT_E_INVALID, "hprt_bvh_info: null argument");
+    info[0] = (uint32_t)b->tree.nodes.size(); info[1] = (uint32_t)b->tree.primOrder.size();
+    info[2] = (uint32_t)b->tree.nLeaves; info[3] = (uint32_t)b->tree.maxDepth;
+    if (bounds6) {
+        if (b->tree.nodes.empty()) for (int i = 0; i < 6; ++i) bounds6[i] = 0;
+        else { memcpy(bounds6, b->tree.nodes[0].bmin, 12); memcpy(bounds6 + 3, b->tree.nodes[0].bmax, 12); }
+    }
+    return HPRT_OK;
+}
+int hprt_bvh_copy(const HprtBvh *b, void *nodes32, uint32_t *prim_order) {
+    if (!b) return SetError(HPRT_E_INVALID, "hprt_bvh_copy: null argument");
+    if (nodes32) memcpy(nodes32, b->tree.nodes.data(), b->tree.nodes.size() * sizeof(BvhNode));
+    if (prim_order) memcpy(prim_order, b->tree.primOrder.data(), b->tree.primOrder.size() * 4);
+    return HPRT_OK;
+}
+
+int hprt_halton_permutations(uint16_t *out, size_t max_entries, size_t *n_entries) {
+    const std::vector<uint16_t> &p = HaltonPermutations();
+    if (n_entries) *n_entries = p.size();
+    if (out) memcpy(out, p.data(), 2 * (p.size() < max_entries ? p.size() : max_entries));
+    return HPRT_OK;
+}
+
+// Film::WriteImage, core/film.cpp:266-303 (no splats)
+int hprt_film_resolve(const float *xyzw, size_t n, float scale, float *rgb) {
+    if (!xyzw || !rgb) return SetError(HPRT_E_INVALID, "hprt_film_resolve: null argument");
+    for (size_t i = 0; i < n; ++i) {
+        const float *x = &xyzw[4 * i];
+        float *o = &rgb[3 * i];
+        o[0] = 3.240479f * x[0] - 1.537150f * x[1] - 0.498535f * x[2];
+        o[1] = -0.969256f * x[0] + 1.875991f * x[1] + 0.041556f * x[2];
+        o[2] = 0.055648f * x[0] - 0.204043f * x[1] + 1.057311f * x[2];
+        float w = x[3];
+        if (w != 0) {
+            float invWt = 1.0f / w;
+            o[0] = sel_max(0.f, o[0] * invWt); o[1] = sel_max(0.f, o[1] * invWt); o[2] = sel_max(0.f, o[2] * invWt);
+        }
+        // splat term: XYZToRGB(0) = +0 in every channel; v + 1*0 keeps v (and turns -0 into +0)
+        o[0] += 0.f; o[1] += 0.f; o[2] += 0.f;
+        o[0] *= scale; o[1] *= scale; o[2] *= scale;
+    }
+    return HPRT_OK;
+}
+
+// WritePFM, core/imageio.cpp:437+ : "PF", width height, scale -1 (little endian), rows bottom to top
+int hprt_write_pfm(const char *path, const float *rgb, int width, int height) {
+    if (!path || !rgb || width <= 0 || height <= 0) return SetError(HPRT_E_INVALID, "hprt_write_pfm: bad argument");
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return SetError(HPRT_E_IO, std::string("cannot create ") + path);
+    bool ok = fprintf(fp, "PF\n%d %d\n-1.000000\n", width, height) > 0;
+    for (int y = height - 1; y >= 0 && ok; --y) ok = fwrite(&rgb[3 * (size_t)y * width], sizeof(float), 3 * (size_t)width, fp) == 3 * (size_t)width;
+    if (fclose(fp) != 0) ok = false;
+    return ok ? HPRT_OK : SetError(HPRT_E_IO, std::string("write error on ") + path);
+}
+
+}  // extern "C"

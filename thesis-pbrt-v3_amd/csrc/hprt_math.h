@@ -1,0 +1,274 @@
+// hprt — scalar/vector arithmetic shared by the host front-end and the HIP kernels.
+//
+// Every function here reproduces, operation for operation, the IEEE-754 single
+// rounding sequence of the pbrt-v3 fork's core/geometry.h / core/pbrt.h helpers
+// it names, because ray/triangle hit selection and the radiance estimate must
+// agree with the CPU PathIntegrator bit for bit.  Translation units including
+// this header are built with -ffp-contract=off and without fast-math; the
+// device keeps f32 denormals and uses correctly rounded f32 divide/sqrt
+// (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HPRT_HD __host__ __device__ __forceinline__
+#else
+#define HPRT_HD inline
+#endif
+
+namespace hprt {
+
+// constants as *float* values (reference: core/pbrt.h:193-210, core/rng.h:52)
+#define HPRT_INF (__builtin_huge_valf())
+#define HPRT_MACHINE_EPS 5.9604644775390625e-08f /* 2^-24 */
+#define HPRT_SHADOW_EPS 0.0001f
+#define HPRT_PI 3.14159274101257324219f
+#define HPRT_INV_PI 0.31830987334251403809f
+#define HPRT_PI_OVER_2 1.57079637050628662109f
+#define HPRT_PI_OVER_4 0.78539818525314331055f
+#define HPRT_ONE_MINUS_EPS 0.99999994039535522461f
+
+HPRT_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+HPRT_HD float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+HPRT_HD bool is_inf(float v) { return (f2u(v) & 0x7fffffffu) == 0x7f800000u; }
+HPRT_HD bool is_nan(float v) { return (f2u(v) & 0x7fffffffu) > 0x7f800000u; }
+
+// libstdc++ std::min/std::max select semantics (NaN-sensitive; never fminf)
+HPRT_HD float sel_min(float a, float b) { return (b < a) ? b : a; }
+HPRT_HD float sel_max(float a, float b) { return (a < b) ? b : a; }
+HPRT_HD int sel_min(int a, int b) { return (b < a) ? b : a; }
+HPRT_HD int sel_max(int a, int b) { return (a < b) ? b : a; }
+HPRT_HD float clampf(float v, float lo, float hi) { return (v < lo) ? lo : ((v > hi) ? hi : v); }
+
+// gamma(n) = n*eps/(1-n*eps), evaluated in float exactly as core/pbrt.h:289-291
+HPRT_HD float gamma_n(int n) { return ((float)n * HPRT_MACHINE_EPS) / (1.0f - (float)n * HPRT_MACHINE_EPS); }
+
+// core/pbrt.h:241-265
+HPRT_HD float next_up(float v) {
+    if (is_inf(v) && v > 0.f) return v;
+    if (v == -0.f) v = 0.f;
+    uint32_t ui = f2u(v);
+    if (v >= 0) ++ui; else --ui;
+    return u2f(ui);
+}
+HPRT_HD float next_down(float v) {
+    if (is_inf(v) && v < 0.f) return v;
+    if (v == 0.f) v = -0.f;
+    uint32_t ui = f2u(v);
+    if (v > 0) --ui; else ++ui;
+    return u2f(ui);
+}
+
+struct vec3 {
+    float x, y, z;
+    HPRT_HD vec3() : x(0.f), y(0.f), z(0.f) {}
+    HPRT_HD vec3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
+    HPRT_HD float get(int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+    HPRT_HD void set(int i, float v) { if (i == 0) x = v; else if (i == 1) y = v; else z = v; }
+};
+HPRT_HD vec3 operator+(vec3 a, vec3 b) { return vec3(a.x + b.x, a.y + b.y, a.z + b.z); }
+HPRT_HD vec3 operator-(vec3 a, vec3 b) { return vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
+HPRT_HD vec3 operator-(vec3 a) { return vec3(-a.x, -a.y, -a.z); }
+HPRT_HD vec3 operator*(float s, vec3 a) { return vec3(s * a.x, s * a.y, s * a.z); }
+HPRT_HD vec3 operator*(vec3 a, float s) { return vec3(s * a.x, s * a.y, s * a.z); }
+// geometry.h:281-286 — "v / f" multiplies by the float reciprocal
+HPRT_HD vec3 div_by(vec3 a, float f) { float inv = 1.0f / f; return vec3(a.x * inv, a.y * inv, a.z * inv); }
+HPRT_HD float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+HPRT_HD float absdot(vec3 a, vec3 b) { return fabsf(dot(a, b)); }
+HPRT_HD float length2(vec3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+HPRT_HD float length(vec3 a) { return sqrtf(length2(a)); }
+HPRT_HD vec3 normalize(vec3 a) { return div_by(a, length(a)); }
+HPRT_HD vec3 vabs(vec3 a) { return vec3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
+// geometry.h:1287-1321 — products and differences in double, one rounding to float
+HPRT_HD vec3 cross(vec3 a, vec3 b) {
+    double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
+    return vec3((float)((ay * bz) - (az * by)), (float)((az * bx) - (ax * bz)), (float)((ax * by) - (ay * bx)));
+}
+HPRT_HD float dist2(vec3 a, vec3 b) { return length2(a - b); }
+HPRT_HD float dist(vec3 a, vec3 b) { return length(a - b); }
+HPRT_HD float max_comp(vec3 v) { return sel_max(v.x, sel_max(v.y, v.z)); }
+HPRT_HD int max_dim(vec3 v) { return (v.x > v.y) ? ((v.x > v.z) ? 0 : 2) : ((v.y > v.z) ? 1 : 2); }
+HPRT_HD vec3 vmin(vec3 a, vec3 b) { return vec3(sel_min(a.x, b.x), sel_min(a.y, b.y), sel_min(a.z, b.z)); }
+HPRT_HD vec3 vmax(vec3 a, vec3 b) { return vec3(sel_max(a.x, b.x), sel_max(a.y, b.y), sel_max(a.z, b.z)); }
+HPRT_HD vec3 face_forward(vec3 n, vec3 v) { return (dot(n, v) < 0.f) ? -n : n; }
+// geometry.h:1360-1367
+HPRT_HD void coordinate_system(vec3 v1, vec3 *v2, vec3 *v3) {
+    if (fabsf(v1.x) > fabsf(v1.y)) *v2 = div_by(vec3(-v1.z, 0.f, v1.x), sqrtf(v1.x * v1.x + v1.z * v1.z));
+    else *v2 = div_by(vec3(0.f, v1.z, -v1.y), sqrtf(v1.y * v1.y + v1.z * v1.z));
+    *v3 = cross(v1, *v2);
+}
+// geometry.h:1782-1802
+HPRT_HD vec3 offset_ray_origin(vec3 p, vec3 pErr, vec3 n, vec3 w) {
+    float d = dot(vabs(n), pErr);
+    vec3 off = d * n;
+    if (dot(w, n) < 0) off = -off;
+    vec3 po = p + off;
+    if (off.x > 0) po.x = next_up(po.x); else if (off.x < 0) po.x = next_down(po.x);
+    if (off.y > 0) po.y = next_up(po.y); else if (off.y < 0) po.y = next_down(po.y);
+    if (off.z > 0) po.z = next_up(po.z); else if (off.z < 0) po.z = next_down(po.z);
+    return po;
+}
+
+// ---------------------------------------------------------------------------
+// Deterministic sin/cos/atan2/acos.  The reference calls glibc here; libm
+// results are not reproducible on the device, so the product path evaluates
+// these from IEEE-exact double operations (Cody-Waite reduction + Taylor
+// polynomials, error ~1e-16) and rounds once to float: correctly rounded for
+// all but ~1e-8 of arguments.  DESIGN.md §Numerics states the measured
+// difference against glibc.
+// ---------------------------------------------------------------------------
+HPRT_HD double k_sin(double r) {
+    double z = r * r;
+    double p = -8.22063524662432971696e-18;
+    p = p * z + 2.81145725434552076320e-15;
+    p = p * z + -7.64716373181981647590e-13;
+    p = p * z + 1.60590438368216145994e-10;
+    p = p * z + -2.50521083854417187751e-08;
+    p = p * z + 2.75573192239858906526e-06;
+    p = p * z + -1.98412698412698412698e-04;
+    p = p * z + 8.33333333333333333333e-03;
+    p = p * z + -1.66666666666666666667e-01;
+    return r + r * (z * p);
+}
+HPRT_HD double k_cos(double r) {
+    double z = r * r;
+    double p = 4.11031762331216485848e-19;
+    p = p * z + -1.56192069685862264622e-16;
+    p = p * z + 4.77947733238738529744e-14;
+    p = p * z + -1.14707455977297247139e-11;
+    p = p * z + 2.08767569878680989792e-09;
+    p = p * z + -2.75573192239858906526e-07;
+    p = p * z + 2.48015873015873015873e-05;
+    p = p * z + -1.38888888888888888889e-03;
+    p = p * z + 4.16666666666666666667e-02;
+    p = p * z + -5.00000000000000000000e-01;
+    return 1.0 + z * p;
+}
+HPRT_HD int reduce_pio2(double x, double *r) {
+    const double P1 = 1.57079632673412561417e+00, P2 = 6.07710050630396597660e-11;
+    const double P3 = 2.02226624871116645580e-21, P3T = 8.47842766036889956997e-32;
+    double fk = x * 6.36619772367581382433e-01;
+    long long k = (long long)(fk + (fk >= 0 ? 0.5 : -0.5));
+    double dk = (double)k;
+    double t = x - dk * P1;
+    t = t - dk * P2;
+    t = t - dk * P3;
+    t = t - dk * P3T;
+    *r = t;
+    return (int)(k & 3);
+}
+HPRT_HD double det_sin(double x) {
+    double r; int q = reduce_pio2(x, &r);
+    double s = k_sin(r), c = k_cos(r);
+    return q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c));
+}
+HPRT_HD double det_cos(double x) {
+    double r; int q = reduce_pio2(x, &r);
+    double s = k_sin(r), c = k_cos(r);
+    return q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
+}
+HPRT_HD double det_atan_pos(double t) {
+    double base = 0.0; bool inv = false;
+    if (t > 1.0) { t = 1.0 / t; inv = true; }
+    if (t > 0.41421356237309504880) { base = 0.78539816339744830962; t = (t - 1.0) / (t + 1.0); }
+    double z = t * t;
+    double p = 1.0 / 45.0;
+    for (int n = 21; n >= 0; --n) {
+        double c = 1.0 / (double)(2 * n + 1);
+        p = c - z * p;
+    }
+    double a = base + t * p;
+    return inv ? (1.57079632679489661923 - a) : a;
+}
+HPRT_HD double det_atan2(double y, double x) {
+    if (x == 0.0) {
+        if (y == 0.0) return 0.0;
+        return y > 0 ? 1.57079632679489661923 : -1.57079632679489661923;
+    }
+    double a = det_atan_pos(fabs(y) / fabs(x));
+    if (x < 0) a = 3.14159265358979323846 - a;
+    return (y < 0) ? -a : a;
+}
+HPRT_HD double det_acos(double x) {
+    if (x <= -1.0) return 3.14159265358979323846;
+    if (x >= 1.0) return 0.0;
+    return 2.0 * det_atan_pos(sqrt((1.0 - x) / (1.0 + x)));
+}
+HPRT_HD float det_sinf(float x) { return (float)det_sin((double)x); }
+HPRT_HD float det_cosf(float x) { return (float)det_cos((double)x); }
+HPRT_HD float det_atan2f(float y, float x) { return (float)det_atan2((double)y, (double)x); }
+HPRT_HD float det_acosf(float x) { return (float)det_acos((double)x); }
+
+// RGB spectrum as three floats (core/spectrum.h RGBSpectrum)
+struct rgb {
+    float r, g, b;
+    HPRT_HD rgb() : r(0.f), g(0.f), b(0.f) {}
+    HPRT_HD explicit rgb(float v) : r(v), g(v), b(v) {}
+    HPRT_HD rgb(float r_, float g_, float b_) : r(r_), g(g_), b(b_) {}
+};
+HPRT_HD rgb operator+(rgb a, rgb b) { return rgb(a.r + b.r, a.g + b.g, a.b + b.b); }
+HPRT_HD rgb operator*(rgb a, rgb b) { return rgb(a.r * b.r, a.g * b.g, a.b * b.b); }
+HPRT_HD rgb operator*(rgb a, float s) { return rgb(a.r * s, a.g * s, a.b * s); }
+HPRT_HD rgb operator/(rgb a, float s) { return rgb(a.r / s, a.g / s, a.b / s); }   // spectrum.h:181-187: true divide
+HPRT_HD bool is_black(rgb a) { return a.r == 0.f && a.g == 0.f && a.b == 0.f; }
+HPRT_HD float max_value(rgb a) { float m = a.r; m = sel_max(m, a.g); m = sel_max(m, a.b); return m; }
+HPRT_HD float luminance(rgb a) { return 0.212671f * a.r + 0.715160f * a.g + 0.072169f * a.b; }
+HPRT_HD rgb clamp0(rgb a) {   // Spectrum::Clamp(0, Infinity)
+    return rgb(clampf(a.r, 0.f, HPRT_INF), clampf(a.g, 0.f, HPRT_INF), clampf(a.b, 0.f, HPRT_INF));
+}
+
+// 4x4 matrix application, core/transform.h:220-347
+struct mat4 { float m[4][4]; };
+HPRT_HD vec3 xf_point(const mat4 &M, vec3 p) {
+    float x = p.x, y = p.y, z = p.z;
+    float xp = M.m[0][0] * x + M.m[0][1] * y + M.m[0][2] * z + M.m[0][3];
+    float yp = M.m[1][0] * x + M.m[1][1] * y + M.m[1][2] * z + M.m[1][3];
+    float zp = M.m[2][0] * x + M.m[2][1] * y + M.m[2][2] * z + M.m[2][3];
+    float wp = M.m[3][0] * x + M.m[3][1] * y + M.m[3][2] * z + M.m[3][3];
+    if (wp == 1.f) return vec3(xp, yp, zp);
+    return div_by(vec3(xp, yp, zp), wp);
+}
+HPRT_HD vec3 xf_vector(const mat4 &M, vec3 v) {
+    float x = v.x, y = v.y, z = v.z;
+    return vec3(M.m[0][0] * x + M.m[0][1] * y + M.m[0][2] * z, M.m[1][0] * x + M.m[1][1] * y + M.m[1][2] * z,
+                M.m[2][0] * x + M.m[2][1] * y + M.m[2][2] * z);
+}
+// normals use the transpose of the inverse: pass the inverse matrix
+HPRT_HD vec3 xf_normal(const mat4 &Minv, vec3 n) {
+    float x = n.x, y = n.y, z = n.z;
+    return vec3(Minv.m[0][0] * x + Minv.m[1][0] * y + Minv.m[2][0] * z,
+                Minv.m[0][1] * x + Minv.m[1][1] * y + Minv.m[2][1] * z,
+                Minv.m[0][2] * x + Minv.m[1][2] * y + Minv.m[2][2] * z);
+}
+HPRT_HD vec3 xf_abs_row_sums(const mat4 &M, vec3 p, bool withTranslation) {
+    float x = p.x, y = p.y, z = p.z;
+    float sx = fabsf(M.m[0][0] * x) + fabsf(M.m[0][1] * y) + fabsf(M.m[0][2] * z);
+    float sy = fabsf(M.m[1][0] * x) + fabsf(M.m[1][1] * y) + fabsf(M.m[1][2] * z);
+    float sz = fabsf(M.m[2][0] * x) + fabsf(M.m[2][1] * y) + fabsf(M.m[2][2] * z);
+    if (withTranslation) { sx = sx + fabsf(M.m[0][3]); sy = sy + fabsf(M.m[1][3]); sz = sz + fabsf(M.m[2][3]); }
+    return vec3(sx, sy, sz);
+}
+// transform.h:277-296
+HPRT_HD vec3 xf_point_err(const mat4 &M, vec3 p, vec3 *pErr) {
+    *pErr = gamma_n(3) * xf_abs_row_sums(M, p, true);
+    return xf_point(M, p);
+}
+// transform.h:298-328
+HPRT_HD vec3 xf_point_err_in(const mat4 &M, vec3 p, vec3 e, vec3 *outErr) {
+    float g3 = gamma_n(3);
+    vec3 s = xf_abs_row_sums(M, p, true);
+    outErr->x = (g3 + 1.0f) * (fabsf(M.m[0][0]) * e.x + fabsf(M.m[0][1]) * e.y + fabsf(M.m[0][2]) * e.z) + g3 * s.x;
+    outErr->y = (g3 + 1.0f) * (fabsf(M.m[1][0]) * e.x + fabsf(M.m[1][1]) * e.y + fabsf(M.m[1][2]) * e.z) + g3 * s.y;
+    outErr->z = (g3 + 1.0f) * (fabsf(M.m[2][0]) * e.x + fabsf(M.m[2][1]) * e.y + fabsf(M.m[2][2]) * e.z) + g3 * s.z;
+    return xf_point(M, p);
+}
+// transform.h:330-347
+HPRT_HD vec3 xf_vector_err(const mat4 &M, vec3 v, vec3 *vErr) {
+    *vErr = gamma_n(3) * xf_abs_row_sums(M, v, false);
+    return xf_vector(M, v);
+}
+
+}  // namespace hprt

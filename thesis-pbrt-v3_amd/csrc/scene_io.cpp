@@ -1,0 +1,219 @@
+// hprt host side — baked scene container ("HPRTSCN1") writer/reader and a small
+// PLY mesh reader (the subset shapes/plymesh.cpp consumes: float x y z [nx ny nz]
+// [u v | s t], faces as a uint8/int list of 3 or 4 indices; quads split 0-1-2, 3-0-2
+// as at shapes/plymesh.cpp:143-152).
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include "scene_model.h"
+
+namespace hprt {
+namespace {
+
+struct Out {
+    FILE *f; bool ok = true;
+    void raw(const void *p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; }
+    void i32(int32_t v) { raw(&v, 4); }
+    void u32(uint32_t v) { raw(&v, 4); }
+    void f32(float v) { raw(&v, 4); }
+};
+struct In {
+    FILE *f; bool ok = true;
+    void raw(void *p, size_t n) { if (ok && n && fread(p, 1, n, f) != n) ok = false; }
+    int32_t i32() { int32_t v = 0; raw(&v, 4); return v; }
+    uint32_t u32() { uint32_t v = 0; raw(&v, 4); return v; }
+    float f32() { float v = 0; raw(&v, 4); return v; }
+};
+
+}  // namespace
+
+bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *err) {
+    FILE *fp = fopen(path.c_str(), "wb");
+    if (!fp) { *err = "cannot create " + path; return false; }
+    Out o{fp};
+    const RenderOptions &p = sc.opt;
+    o.raw("HPRTSCN1", 8); o.u32(1);
+    o.i32(p.xres); o.i32(p.yres);
+    o.raw(p.crop, 16);
+    o.raw(p.filterRadius, 8); o.i32(p.filterType);
+    o.f32(p.filmScale); o.f32(p.maxSampleLuminance);
+    o.f32(p.fov); o.f32(p.lensRadius); o.f32(p.focalDistance);
+    o.raw(p.screenWindow, 16);
+    o.f32(p.shutterOpen); o.f32(p.shutterClose);
+    o.raw(p.cameraToWorld.m, 64); o.raw(p.worldToCamera.m, 64);
+    o.i32(p.spp); o.i32(p.samplePixelCenter);
+    o.i32(p.maxDepth); o.f32(p.rrThreshold); o.i32(p.lightStrategy);
+    o.i32(p.maxNodePrims); o.i32(p.isectCost); o.i32(p.travCost);
+    o.u32((uint32_t)sc.materials.size()); o.u32((uint32_t)sc.shapes.size()); o.u32((uint32_t)sc.lights.size());
+    for (const MaterialDesc &m : sc.materials) {
+        o.i32(m.type); o.raw(m.Kd, 12); o.f32(m.sigma); o.raw(m.Ks, 12); o.f32(m.roughness); o.i32(m.remapRoughness);
+    }
+    for (const ShapeDesc &s : sc.shapes) {
+        o.i32(s.kind); o.i32(s.material); o.i32(s.areaLight); o.i32(s.reverseOrientation); o.i32(s.transformSwapsHandedness);
+        if (s.kind == kTriangleMesh) {
+            const MeshData &m = s.mesh;
+            uint32_t flags = (m.N.empty() ? 0u : 1u) | (m.UV.empty() ? 0u : 2u) | (m.S.empty() ? 0u : 4u);
+            o.u32(m.nTris()); o.u32(m.nVerts()); o.u32(flags);
+            o.raw(m.indices.data(), 4 * m.indices.size());
+            o.raw(m.P.data(), 4 * m.P.size());
+            o.raw(m.N.data(), 4 * m.N.size());
+            o.raw(m.UV.data(), 4 * m.UV.size());
+            o.raw(m.S.data(), 4 * m.S.size());
+        } else {
+            const SphereData &sp = s.sphere;
+            o.raw(sp.objectToWorld.m, 64); o.raw(sp.worldToObject.m, 64);
+            o.f32(sp.radius); o.f32(sp.zMin); o.f32(sp.zMax); o.f32(sp.thetaMin); o.f32(sp.thetaMax); o.f32(sp.phiMax);
+        }
+    }
+    for (const LightDesc &l : sc.lights) { o.i32(l.type); o.raw(l.pos, 12); o.raw(l.I, 12); o.i32(l.shape); o.i32(l.twoSided); }
+    bool ok = o.ok;
+    if (fclose(fp) != 0) ok = false;
+    if (!ok) *err = "write error on " + path;
+    return ok;
+}
+
+bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
+    FILE *fp = fopen(path.c_str(), "rb");
+    if (!fp) { *err = "cannot open " + path; return false; }
+    In in{fp};
+    auto fail = [&](const char *m) { *err = path + ": " + m; fclose(fp); return false; };
+    char magic[8]; in.raw(magic, 8);
+    if (!in.ok || memcmp(magic, "HPRTSCN1", 8) != 0) return fail("not a baked hprt scene");
+    if (in.u32() != 1) return fail("unsupported version");
+    RenderOptions &p = sc->opt;
+    p.xres = in.i32(); p.yres = in.i32();
+    in.raw(p.crop, 16);
+    in.raw(p.filterRadius, 8); p.filterType = in.i32();
+    p.filmScale = in.f32(); p.maxSampleLuminance = in.f32();
+    p.fov = in.f32(); p.lensRadius = in.f32(); p.focalDistance = in.f32();
+    in.raw(p.screenWindow, 16);
+    p.shutterOpen = in.f32(); p.shutterClose = in.f32();
+    in.raw(p.cameraToWorld.m, 64); in.raw(p.worldToCamera.m, 64);
+    p.spp = in.i32(); p.samplePixelCenter = in.i32();
+    p.maxDepth = in.i32(); p.rrThreshold = in.f32(); p.lightStrategy = in.i32();
+    p.maxNodePrims = in.i32(); p.isectCost = in.i32(); p.travCost = in.i32();
+    uint32_t nMat = in.u32(), nShapes = in.u32(), nLights = in.u32();
+    if (!in.ok || nMat > (1u << 24) || nShapes > (1u << 24) || nLights > (1u << 24)) return fail("truncated or corrupt header");
+    sc->materials.resize(nMat);
+    for (MaterialDesc &m : sc->materials) {
+        m.type = in.i32(); in.raw(m.Kd, 12); m.sigma = in.f32(); in.raw(m.Ks, 12); m.roughness = in.f32(); m.remapRoughness = in.i32();
+    }
+    sc->shapes.resize(nShapes);
+    for (ShapeDesc &s : sc->shapes) {
+        s.kind = in.i32(); s.material = in.i32(); s.areaLight = in.i32(); s.reverseOrientation = in.i32(); s.transformSwapsHandedness = in.i32();
+        if (s.material < 0 || (uint32_t)s.material >= nMat) return fail("material index out of range");
+        if (s.kind == kTriangleMesh) {
+            uint32_t nt = in.u32(), nv = in.u32(), flags = in.u32();
+            if (!in.ok || nt > (1u << 28) || nv > (1u << 28)) return fail("corrupt mesh header");
+            MeshData &m = s.mesh;
+            m.indices.resize(3 * (size_t)nt); in.raw(m.indices.data(), 12 * (size_t)nt);
+            m.P.resize(3 * (size_t)nv); in.raw(m.P.data(), 12 * (size_t)nv);
+            if (flags & 1) { m.N.resize(3 * (size_t)nv); in.raw(m.N.data(), 12 * (size_t)nv); }
+            if (flags & 2) { m.UV.resize(2 * (size_t)nv); in.raw(m.UV.data(), 8 * (size_t)nv); }
+            if (flags & 4) { m.S.resize(3 * (size_t)nv); in.raw(m.S.data(), 12 * (size_t)nv); }
+            for (int32_t i : m.indices) if (i < 0 || (uint32_t)i >= nv) return fail("vertex index out of range");
+        } else if (s.kind == kSphere) {
+            SphereData &sp = s.sphere;
+            in.raw(sp.objectToWorld.m, 64); in.raw(sp.worldToObject.m, 64);
+            sp.radius = in.f32(); sp.zMin = in.f32(); sp.zMax = in.f32(); sp.thetaMin = in.f32(); sp.thetaMax = in.f32(); sp.phiMax = in.f32();
+        } else return fail("unknown shape kind");
+    }
+    sc->lights.resize(nLights);
+    for (LightDesc &l : sc->lights) {
+        l.type = in.i32(); in.raw(l.pos, 12); in.raw(l.I, 12); l.shape = in.i32(); l.twoSided = in.i32();
+        if (l.type == kDiffuseAreaLight && (l.shape < 0 || (uint32_t)l.shape >= nShapes)) return fail("area light shape out of range");
+    }
+    if (!in.ok) return fail("truncated file");
+    fclose(fp);
+    return true;
+}
+
+bool ReadPlyMesh(const std::string &path, std::vector<int> *idx, std::vector<float> *P, std::vector<float> *N,
+                 std::vector<float> *UV, std::string *err) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) { *err = "Couldn't open PLY file \"" + path + "\""; return false; }
+    std::string line;
+    std::getline(in, line);
+    if (line.substr(0, 3) != "ply") { *err = path + ": not a PLY file"; return false; }
+    bool binary = false;
+    struct Prop { std::string name, type, countType; bool list = false; };
+    struct Elem { std::string name; long count = 0; std::vector<Prop> props; };
+    std::vector<Elem> elems;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::istringstream ls(line);
+        std::string w; ls >> w;
+        if (w == "format") { std::string f; ls >> f; if (f == "binary_little_endian") binary = true; else if (f != "ascii") { *err = path + ": unsupported PLY format " + f; return false; } }
+        else if (w == "element") { Elem e; ls >> e.name >> e.count; elems.push_back(e); }
+        else if (w == "property" && !elems.empty()) {
+            Prop p; std::string t; ls >> t;
+            if (t == "list") { p.list = true; ls >> p.countType >> p.type >> p.name; } else { p.type = t; ls >> p.name; }
+            elems.back().props.push_back(p);
+        } else if (w == "end_header") break;
+    }
+    auto tsize = [](const std::string &t) -> int {
+        if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+        if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+        if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+        if (t == "double" || t == "float64") return 8;
+        return 0;
+    };
+    auto readScalar = [&](const std::string &t, double *out) -> bool {
+        if (!binary) { return (bool)(in >> *out); }
+        unsigned char b[8]; int n = tsize(t);
+        if (n == 0 || !in.read((char *)b, n)) return false;
+        if (t == "float" || t == "float32") { float f; memcpy(&f, b, 4); *out = f; }
+        else if (t == "double" || t == "float64") { double d; memcpy(&d, b, 8); *out = d; }
+        else if (t == "uchar" || t == "uint8") *out = b[0];
+        else if (t == "char" || t == "int8") *out = (signed char)b[0];
+        else if (t == "ushort" || t == "uint16") { uint16_t v; memcpy(&v, b, 2); *out = v; }
+        else if (t == "short" || t == "int16") { int16_t v; memcpy(&v, b, 2); *out = v; }
+        else if (t == "uint" || t == "uint32") { uint32_t v; memcpy(&v, b, 4); *out = v; }
+        else { int32_t v; memcpy(&v, b, 4); *out = v; }
+        return true;
+    };
+    for (const Elem &e : elems) {
+        if (e.name == "vertex") {
+            int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, iu = -1, iv = -1;
+            for (size_t k = 0; k < e.props.size(); ++k) {
+                const std::string &n = e.props[k].name;
+                if (n == "x") ix = (int)k; else if (n == "y") iy = (int)k; else if (n == "z") iz = (int)k;
+                else if (n == "nx") inx = (int)k; else if (n == "ny") iny = (int)k; else if (n == "nz") inz = (int)k;
+                else if (n == "u" || n == "s" || n == "texture_u" || n == "texture_s") iu = (int)k;
+                else if (n == "v" || n == "t" || n == "texture_v" || n == "texture_t") iv = (int)k;
+            }
+            if (ix < 0 || iy < 0 || iz < 0) { *err = path + ": Vertex coordinate property not found!"; return false; }
+            bool hasN = inx >= 0 && iny >= 0 && inz >= 0, hasUV = iu >= 0 && iv >= 0;
+            P->resize(3 * (size_t)e.count); if (hasN) N->resize(3 * (size_t)e.count); if (hasUV) UV->resize(2 * (size_t)e.count);
+            std::vector<double> vals(e.props.size());
+            for (long i = 0; i < e.count; ++i) {
+                for (size_t k = 0; k < e.props.size(); ++k) if (!readScalar(e.props[k].type, &vals[k])) { *err = path + ": unable to read the contents of PLY file"; return false; }
+                (*P)[3 * i] = (float)vals[ix]; (*P)[3 * i + 1] = (float)vals[iy]; (*P)[3 * i + 2] = (float)vals[iz];
+                if (hasN) { (*N)[3 * i] = (float)vals[inx]; (*N)[3 * i + 1] = (float)vals[iny]; (*N)[3 * i + 2] = (float)vals[inz]; }
+                if (hasUV) { (*UV)[2 * i] = (float)vals[iu]; (*UV)[2 * i + 1] = (float)vals[iv]; }
+            }
+        } else {
+            for (long i = 0; i < e.count; ++i)
+                for (const Prop &p : e.props) {
+                    if (p.list) {
+                        double c; if (!readScalar(p.countType, &c)) { *err = path + ": truncated face list"; return false; }
+                        int n = (int)c; std::vector<int> face(n);
+                        for (int k = 0; k < n; ++k) { double v; if (!readScalar(p.type, &v)) { *err = path + ": truncated face list"; return false; } face[k] = (int)v; }
+                        if (e.name == "face" && (p.name == "vertex_indices" || p.name == "vertex_index")) {
+                            if (n == 3 || n == 4) {
+                                for (int k = 0; k < 3; ++k) idx->push_back(face[k]);
+                                if (n == 4) { idx->push_back(face[3]); idx->push_back(face[0]); idx->push_back(face[2]); }
+                            }
+                        }
+                    } else { double v; if (!readScalar(p.type, &v)) { *err = path + ": truncated element"; return false; } }
+                }
+        }
+    }
+    if (P->empty() || idx->empty()) { *err = path + ": PLY file is invalid! No face/vertex elements found!"; return false; }
+    size_t nv = P->size() / 3;
+    for (int i : *idx) if (i < 0 || (size_t)i >= nv) { *err = path + ": plymesh: Vertex reference out of bounds"; return false; }
+    return true;
+}
+
+}  // namespace hprt

@@ -1,0 +1,78 @@
+// hprt host side — the scene as pbrt's MakeScene()/MakeIntegrator() would hold it
+// after parsing (reference: core/api.cpp:1883-1946): render options, materials,
+// shapes in creation order with world-space mesh data, lights.  Also the baked
+// container ("HPRTSCN1") that lets a parsed scene travel without its .pbrt
+// sources (layout: DESIGN.md §Baked scene).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include "hprt_math.h"
+
+namespace hprt {
+
+enum MaterialType { kMatte = 0, kPlastic = 1 };
+enum LightType { kPointLight = 0, kDistantLight = 1, kDiffuseAreaLight = 2 };
+enum ShapeKind { kTriangleMesh = 0, kSphere = 1 };
+enum LightStrategy { kUniform = 0, kPower = 1, kSpatial = 2 };
+
+struct MaterialDesc {
+    int32_t type;
+    float Kd[3]; float sigma; float Ks[3]; float roughness; int32_t remapRoughness;
+};
+
+struct MeshData {             // world space, as TriangleMesh holds it (shapes/triangle.cpp:54-92)
+    std::vector<int32_t> indices;   // 3 per triangle
+    std::vector<float> P, N, UV, S; // 3/3/2/3 floats per vertex; N/UV/S may be empty
+    uint32_t nTris() const { return (uint32_t)(indices.size() / 3); }
+    uint32_t nVerts() const { return (uint32_t)(P.size() / 3); }
+};
+struct SphereData {
+    mat4 objectToWorld, worldToObject;
+    float radius, zMin, zMax, thetaMin, thetaMax, phiMax;
+};
+struct ShapeDesc {
+    int32_t kind, material, areaLight, reverseOrientation, transformSwapsHandedness;
+    MeshData mesh;        // kind == kTriangleMesh
+    SphereData sphere;    // kind == kSphere
+    uint32_t nPrims() const { return kind == kTriangleMesh ? mesh.nTris() : 1u; }
+};
+struct LightDesc {
+    int32_t type;
+    float pos[3];     // point: world position; distant: normalised world direction
+    float I[3];       // point: I; distant: L; area: Lemit (already multiplied by "scale")
+    int32_t shape;    // area: index into shapes
+    int32_t twoSided;
+};
+struct RenderOptions {
+    int32_t xres = 1280, yres = 720;
+    float crop[4] = {0, 1, 0, 1};                 // x0 x1 y0 y1
+    float filterRadius[2] = {0.5f, 0.5f}; int32_t filterType = 0;   // box
+    float filmScale = 1.f, maxSampleLuminance = HPRT_INF;
+    float fov = 90.f, lensRadius = 0.f, focalDistance = 1e6f;
+    float screenWindow[4] = {-1, 1, -1, 1};       // x0 x1 y0 y1
+    float shutterOpen = 0.f, shutterClose = 1.f;
+    mat4 cameraToWorld, worldToCamera;
+    int32_t spp = 16, samplePixelCenter = 0;
+    int32_t maxDepth = 5; float rrThreshold = 1.f; int32_t lightStrategy = kSpatial;
+    int32_t maxNodePrims = 4, isectCost = 8, travCost = 1;
+    std::string filename = "pbrt.exr", accelerator = "bvh", integrator = "path", sampler = "halton";
+};
+struct SceneModel {
+    RenderOptions opt;
+    std::vector<MaterialDesc> materials;
+    std::vector<ShapeDesc> shapes;
+    std::vector<LightDesc> lights;
+    std::vector<std::string> warnings;
+    uint64_t totalPrims() const { uint64_t n = 0; for (auto &s : shapes) n += s.nPrims(); return n; }
+};
+
+bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *err);
+bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err);
+// pbrt front-end (pbrt_frontend.cpp): parses the directive subset of SURVEY.md §8(f)-2
+bool ParsePbrtFile(const std::string &path, const std::map<std::string, std::string> &subst, SceneModel *sc,
+                   std::string *err);
+bool ParsePbrtString(const std::string &text, const std::string &baseDir,
+                     const std::map<std::string, std::string> &subst, SceneModel *sc, std::string *err);
+
+}  // namespace hprt
