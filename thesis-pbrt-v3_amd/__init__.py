@@ -1,0 +1,295 @@
+"""hprt — Python (ctypes) binding of the C ABI in include/hprt.h.
+
+Host-side mirror of the pbrt plugin surface for the one hot path this package
+accelerates:
+
+    Model   <- pbrtParseFile / api.cpp state          (core/parser.cpp, core/api.cpp)
+    Bvh     <- CreateBVHAccelerator / BVHAccel ctor   (accelerators/bvh.cpp:155-185,529-535)
+    Scene   <- Scene + BVHAccel::Intersect/IntersectP (accelerators/bvh.cpp:354-437)
+               and SamplerIntegrator::Render with PathIntegrator::Li
+               (core/integrator.cpp:230-360, integrators/path.cpp:64-204)
+
+The shared library is built in-tree by build.py (hipcc, gfx950).  There is no CPU
+fallback: device calls raise HprtError when no GPU is present, and importing this
+package raises if the library is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhprt.so")
+
+
+class HprtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("hprt error %d: %s" % (code, msg))
+        self.code = code
+
+
+E_INVALID, E_IO, E_PARSE, E_NO_DEVICE, E_DEVICE, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+RENDER_COUNT_WORK = 1
+
+
+class RenderOptions(C.Structure):
+    _fields_ = [
+        ("xres", C.c_int32), ("yres", C.c_int32), ("crop", C.c_float * 4), ("filter_radius", C.c_float * 2),
+        ("film_scale", C.c_float), ("max_sample_luminance", C.c_float),
+        ("fov", C.c_float), ("lens_radius", C.c_float), ("focal_distance", C.c_float),
+        ("screen_window", C.c_float * 4), ("camera_to_world", C.c_float * 16), ("world_to_camera", C.c_float * 16),
+        ("spp", C.c_int32), ("sample_pixel_center", C.c_int32), ("max_depth", C.c_int32), ("rr_threshold", C.c_float),
+        ("light_strategy", C.c_int32), ("max_node_prims", C.c_int32), ("isect_cost", C.c_int32), ("trav_cost", C.c_int32),
+    ]
+
+    def copy(self):
+        o = RenderOptions()
+        C.memmove(C.byref(o), C.byref(self), C.sizeof(RenderOptions))
+        return o
+
+    def film_bounds(self):
+        """croppedPixelBounds (core/film.cpp:56-60) as (x0, y0, x1, y1)."""
+        f32 = np.float32
+        x0 = int(np.ceil(f32(self.xres) * f32(self.crop[0])))
+        x1 = int(np.ceil(f32(self.xres) * f32(self.crop[1])))
+        y0 = int(np.ceil(f32(self.yres) * f32(self.crop[2])))
+        y1 = int(np.ceil(f32(self.yres) * f32(self.crop[3])))
+        return x0, y0, x1, y1
+
+
+class RenderDesc(C.Structure):
+    _fields_ = [("opt", RenderOptions), ("tile_begin", C.c_int32), ("tile_end", C.c_int32), ("tile_stride", C.c_int32),
+                ("spp_chunk", C.c_int32), ("flags", C.c_int32)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "camera_rays", "rays", "shadow_rays", "nodes_fetched", "nodes_fetched_p", "nodes_entered", "nodes_entered_p",
+        "tri_tests", "tri_tests_p", "sphere_tests", "sphere_tests_p")] + [
+        ("render_seconds", C.c_double), ("extend_seconds", C.c_double), ("occluded_seconds", C.c_double),
+        ("extend_launches", C.c_uint64), ("occluded_launches", C.c_uint64), ("extend_rays", C.c_uint64), ("occluded_rays", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("hprt: %s is missing — run `python thesis-pbrt-v3_amd/build.py` (hipcc, gfx950). "
+                          "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, cp, i32, u32, u64, sz = C.c_void_p, C.c_char_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_size_t
+    P = C.POINTER
+    sig = {
+        "hprt_last_error": (cp, []),
+        "hprt_version": (cp, []),
+        "hprt_model_parse": (C.c_int, [cp, P(cp), C.c_int, P(vp)]),
+        "hprt_model_load": (C.c_int, [cp, P(vp)]),
+        "hprt_model_save": (C.c_int, [vp, cp]),
+        "hprt_model_destroy": (None, [vp]),
+        "hprt_model_get_options": (C.c_int, [vp, P(RenderOptions)]),
+        "hprt_model_set_options": (C.c_int, [vp, P(RenderOptions)]),
+        "hprt_model_counts": (C.c_int, [vp, P(u64)]),
+        "hprt_model_warnings": (cp, [vp]),
+        "hprt_bvh_build": (C.c_int, [vp, P(vp)]),
+        "hprt_bvh_destroy": (None, [vp]),
+        "hprt_bvh_info": (C.c_int, [vp, P(u32), P(C.c_float)]),
+        "hprt_bvh_copy": (C.c_int, [vp, vp, vp]),
+        "hprt_scene_create": (C.c_int, [vp, C.c_int, P(vp)]),
+        "hprt_scene_create_from_model": (C.c_int, [vp, vp, C.c_int, P(vp)]),
+        "hprt_scene_destroy": (None, [vp]),
+        "hprt_intersect": (C.c_int, [vp, sz, vp, vp, vp, vp, vp, vp, vp]),
+        "hprt_occluded": (C.c_int, [vp, sz, vp, vp, vp, vp, vp]),
+        "hprt_intersect_device": (C.c_int, [vp, sz, vp, vp, vp, vp, vp]),
+        "hprt_occluded_device": (C.c_int, [vp, sz, vp, vp, vp]),
+        "hprt_render": (C.c_int, [vp, P(RenderDesc), vp, vp, P(RenderStats)]),
+        "hprt_film_resolve": (C.c_int, [vp, sz, C.c_float, vp]),
+        "hprt_film_read": (C.c_int, [vp, vp, sz]),
+        "hprt_write_pfm": (C.c_int, [cp, vp, C.c_int, C.c_int]),
+        "hprt_sample_radiance": (C.c_int, [vp, P(RenderOptions), sz, vp, vp, vp, vp]),
+        "hprt_halton_permutations": (C.c_int, [vp, sz, P(sz)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)   # raises AttributeError if an export is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def _check(rc):
+    if rc != 0:
+        raise HprtError(rc, lib.hprt_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def version():
+    return lib.hprt_version().decode()
+
+
+class Model:
+    """Parsed scene (host)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def parse(path, subst=None):
+        kv = []
+        for k, v in (subst or {}).items():
+            kv += [k.encode(), v.encode()]
+        arr = (C.c_char_p * max(1, len(kv)))(*kv)
+        h = C.c_void_p()
+        _check(lib.hprt_model_parse(path.encode(), arr, len(kv) // 2, C.byref(h)))
+        return Model(h)
+
+    @staticmethod
+    def load(path):
+        h = C.c_void_p()
+        _check(lib.hprt_model_load(path.encode(), C.byref(h)))
+        return Model(h)
+
+    def save(self, path):
+        _check(lib.hprt_model_save(self._h, path.encode()))
+
+    @property
+    def options(self):
+        o = RenderOptions()
+        _check(lib.hprt_model_get_options(self._h, C.byref(o)))
+        return o
+
+    @options.setter
+    def options(self, o):
+        _check(lib.hprt_model_set_options(self._h, C.byref(o)))
+
+    def counts(self):
+        c = (C.c_uint64 * 6)()
+        _check(lib.hprt_model_counts(self._h, c))
+        return dict(zip(("shapes", "primitives", "triangles", "spheres", "materials", "lights"), [int(x) for x in c]))
+
+    def warnings(self):
+        w = lib.hprt_model_warnings(self._h).decode()
+        return [x for x in w.split("\n") if x]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.hprt_model_destroy(self._h)
+            self._h = None
+
+
+class Bvh:
+    """Flattened BVH (host): CreateBVHAccelerator(prims, params)."""
+
+    def __init__(self, model):
+        h = C.c_void_p()
+        _check(lib.hprt_bvh_build(model._h, C.byref(h)))
+        self._h = h
+
+    def info(self):
+        i = (C.c_uint32 * 4)()
+        b = (C.c_float * 6)()
+        _check(lib.hprt_bvh_info(self._h, i, b))
+        return {"nodes": i[0], "prims": i[1], "leaves": i[2], "max_depth": i[3], "bounds": [float(x) for x in b]}
+
+    def arrays(self):
+        inf = self.info()
+        nodes = np.zeros((inf["nodes"], 8), np.uint32)
+        order = np.zeros(inf["prims"], np.uint32)
+        _check(lib.hprt_bvh_copy(self._h, _ptr(nodes), _ptr(order)))
+        return nodes, order
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.hprt_bvh_destroy(self._h)
+            self._h = None
+
+
+class Scene:
+    """Device-resident scene: Aggregate (Intersect/IntersectP) + Integrator (Render)."""
+
+    def __init__(self, model, bvh, device=-1):
+        h = C.c_void_p()
+        _check(lib.hprt_scene_create_from_model(model._h, bvh._h, device, C.byref(h)))
+        self._h = h
+        self._model = model
+
+    def intersect(self, o, d, tmax, count=False):
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = tmax.shape[0]
+        t = np.zeros(n, np.float32); prim = np.zeros(n, np.int32); bary = np.zeros((n, 3), np.float32)
+        ctr = np.zeros(4, np.uint64) if count else None
+        _check(lib.hprt_intersect(self._h, n, _ptr(o), _ptr(d), _ptr(tmax), _ptr(t), _ptr(prim), _ptr(bary), _ptr(ctr)))
+        return (t, prim, bary, ctr) if count else (t, prim, bary)
+
+    def occluded(self, o, d, tmax, count=False):
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = tmax.shape[0]
+        occ = np.zeros(n, np.uint8)
+        ctr = np.zeros(4, np.uint64) if count else None
+        _check(lib.hprt_occluded(self._h, n, _ptr(o), _ptr(d), _ptr(tmax), _ptr(occ), _ptr(ctr)))
+        return (occ, ctr) if count else occ
+
+    def intersect_device(self, n, rays7_ptr, t_ptr, prim_ptr, bary_ptr=None, stream=None):
+        _check(lib.hprt_intersect_device(self._h, n, rays7_ptr, t_ptr, prim_ptr, bary_ptr, stream))
+
+    def occluded_device(self, n, rays7_ptr, occ_ptr, stream=None):
+        _check(lib.hprt_occluded_device(self._h, n, rays7_ptr, occ_ptr, stream))
+
+    def render(self, opt=None, tile_begin=0, tile_end=0, tile_stride=1, spp_chunk=0, count_work=False, film_ptr=None,
+               stream=None):
+        """Render(): returns (film_xyzw [H,W,4] float32 or None when film_ptr is given, stats dict)."""
+        opt = opt or self._model.options
+        desc = RenderDesc()
+        desc.opt = opt
+        desc.tile_begin, desc.tile_end, desc.tile_stride = tile_begin, tile_end, tile_stride
+        desc.spp_chunk = spp_chunk
+        desc.flags = RENDER_COUNT_WORK if count_work else 0
+        st = RenderStats()
+        _check(lib.hprt_render(self._h, C.byref(desc), film_ptr, stream, C.byref(st)))
+        film = None
+        if film_ptr is None:
+            x0, y0, x1, y1 = opt.film_bounds()
+            film = np.zeros((y1 - y0, x1 - x0, 4), np.float32)
+            _check(lib.hprt_film_read(self._h, _ptr(film), film.shape[0] * film.shape[1]))
+        return film, st.as_dict()
+
+    def sample_radiance(self, px, py, sample, opt=None):
+        opt = opt or self._model.options
+        px = np.ascontiguousarray(px, np.int32); py = np.ascontiguousarray(py, np.int32)
+        sample = np.ascontiguousarray(sample, np.int64)
+        L = np.zeros((px.shape[0], 3), np.float32)
+        _check(lib.hprt_sample_radiance(self._h, C.byref(opt), px.shape[0], _ptr(px), _ptr(py), _ptr(sample), _ptr(L)))
+        return L
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.hprt_scene_destroy(self._h)
+            self._h = None
+
+
+def film_resolve(film_xyzw, scale=1.0):
+    """Film::WriteImage arithmetic (core/film.cpp:266-303): [H,W,4] xyz+weight -> [H,W,3] linear RGB."""
+    f = np.ascontiguousarray(film_xyzw, np.float32)
+    rgb = np.zeros(f.shape[:-1] + (3,), np.float32)
+    _check(lib.hprt_film_resolve(_ptr(f), f.size // 4, C.c_float(scale), _ptr(rgb)))
+    return rgb
+
+
+def write_pfm(path, rgb):
+    a = np.ascontiguousarray(rgb, np.float32)
+    _check(lib.hprt_write_pfm(path.encode(), _ptr(a), a.shape[1], a.shape[0]))
+
+
+def halton_permutations():
+    n = C.c_size_t()
+    _check(lib.hprt_halton_permutations(None, 0, C.byref(n)))
+    out = np.zeros(n.value, np.uint16)
+    _check(lib.hprt_halton_permutations(_ptr(out), n.value, C.byref(n)))
+    return out

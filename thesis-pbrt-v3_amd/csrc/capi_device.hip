@@ -1,0 +1,765 @@
+// hprt — device half of the C ABI (include/hprt.h): HBM scene upload, batched
+// Intersect/IntersectP, the wavefront Render loop and the film.  Host-side
+// orchestration only; the arithmetic lives in device/*.h and device/kernels.hip.
+// There is no CPU fallback: every entry point fails with HPRT_E_NO_DEVICE when no
+// HIP device is usable.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/hprt.h"
+#include "device/kernels.h"
+#include "halton_tables.h"
+#include "host_transform.h"
+#include "hprt_internal.h"
+
+using namespace hprt;
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return SetError(HPRT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));         \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) {
+        if (p && bytes >= n) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (n == 0) return hipSuccess;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <typename T> T *as() const { return (T *)p; }
+};
+template <typename T> hipError_t upload(DevBuf &b, const std::vector<T> &v) {
+    hipError_t e = b.alloc(std::max<size_t>(v.size() * sizeof(T), 16));
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+}  // namespace
+
+struct HprtScene {
+    int device = 0;
+    DevScene dev;
+    DevBuf nodes, tris, primVtx, vN, vUV, vS, shapes, materials, lights, spheres, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
+    DevBuf counters;
+    // render-time state
+    DevBuf planes; size_t planeCapacity = 0;         // PathPlanes backing store
+    DevBuf queues, queueCounts;
+    DevBuf pixelXY, pixelOffset, Lall, film, irregular, irregularCount;
+    DevBuf exOwnBegin, exOwnSrc, exOwnSample, exOwnPre, exFDest, exFDestBegin, exFGroupBegin, exFSrc, exFSample;
+    uint32_t *hostCounts = nullptr;                   // pinned
+    size_t filmPixels = 0;
+    uint32_t nPrims = 0;
+    ~HprtScene() { if (hostCounts) (void)hipHostFree(hostCounts); }
+};
+
+namespace {
+
+int CheckDevice(int device, int *chosen) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return SetError(HPRT_E_NO_DEVICE, "no HIP device available (hprt has no CPU fallback)");
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= n) return SetError(HPRT_E_INVALID, "device ordinal out of range");
+    if (hipSetDevice(device) != hipSuccess) return SetError(HPRT_E_DEVICE, "hipSetDevice failed");
+    *chosen = device;
+    return HPRT_OK;
+}
+
+// TrowbridgeReitzDistribution::RoughnessToAlpha, core/microfacet.h:123-128 (host libm logf,
+// as in the reference; constant textures make it a per-material constant)
+float RoughnessToAlpha(float roughness) {
+    roughness = sel_max(roughness, (float)1e-3);
+    float x = std::log(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+
+// Would Triangle::Intersect reject every hit on this triangle as "bogus"
+// (shapes/triangle.cpp:300-316)?  Depends on the triangle only, so decided here.
+bool TriangleIsBogus(vec3 p0, vec3 p1, vec3 p2, const float *uv0, const float *uv1, const float *uv2) {
+    float u0x = 0, u0y = 0, u1x = 1, u1y = 0, u2x = 1, u2y = 1;
+    if (uv0) { u0x = uv0[0]; u0y = uv0[1]; u1x = uv1[0]; u1y = uv1[1]; u2x = uv2[0]; u2y = uv2[1]; }
+    float duv02x = u0x - u2x, duv02y = u0y - u2y, duv12x = u1x - u2x, duv12y = u1y - u2y;
+    vec3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float determinant = duv02x * duv12y - duv02y * duv12x;
+    bool degenerateUV = std::fabs(determinant) < 1e-8;
+    vec3 dpdu, dpdv;
+    if (!degenerateUV) {
+        float invdet = 1 / determinant;
+        dpdu = (duv12y * dp02 - duv02y * dp12) * invdet;
+        dpdv = (-duv12x * dp02 + duv02x * dp12) * invdet;
+    }
+    if (degenerateUV || length2(cross(dpdu, dpdv)) == 0) {
+        vec3 ng = cross(p2 - p0, p1 - p0);
+        if (length2(ng) == 0) return true;
+    }
+    return false;
+}
+
+struct PlaneAllocator {
+    char *base; size_t off = 0, cap;
+    template <typename T> T *take(size_t n) { off = (off + 255) & ~(size_t)255; T *p = (T *)(base + off); off += n * sizeof(T); return p; }
+};
+const size_t kPlaneBytesPerSlot = 4 * (7 + 5 + 6 + 1 + 7 + 6 + 5 + 10 + 1) + 1 + 64;   // generous upper bound incl. alignment slack
+
+void CarvePlanes(char *base, size_t n, PathPlanes *ps) {
+    PlaneAllocator a{base, 0, 0};
+    auto rays = [&](RayPlanes &r, bool withT) {
+        r.ox = a.take<float>(n); r.oy = a.take<float>(n); r.oz = a.take<float>(n);
+        r.dx = a.take<float>(n); r.dy = a.take<float>(n); r.dz = a.take<float>(n);
+        r.tmax = withT ? a.take<float>(n) : nullptr;
+    };
+    rays(ps->ray, true);
+    ps->hit.t = a.take<float>(n); ps->hit.prim = a.take<int32_t>(n);
+    ps->hit.b0 = a.take<float>(n); ps->hit.b1 = a.take<float>(n); ps->hit.b2 = a.take<float>(n);
+    ps->betaR = a.take<float>(n); ps->betaG = a.take<float>(n); ps->betaB = a.take<float>(n);
+    ps->LR = a.take<float>(n); ps->LG = a.take<float>(n); ps->LB = a.take<float>(n);
+    ps->state = a.take<uint32_t>(n);
+    rays(ps->sh, true);
+    rays(ps->mis, false);
+    ps->misHit.t = a.take<float>(n); ps->misHit.prim = a.take<int32_t>(n);
+    ps->misHit.b0 = ps->misHit.b1 = ps->misHit.b2 = nullptr;
+    ps->occluded = a.take<uint8_t>(n);
+    ps->pendLightR = a.take<float>(n); ps->pendLightG = a.take<float>(n); ps->pendLightB = a.take<float>(n);
+    ps->pendMisR = a.take<float>(n); ps->pendMisG = a.take<float>(n); ps->pendMisB = a.take<float>(n);
+    ps->pendBetaR = a.take<float>(n); ps->pendBetaG = a.take<float>(n); ps->pendBetaB = a.take<float>(n);
+    ps->pendPdf = a.take<float>(n);
+    ps->pendInfo = a.take<uint32_t>(n);
+}
+size_t PlaneBytes(size_t n) { return n * kPlaneBytesPerSlot + 64 * 256; }
+
+struct EventTimer {
+    std::vector<hipEvent_t> pool; size_t used = 0;
+    ~EventTimer() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+        return pool[used++];
+    }
+    void reset() { used = 0; }
+};
+
+// Camera matrices: ProjectiveCamera ctor, core/camera.h:84-115
+void MakeCamera(const HprtRenderOptions &o, DevCamera *cam) {
+    Xform camToScreen = xf_perspective(o.fov, 1e-2f, 1000.f);
+    const float *sw = o.screen_window;
+    Xform screenToRaster = xf_scale((float)o.xres, (float)o.yres, 1) * xf_scale(1 / (sw[1] - sw[0]), 1 / (sw[2] - sw[3]), 1) *
+                           xf_translate(vec3(-sw[0], -sw[3], 0));
+    Xform rasterToScreen = screenToRaster.inverse();
+    Xform rasterToCamera = camToScreen.inverse() * rasterToScreen;
+    cam->rasterToCamera = rasterToCamera.m;
+    memcpy(cam->cameraToWorld.m, o.camera_to_world, 64);
+    cam->lensRadius = o.lens_radius; cam->focalDistance = o.focal_distance;
+}
+
+struct FrameSetup {
+    FilmGeom fg; int ntx, nty; HaltonLayout hal; RenderParams rp;
+    std::vector<uint32_t> pixelXY; std::vector<uint64_t> pixelOffset;
+    std::vector<int32_t> localIndex;   // cropped-film index -> local pixel index or -1
+    int W, H;
+};
+int SetupFrame(const HprtRenderOptions &o, FrameSetup *f) {
+    if (o.xres <= 0 || o.yres <= 0 || o.xres > 32768 || o.yres > 32768) return SetError(HPRT_E_INVALID, "film resolution out of range");
+    if (o.filter_radius[0] != 0.5f || o.filter_radius[1] != 0.5f)
+        return SetError(HPRT_E_UNSUPPORTED, "only the box filter with radius 0.5 is in the hot-path scope (SURVEY.md §2)");
+    FilmGeom &fg = f->fg;
+    fg.cx0 = (int)std::ceil(o.xres * o.crop[0]); fg.cx1 = (int)std::ceil(o.xres * o.crop[1]);   // core/film.cpp:56-60
+    fg.cy0 = (int)std::ceil(o.yres * o.crop[2]); fg.cy1 = (int)std::ceil(o.yres * o.crop[3]);
+    fg.rx = o.filter_radius[0]; fg.ry = o.filter_radius[1];
+    fg.sx0 = (int)std::floor((float)fg.cx0 + 0.5f - fg.rx); fg.sy0 = (int)std::floor((float)fg.cy0 + 0.5f - fg.ry);   // core/film.cpp:81-87
+    fg.sx1 = (int)std::ceil((float)fg.cx1 - 0.5f + fg.rx); fg.sy1 = (int)std::ceil((float)fg.cy1 - 0.5f + fg.ry);
+    fg.maxSampleLuminance = o.max_sample_luminance;
+    f->W = fg.cx1 - fg.cx0; f->H = fg.cy1 - fg.cy0;
+    if (f->W <= 0 || f->H <= 0) return SetError(HPRT_E_INVALID, "empty crop window");
+    f->ntx = (fg.sx1 - fg.sx0 + 15) / 16; f->nty = (fg.sy1 - fg.sy0 + 15) / 16;                   // core/integrator.cpp:237-239
+    f->hal = MakeHaltonLayout(fg.sx1 - fg.sx0, fg.sy1 - fg.sy0);
+    return HPRT_OK;
+}
+void AddTilePixels(FrameSetup *f, int tile) {
+    const FilmGeom &fg = f->fg;
+    int tx = tile % f->ntx, ty = tile / f->ntx;
+    int x0 = fg.sx0 + tx * 16, x1 = std::min(x0 + 16, fg.sx1), y0 = fg.sy0 + ty * 16, y1 = std::min(y0 + 16, fg.sy1);
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            f->localIndex[(size_t)(y - fg.cy0) * f->W + (x - fg.cx0)] = (int32_t)f->pixelXY.size();
+            f->pixelXY.push_back((uint32_t)x | ((uint32_t)y << 16));
+            f->pixelOffset.push_back((uint64_t)HaltonPixelOffset(f->hal, x, y));
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
+    if (!d || !out) return SetError(HPRT_E_INVALID, "hprt_scene_create: null argument");
+    if ((d->n_nodes && !d->nodes) || (d->n_prims && !d->prim_order) || (d->n_shapes && !d->shapes) ||
+        (d->n_materials && !d->materials) || (d->n_lights && !d->lights))
+        return SetError(HPRT_E_INVALID, "hprt_scene_create: null array with non-zero count");
+    // ---- validate the description against what the kernels assume ----
+    std::vector<uint64_t> firstPrim(d->n_shapes + 1, 0);
+    std::vector<uint64_t> vtxBase(d->n_shapes + 1, 0);
+    uint32_t nSpheres = 0;
+    for (uint32_t s = 0; s < d->n_shapes; ++s) {
+        const HprtShapeDesc &sh = d->shapes[s];
+        if (sh.material < 0 || (uint32_t)sh.material >= d->n_materials) return SetError(HPRT_E_INVALID, "shape material index out of range");
+        if (sh.area_light >= (int32_t)d->n_lights) return SetError(HPRT_E_INVALID, "shape area light index out of range");
+        if (sh.kind == 0) {
+            if (sh.n_tris && (!sh.indices || !sh.P)) return SetError(HPRT_E_INVALID, "mesh without indices or positions");
+            for (uint64_t i = 0; i < 3ull * sh.n_tris; ++i)
+                if (sh.indices[i] < 0 || (uint32_t)sh.indices[i] >= sh.n_verts) return SetError(HPRT_E_INVALID, "mesh vertex index out of range");
+            if (sh.area_light >= 0) return SetError(HPRT_E_UNSUPPORTED, "area lights on triangle meshes are outside the hot-path scope");
+            firstPrim[s + 1] = firstPrim[s] + sh.n_tris; vtxBase[s + 1] = vtxBase[s] + sh.n_verts;
+        } else if (sh.kind == 1) {
+            firstPrim[s + 1] = firstPrim[s] + 1; vtxBase[s + 1] = vtxBase[s]; ++nSpheres;
+        } else return SetError(HPRT_E_INVALID, "unknown shape kind");
+    }
+    if (firstPrim[d->n_shapes] != d->n_prims) return SetError(HPRT_E_INVALID, "prim_order length does not match the shapes' primitive count");
+    if (vtxBase[d->n_shapes] > 0xffffffffull) return SetError(HPRT_E_UNSUPPORTED, "more than 2^32 vertices");
+    {   // BVH sanity: every child/primitive reference must stay inside the arrays
+        const BvhNode *nd = (const BvhNode *)d->nodes;
+        for (uint32_t i = 0; i < d->n_nodes; ++i) {
+            uint32_t axis = nd[i].countAxis & 3u, cnt = nd[i].countAxis >> 2;
+            if (axis == 3u) { if (nd[i].offset < 0 || (uint64_t)nd[i].offset + cnt > d->n_prims) return SetError(HPRT_E_INVALID, "BVH leaf references primitives out of range"); }
+            else if (nd[i].offset <= (int32_t)i || (uint32_t)nd[i].offset >= d->n_nodes || i + 1 >= d->n_nodes) return SetError(HPRT_E_INVALID, "BVH interior node has an invalid child");
+        }
+        for (uint32_t i = 0; i < d->n_prims; ++i) if (d->prim_order[i] >= d->n_prims) return SetError(HPRT_E_INVALID, "prim_order entry out of range");
+    }
+    for (uint32_t l = 0; l < d->n_lights; ++l) {
+        const HprtLightDesc &L = d->lights[l];
+        if (L.type < 0 || L.type > 2) return SetError(HPRT_E_INVALID, "unknown light type");
+        if (L.type == 2 && (L.shape < 0 || (uint32_t)L.shape >= d->n_shapes || d->shapes[L.shape].kind != 1))
+            return SetError(HPRT_E_UNSUPPORTED, "diffuse area lights are supported on spheres only");
+    }
+    if (d->n_lights > 1 && d->light_strategy != 0)
+        return SetError(HPRT_E_UNSUPPORTED, "with more than one light only lightsamplestrategy \"uniform\" is in scope (SURVEY.md §2)");
+    int dev;
+    int rc = CheckDevice(device, &dev);
+    if (rc != HPRT_OK) return rc;
+
+    HprtScene *sc = new HprtScene();
+    sc->device = dev; sc->nPrims = d->n_prims;
+    std::unique_ptr<HprtScene> guard(sc);
+    // ---- flatten ----
+    const uint32_t nVtx = (uint32_t)vtxBase[d->n_shapes];
+    std::vector<float> vN(3 * (size_t)nVtx, 0.f), vUV(2 * (size_t)nVtx, 0.f), vS(3 * (size_t)nVtx, 0.f);
+    std::vector<DevShape> shapes(d->n_shapes);
+    std::vector<DevSphere> spheres; std::vector<int> sphereOfShape(d->n_shapes, -1);
+    for (uint32_t s = 0; s < d->n_shapes; ++s) {
+        const HprtShapeDesc &sh = d->shapes[s];
+        DevShape &o = shapes[s];
+        o.material = sh.material; o.areaLight = sh.area_light; o.sphere = -1;
+        o.flags = ((sh.reverse_orientation != 0) ^ (sh.transform_swaps_handedness != 0)) ? SHAPE_FLIP : 0u;
+        if (sh.reverse_orientation) o.flags |= SHAPE_REVERSE;
+        if (sh.kind == 0) {
+            size_t b = vtxBase[s];
+            if (sh.N) { o.flags |= SHAPE_HAS_N; memcpy(&vN[3 * b], sh.N, 12 * (size_t)sh.n_verts); }
+            if (sh.UV) { o.flags |= SHAPE_HAS_UV; memcpy(&vUV[2 * b], sh.UV, 8 * (size_t)sh.n_verts); }
+            if (sh.S) { o.flags |= SHAPE_HAS_S; memcpy(&vS[3 * b], sh.S, 12 * (size_t)sh.n_verts); }
+        } else {
+            DevSphere sp;
+            memcpy(sp.o2w.m, sh.object_to_world, 64); memcpy(sp.w2o.m, sh.world_to_object, 64);
+            sp.radius = sh.radius; sp.zMin = sh.z_min; sp.zMax = sh.z_max; sp.thetaMin = sh.theta_min; sp.thetaMax = sh.theta_max; sp.phiMax = sh.phi_max;
+            o.sphere = sphereOfShape[s] = (int)spheres.size();
+            spheres.push_back(sp);
+        }
+    }
+    std::vector<float4> tris(3 * (size_t)d->n_prims);
+    std::vector<uint32_t> primVtx(3 * (size_t)d->n_prims, 0u);
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        uint64_t pn = d->prim_order[i];
+        uint32_t s = (uint32_t)(std::upper_bound(firstPrim.begin(), firstPrim.end(), pn) - firstPrim.begin() - 1);
+        const HprtShapeDesc &sh = d->shapes[s];
+        float4 r0, r1, r2;
+        if (sh.kind == 0) {
+            uint64_t local = pn - firstPrim[s];
+            const int32_t *v = &sh.indices[3 * local];
+            const float *a = &sh.P[3 * (size_t)v[0]], *b = &sh.P[3 * (size_t)v[1]], *c = &sh.P[3 * (size_t)v[2]];
+            bool bogus = TriangleIsBogus(vec3(a[0], a[1], a[2]), vec3(b[0], b[1], b[2]), vec3(c[0], c[1], c[2]),
+                                         sh.UV ? &sh.UV[2 * (size_t)v[0]] : nullptr, sh.UV ? &sh.UV[2 * (size_t)v[1]] : nullptr,
+                                         sh.UV ? &sh.UV[2 * (size_t)v[2]] : nullptr);
+            uint32_t tag = bogus ? TAG_BOGUS : 0u;
+            r0 = make_float4(a[0], a[1], a[2], u2f(tag)); r1 = make_float4(b[0], b[1], b[2], u2f(s)); r2 = make_float4(c[0], c[1], c[2], u2f(0u));
+            for (int k = 0; k < 3; ++k) primVtx[3 * (size_t)i + k] = (uint32_t)(vtxBase[s] + (uint32_t)v[k]);
+        } else {
+            r0 = make_float4(0, 0, 0, u2f(TAG_SPHERE)); r1 = make_float4(0, 0, 0, u2f(s)); r2 = make_float4(0, 0, 0, u2f((uint32_t)sphereOfShape[s]));
+        }
+        tris[3 * (size_t)i] = r0; tris[3 * (size_t)i + 1] = r1; tris[3 * (size_t)i + 2] = r2;
+    }
+    std::vector<DevMaterial> mats(d->n_materials);
+    for (uint32_t m = 0; m < d->n_materials; ++m) {
+        const HprtMaterialDesc &in = d->materials[m];
+        if (in.type != 0 && in.type != 1) return SetError(HPRT_E_UNSUPPORTED, "material type outside the hot-path scope (matte, plastic)");
+        if (in.type == 0 && in.sigma != 0.f) return SetError(HPRT_E_UNSUPPORTED, "matte sigma != 0 (OrenNayar) is outside the hot-path scope");
+        DevMaterial &o = mats[m];
+        o.type = in.type; memcpy(o.Kd, in.Kd, 12); memcpy(o.Ks, in.Ks, 12);
+        o.alpha = in.remap_roughness ? RoughnessToAlpha(in.roughness) : in.roughness;
+    }
+    std::vector<DevLight> lights(d->n_lights);
+    for (uint32_t l = 0; l < d->n_lights; ++l) {
+        const HprtLightDesc &in = d->lights[l];
+        DevLight &o = lights[l];
+        o.type = in.type; memcpy(o.pos, in.pos, 12); memcpy(o.I, in.I, 12); o.shape = in.shape; o.twoSided = in.two_sided;
+        o.sphere = in.type == 2 ? sphereOfShape[in.shape] : -1;
+        o.shapeFlags = in.type == 2 ? shapes[in.shape].flags : 0u;
+    }
+    // UniformLightDistribution (core/lightdistrib.cpp:68-75) as a Distribution1D (core/sampling.h:57-70)
+    std::vector<float> func(std::max<uint32_t>(1, d->n_lights), 1.f), cdf(d->n_lights + 1, 0.f);
+    float funcInt = 0.f;
+    if (d->n_lights) {
+        int n = (int)d->n_lights;
+        for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / n;
+        funcInt = cdf[n];
+        if (funcInt == 0) for (int i = 1; i < n + 1; ++i) cdf[i] = float(i) / float(n);
+        else for (int i = 1; i < n + 1; ++i) cdf[i] /= funcInt;
+    }
+    // Halton tables + 64-bit division magics
+    const std::vector<uint16_t> &perms = HaltonPermutations();
+    std::vector<int32_t> primes(PrimeTable().begin(), PrimeTable().end()), primeSums(PrimeSumTable().begin(), PrimeSumTable().end());
+    std::vector<uint64_t> magic(primes.size());
+    for (size_t i = 0; i < primes.size(); ++i) magic[i] = 0xffffffffffffffffull / (uint64_t)primes[i] + 1ull;
+    // ---- upload ----
+    std::vector<BvhNode> nodeCopy((const BvhNode *)d->nodes, (const BvhNode *)d->nodes + d->n_nodes);
+    HIP_TRY(upload(sc->nodes, nodeCopy)); HIP_TRY(upload(sc->tris, tris)); HIP_TRY(upload(sc->primVtx, primVtx));
+    HIP_TRY(upload(sc->vN, vN)); HIP_TRY(upload(sc->vUV, vUV)); HIP_TRY(upload(sc->vS, vS));
+    HIP_TRY(upload(sc->shapes, shapes)); HIP_TRY(upload(sc->materials, mats)); HIP_TRY(upload(sc->lights, lights));
+    HIP_TRY(upload(sc->spheres, spheres)); HIP_TRY(upload(sc->lightFunc, func)); HIP_TRY(upload(sc->lightCdf, cdf));
+    HIP_TRY(upload(sc->perms, perms)); HIP_TRY(upload(sc->primes, primes)); HIP_TRY(upload(sc->primeSums, primeSums));
+    HIP_TRY(upload(sc->primeMagic, magic));
+    HIP_TRY(sc->counters.alloc(sizeof(DevCounters)));
+    HIP_TRY(hipMemset(sc->counters.p, 0, sizeof(DevCounters)));
+    DevScene &dv = sc->dev;
+    dv.nodes = sc->nodes.as<DevNode>(); dv.nNodes = d->n_nodes;
+    dv.tris = sc->tris.as<float4>(); dv.nPrims = d->n_prims;
+    dv.primVtx = sc->primVtx.as<uint32_t>();
+    dv.vN = sc->vN.as<float>(); dv.vUV = sc->vUV.as<float>(); dv.vS = sc->vS.as<float>();
+    dv.shapes = sc->shapes.as<DevShape>(); dv.nShapes = d->n_shapes;
+    dv.materials = sc->materials.as<DevMaterial>();
+    dv.lights = sc->lights.as<DevLight>(); dv.nLights = d->n_lights;
+    dv.spheres = sc->spheres.as<DevSphere>();
+    dv.lightFunc = sc->lightFunc.as<float>(); dv.lightCdf = sc->lightCdf.as<float>(); dv.lightFuncInt = funcInt;
+    dv.perms = sc->perms.as<uint16_t>(); dv.primes = sc->primes.as<int32_t>(); dv.primeSums = sc->primeSums.as<int32_t>();
+    dv.primeMagic = sc->primeMagic.as<uint64_t>();
+    // Scene::worldBound + Bounds3::BoundingSphere (core/scene.h:56-66, core/geometry.h:980-983)
+    dv.worldRadius = 0.f;
+    if (d->n_nodes) {
+        const BvhNode &root = nodeCopy[0];
+        vec3 lo(root.bmin[0], root.bmin[1], root.bmin[2]), hi(root.bmax[0], root.bmax[1], root.bmax[2]);
+        vec3 c = div_by(lo + hi, 2.f);
+        bool inside = c.x >= lo.x && c.x <= hi.x && c.y >= lo.y && c.y <= hi.y && c.z >= lo.z && c.z <= hi.z;
+        dv.worldRadius = inside ? dist(c, hi) : 0.f;
+    }
+    HIP_TRY(hipHostMalloc((void **)&sc->hostCounts, 64 * sizeof(uint32_t)));
+    *out = guard.release();
+    return HPRT_OK;
+}
+
+int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int device, HprtScene **out) {
+    if (!m || !b || !out) return SetError(HPRT_E_INVALID, "hprt_scene_create_from_model: null argument");
+    const SceneModel &sm = m->sc;
+    std::vector<HprtShapeDesc> shapes(sm.shapes.size());
+    for (size_t i = 0; i < sm.shapes.size(); ++i) {
+        const ShapeDesc &s = sm.shapes[i];
+        HprtShapeDesc &o = shapes[i];
+        memset(&o, 0, sizeof(o));
+        o.kind = s.kind; o.material = s.material; o.area_light = s.areaLight;
+        o.reverse_orientation = s.reverseOrientation; o.transform_swaps_handedness = s.transformSwapsHandedness;
+        if (s.kind == kTriangleMesh) {
+            o.n_tris = s.mesh.nTris(); o.n_verts = s.mesh.nVerts();
+            o.indices = s.mesh.indices.data(); o.P = s.mesh.P.data();
+            o.N = s.mesh.N.empty() ? nullptr : s.mesh.N.data();
+            o.UV = s.mesh.UV.empty() ? nullptr : s.mesh.UV.data();
+            o.S = s.mesh.S.empty() ? nullptr : s.mesh.S.data();
+        } else {
+            memcpy(o.object_to_world, s.sphere.objectToWorld.m, 64); memcpy(o.world_to_object, s.sphere.worldToObject.m, 64);
+            o.radius = s.sphere.radius; o.z_min = s.sphere.zMin; o.z_max = s.sphere.zMax;
+            o.theta_min = s.sphere.thetaMin; o.theta_max = s.sphere.thetaMax; o.phi_max = s.sphere.phiMax;
+        }
+    }
+    std::vector<HprtMaterialDesc> mats(sm.materials.size());
+    for (size_t i = 0; i < mats.size(); ++i) {
+        const MaterialDesc &s = sm.materials[i];
+        mats[i].type = s.type; memcpy(mats[i].Kd, s.Kd, 12); mats[i].sigma = s.sigma; memcpy(mats[i].Ks, s.Ks, 12);
+        mats[i].roughness = s.roughness; mats[i].remap_roughness = s.remapRoughness;
+    }
+    std::vector<HprtLightDesc> lights(sm.lights.size());
+    for (size_t i = 0; i < lights.size(); ++i) {
+        const LightDesc &s = sm.lights[i];
+        lights[i].type = s.type; memcpy(lights[i].pos, s.pos, 12); memcpy(lights[i].I, s.I, 12); lights[i].shape = s.shape; lights[i].two_sided = s.twoSided;
+    }
+    HprtSceneDesc d;
+    d.nodes = b->tree.nodes.data(); d.n_nodes = (uint32_t)b->tree.nodes.size();
+    d.prim_order = b->tree.primOrder.data(); d.n_prims = (uint32_t)b->tree.primOrder.size();
+    d.shapes = shapes.data(); d.n_shapes = (uint32_t)shapes.size();
+    d.materials = mats.data(); d.n_materials = (uint32_t)mats.size();
+    d.lights = lights.data(); d.n_lights = (uint32_t)lights.size();
+    // a single light always gets the uniform distribution (core/lightdistrib.cpp:50-52)
+    d.light_strategy = sm.lights.size() <= 1 ? 0 : sm.opt.lightStrategy;
+    return hprt_scene_create(&d, device, out);
+}
+
+void hprt_scene_destroy(HprtScene *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    delete s;
+}
+
+// ---------------------------------------------------------------------------
+// batched Aggregate calls
+// ---------------------------------------------------------------------------
+static void ReadCounters(HprtScene *s, bool anyHit, uint64_t out[4]) {
+    DevCounters c;
+    (void)hipMemcpy(&c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost);
+    if (!anyHit) { out[0] = c.nodesFetched; out[1] = c.nodesEntered; out[2] = c.triTests; out[3] = c.sphereTests; }
+    else { out[0] = c.nodesFetchedP; out[1] = c.nodesEnteredP; out[2] = c.triTestsP; out[3] = c.sphereTestsP; }
+}
+static RayPlanes RaysFrom7(const float *d7, size_t n) {
+    RayPlanes r; float *p = const_cast<float *>(d7);
+    r.ox = p; r.oy = p + n; r.oz = p + 2 * n; r.dx = p + 3 * n; r.dy = p + 4 * n; r.dz = p + 5 * n; r.tmax = p + 6 * n;
+    return r;
+}
+
+int hprt_intersect_device(HprtScene *s, size_t n, const float *d_rays7, float *d_t, int32_t *d_prim, float *d_bary3, void *stream) {
+    if (!s || (n && (!d_rays7 || !d_t || !d_prim))) return SetError(HPRT_E_INVALID, "hprt_intersect_device: null argument");
+    if (n > 0xfffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
+    HIP_TRY(hipSetDevice(s->device));
+    HitPlanes h; h.t = d_t; h.prim = d_prim;
+    h.b0 = d_bary3; h.b1 = d_bary3 ? d_bary3 + n : nullptr; h.b2 = d_bary3 ? d_bary3 + 2 * n : nullptr;
+    LaunchTrace((hipStream_t)stream, s->dev, false, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(d_rays7, n), h, nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    return HPRT_OK;
+}
+int hprt_occluded_device(HprtScene *s, size_t n, const float *d_rays7, uint8_t *d_occ, void *stream) {
+    if (!s || (n && (!d_rays7 || !d_occ))) return SetError(HPRT_E_INVALID, "hprt_occluded_device: null argument");
+    if (n > 0xfffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
+    HIP_TRY(hipSetDevice(s->device));
+    HitPlanes h; h.t = nullptr; h.prim = nullptr; h.b0 = h.b1 = h.b2 = nullptr;
+    LaunchTrace((hipStream_t)stream, s->dev, true, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(d_rays7, n), h, d_occ, nullptr);
+    HIP_TRY(hipGetLastError());
+    return HPRT_OK;
+}
+
+static int TraceHost(HprtScene *s, bool anyHit, size_t n, const float *o, const float *d, const float *tmax, float *t_out,
+                     int32_t *prim_out, float *bary_out, uint8_t *occ_out, uint64_t counters[4]) {
+    if (!s || (n && (!o || !d || !tmax))) return SetError(HPRT_E_INVALID, "trace: null argument");
+    if (n > 0xfffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
+    if (n == 0) { if (counters) memset(counters, 0, 32); return HPRT_OK; }
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<float> soa(7 * n);
+    for (size_t i = 0; i < n; ++i) {
+        soa[i] = o[3 * i]; soa[n + i] = o[3 * i + 1]; soa[2 * n + i] = o[3 * i + 2];
+        soa[3 * n + i] = d[3 * i]; soa[4 * n + i] = d[3 * i + 1]; soa[5 * n + i] = d[3 * i + 2];
+        soa[6 * n + i] = tmax[i];
+    }
+    DevBuf rays, outT, outPrim, outB, outOcc;
+    HIP_TRY(rays.alloc(28 * n)); HIP_TRY(hipMemcpy(rays.p, soa.data(), 28 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(s->counters.p, 0, sizeof(DevCounters)));
+    const bool count = counters != nullptr;
+    if (!anyHit) {
+        HIP_TRY(outT.alloc(4 * n)); HIP_TRY(outPrim.alloc(4 * n)); HIP_TRY(outB.alloc(12 * n));
+        HitPlanes h; h.t = outT.as<float>(); h.prim = outPrim.as<int32_t>();
+        h.b0 = outB.as<float>(); h.b1 = h.b0 + n; h.b2 = h.b0 + 2 * n;
+        LaunchTrace(nullptr, s->dev, false, count, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(rays.as<float>(), n), h, nullptr, s->counters.as<DevCounters>());
+        HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
+        if (t_out) HIP_TRY(hipMemcpy(t_out, outT.p, 4 * n, hipMemcpyDeviceToHost));
+        if (prim_out) HIP_TRY(hipMemcpy(prim_out, outPrim.p, 4 * n, hipMemcpyDeviceToHost));
+        if (bary_out) {
+            std::vector<float> b(3 * n);
+            HIP_TRY(hipMemcpy(b.data(), outB.p, 12 * n, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n; ++i) { bary_out[3 * i] = b[i]; bary_out[3 * i + 1] = b[n + i]; bary_out[3 * i + 2] = b[2 * n + i]; }
+        }
+    } else {
+        HIP_TRY(outOcc.alloc(n));
+        HitPlanes h; h.t = nullptr; h.prim = nullptr; h.b0 = h.b1 = h.b2 = nullptr;
+        LaunchTrace(nullptr, s->dev, true, count, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(rays.as<float>(), n), h, outOcc.as<uint8_t>(), s->counters.as<DevCounters>());
+        HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
+        if (occ_out) HIP_TRY(hipMemcpy(occ_out, outOcc.p, n, hipMemcpyDeviceToHost));
+    }
+    if (counters) ReadCounters(s, anyHit, counters);
+    return HPRT_OK;
+}
+int hprt_intersect(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, float *t_out, int32_t *prim_out,
+                   float *bary_out, uint64_t counters[4]) {
+    return TraceHost(s, false, n, o, d, tmax, t_out, prim_out, bary_out, nullptr, counters);
+}
+int hprt_occluded(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, uint8_t *occ, uint64_t counters[4]) {
+    return TraceHost(s, true, n, o, d, tmax, nullptr, nullptr, nullptr, occ, counters);
+}
+
+// ---------------------------------------------------------------------------
+// Render
+// ---------------------------------------------------------------------------
+namespace {
+
+struct BatchTimers { double extendMs = 0, occludedMs = 0; uint64_t extendLaunches = 0, occludedLaunches = 0, extendRays = 0, occludedRays = 0; };
+
+// Runs the bounce loop for one batch of nSlots freshly generated paths.
+int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const PathPlanes &ps, const QueueSet &qa, const QueueSet &qb,
+             uint32_t s0, uint32_t nSlots, bool count, EventTimer &ev, BatchTimers *bt, HprtRenderStats *stats) {
+    LaunchGenerate(st, s->dev, rp, ps, s0, nSlots);
+    const uint32_t *activeQ = nullptr; uint32_t active = nSlots;
+    QueueSet q[2] = {qa, qb};
+    DevCounters *ctr = s->counters.as<DevCounters>();
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evExt, evOcc;
+    for (int bounce = 0; active > 0; ++bounce) {
+        const QueueSet &cur = q[bounce & 1];
+        hipEvent_t e0 = ev.get(), e1 = ev.get();
+        HIP_TRY(hipEventRecord(e0, st));
+        LaunchTrace(st, s->dev, false, count, activeQ, nullptr, active, active, ps.ray, ps.hit, nullptr, ctr);
+        HIP_TRY(hipEventRecord(e1, st));
+        evExt.push_back({e0, e1}); bt->extendRays += active; ++bt->extendLaunches;
+        stats->rays += active;
+        HIP_TRY(hipMemsetAsync(cur.nextCount, 0, 4 * sizeof(uint32_t), st));   // the four counters are contiguous
+        LaunchShade(st, s->dev, rp, ps, activeQ, nullptr, active, active, s0, cur);
+        HIP_TRY(hipMemcpyAsync(s->hostCounts, cur.nextCount, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const uint32_t nNext = s->hostCounts[0], nShadow = s->hostCounts[1], nMis = s->hostCounts[2], nResolve = s->hostCounts[3];
+        if (nShadow) {
+            hipEvent_t a = ev.get(), b = ev.get();
+            HIP_TRY(hipEventRecord(a, st));
+            HitPlanes none; none.t = nullptr; none.prim = nullptr; none.b0 = none.b1 = none.b2 = nullptr;
+            LaunchTrace(st, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, ps.sh, none, ps.occluded, ctr);
+            HIP_TRY(hipEventRecord(b, st));
+            evOcc.push_back({a, b}); bt->occludedRays += nShadow; ++bt->occludedLaunches;
+            stats->shadow_rays += nShadow;
+        }
+        if (nMis) {
+            hipEvent_t a = ev.get(), b = ev.get();
+            HIP_TRY(hipEventRecord(a, st));
+            LaunchTrace(st, s->dev, false, count, cur.mis, nullptr, nMis, nMis, ps.mis, ps.misHit, nullptr, ctr);
+            HIP_TRY(hipEventRecord(b, st));
+            evExt.push_back({a, b}); bt->extendRays += nMis; ++bt->extendLaunches;
+            stats->rays += nMis;
+        }
+        if (nResolve) LaunchResolve(st, s->dev, ps, cur.resolve, cur.resolveCount, nResolve);
+        activeQ = cur.next; active = nNext;
+        if (bounce > 250) break;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    for (auto &p : evExt) { float ms = 0; if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) bt->extendMs += ms; }
+    for (auto &p : evOcc) { float ms = 0; if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) bt->occludedMs += ms; }
+    ev.reset();
+    return HPRT_OK;
+}
+
+int EnsureWorkspace(HprtScene *s, size_t nSlots, PathPlanes *ps, QueueSet *qa, QueueSet *qb) {
+    HIP_TRY(s->planes.alloc(PlaneBytes(nSlots)));
+    CarvePlanes(s->planes.as<char>(), nSlots, ps);
+    HIP_TRY(s->queues.alloc(8 * nSlots * sizeof(uint32_t) + 4096));
+    HIP_TRY(s->queueCounts.alloc(64 * sizeof(uint32_t)));
+    uint32_t *qbase = s->queues.as<uint32_t>(), *cbase = s->queueCounts.as<uint32_t>();
+    QueueSet *qs[2] = {qa, qb};
+    for (int k = 0; k < 2; ++k) {
+        qs[k]->next = qbase + (4 * k + 0) * nSlots; qs[k]->shadow = qbase + (4 * k + 1) * nSlots;
+        qs[k]->mis = qbase + (4 * k + 2) * nSlots; qs[k]->resolve = qbase + (4 * k + 3) * nSlots;
+        qs[k]->nextCount = cbase + 16 * k; qs[k]->shadowCount = cbase + 16 * k + 1; qs[k]->misCount = cbase + 16 * k + 2; qs[k]->resolveCount = cbase + 16 * k + 3;
+    }
+    return HPRT_OK;
+}
+
+// Host-side grouping of the irregular samples into per-destination lists, in the exact
+// order the reference's tile loop would have added them (core/integrator.cpp:267-333).
+struct ExtraEntry { uint32_t dest; uint32_t srcTile; uint32_t srcPos; uint32_t sample; uint32_t srcPix; uint8_t pre; };
+
+}  // namespace
+
+int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, void *stream, HprtRenderStats *stats) {
+    if (!s || !desc) return SetError(HPRT_E_INVALID, "hprt_render: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    const HprtRenderOptions &o = desc->opt;
+    if (o.spp <= 0 || o.max_depth < 0) return SetError(HPRT_E_INVALID, "spp must be positive and max_depth non-negative");
+    FrameSetup f;
+    int rc = SetupFrame(o, &f);
+    if (rc != HPRT_OK) return rc;
+    HprtRenderStats localStats; if (!stats) stats = &localStats;
+    memset(stats, 0, sizeof(*stats));
+    // ---- local tiles ----
+    const int nTiles = f.ntx * f.nty;
+    int tb = std::max(0, desc->tile_begin), te = desc->tile_end <= 0 ? nTiles : std::min(desc->tile_end, nTiles), ts = std::max(1, desc->tile_stride);
+    f.localIndex.assign((size_t)f.W * f.H, -1);
+    std::vector<uint8_t> tileIsLocal(nTiles, 0);
+    for (int t = tb; t < te; t += ts) { tileIsLocal[t] = 1; AddTilePixels(&f, t); }
+    const uint32_t nPix = (uint32_t)f.pixelXY.size();
+    const uint32_t spp = (uint32_t)o.spp;
+    s->filmPixels = (size_t)f.W * f.H;
+    float *film = d_film_xyzw;
+    if (!film) { HIP_TRY(s->film.alloc(16 * s->filmPixels)); film = s->film.as<float>(); }
+    HIP_TRY(hipMemsetAsync(film, 0, 16 * s->filmPixels, st));
+    if (nPix == 0) { HIP_TRY(hipStreamSynchronize(st)); return HPRT_OK; }
+    // ---- sizes ----
+    const size_t lallBytes = 3ull * spp * nPix * sizeof(float);
+    if (lallBytes > (96ull << 30)) return SetError(HPRT_E_UNSUPPORTED, "per-sample radiance store would exceed 96 GiB; render in several tile ranges");
+    uint32_t chunk = desc->spp_chunk > 0 ? (uint32_t)desc->spp_chunk : std::max<uint32_t>(1u, (uint32_t)((8u << 20) / std::max<uint32_t>(nPix, 1u)));
+    chunk = std::min(chunk, spp);
+    if ((uint64_t)chunk * nPix > 0x7fffffffull) chunk = (uint32_t)(0x7fffffffull / nPix);
+    const size_t maxSlots = (size_t)chunk * nPix;
+    PathPlanes ps; QueueSet qa, qb;
+    rc = EnsureWorkspace(s, maxSlots, &ps, &qa, &qb);
+    if (rc != HPRT_OK) return rc;
+    HIP_TRY(s->Lall.alloc(lallBytes));
+    float *LallR = s->Lall.as<float>(), *LallG = LallR + (size_t)spp * nPix, *LallB = LallG + (size_t)spp * nPix;
+    HIP_TRY(upload(s->pixelXY, f.pixelXY)); HIP_TRY(upload(s->pixelOffset, f.pixelOffset));
+    RenderParams rp;
+    MakeCamera(o, &rp.cam);
+    rp.hal.baseScale1 = f.hal.baseScales[1]; rp.hal.baseExp0 = f.hal.baseExponents[0]; rp.hal.sampleStride = f.hal.sampleStride;
+    rp.hal.samplePixelCenter = o.sample_pixel_center;
+    rp.pixelXY = s->pixelXY.as<uint32_t>(); rp.pixelOffset = s->pixelOffset.as<uint64_t>(); rp.nPix = nPix;
+    rp.maxDepth = o.max_depth; rp.rrThreshold = o.rr_threshold;
+    const bool count = (desc->flags & HPRT_RENDER_COUNT_WORK) != 0;
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, sizeof(DevCounters), st));
+
+    auto wall0 = std::chrono::high_resolution_clock::now();
+    // ---- film footprint pre-pass ----
+    const uint32_t irrCap = (uint32_t)std::min<uint64_t>((uint64_t)nPix * spp, 1u << 24);
+    HIP_TRY(s->irregular.alloc((size_t)irrCap * sizeof(IrregularSample)));
+    HIP_TRY(s->irregularCount.alloc(16));
+    HIP_TRY(hipMemsetAsync(s->irregularCount.p, 0, 16, st));
+    LaunchFindIrregular(st, s->dev, rp, f.fg, spp, s->irregularCount.as<uint32_t>(), irrCap, s->irregular.as<IrregularSample>());
+    HIP_TRY(hipMemcpyAsync(s->hostCounts + 8, s->irregularCount.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t nIrr = s->hostCounts[8];
+    if (nIrr > irrCap) return SetError(HPRT_E_UNSUPPORTED, "too many irregular film samples");
+    std::vector<IrregularSample> irr(nIrr);
+    if (nIrr) HIP_TRY(hipMemcpy(irr.data(), s->irregular.p, (size_t)nIrr * sizeof(IrregularSample), hipMemcpyDeviceToHost));
+    std::vector<ExtraEntry> own, foreign;
+    for (const IrregularSample &r : irr) {
+        const uint32_t pxy = f.pixelXY[r.pix];
+        const int qx = (int)(pxy & 0xffffu), qy = (int)(pxy >> 16);
+        const int qtx = (qx - f.fg.sx0) / 16, qty = (qy - f.fg.sy0) / 16;
+        const uint32_t qTile = (uint32_t)(qty * f.ntx + qtx);
+        const uint32_t qPos = (uint32_t)((qy - (f.fg.sy0 + qty * 16)) * 16 + (qx - (f.fg.sx0 + qtx * 16)));
+        for (int y = r.y0; y < r.y1; ++y)
+            for (int x = r.x0; x < r.x1; ++x) {
+                if (x == qx && y == qy) continue;
+                const int dtx = (x - f.fg.sx0) / 16, dty = (y - f.fg.sy0) / 16;
+                const uint32_t filmIdx = (uint32_t)((size_t)(y - f.fg.cy0) * f.W + (x - f.fg.cx0));
+                ExtraEntry e; e.srcTile = qTile; e.srcPos = qPos; e.sample = r.sample; e.srcPix = r.pix;
+                if (dtx == qtx && dty == qty) {
+                    e.dest = (uint32_t)f.localIndex[filmIdx];
+                    e.pre = (qy < y || (qy == y && qx < x)) ? 1 : 0;
+                    own.push_back(e);
+                } else { e.dest = filmIdx; e.pre = 0; foreign.push_back(e); }
+            }
+    }
+    std::sort(own.begin(), own.end(), [](const ExtraEntry &a, const ExtraEntry &b) {
+        if (a.dest != b.dest) return a.dest < b.dest;
+        if (a.srcPos != b.srcPos) return a.srcPos < b.srcPos;   // pre entries have smaller positions than the destination's
+        return a.sample < b.sample;
+    });
+    std::sort(foreign.begin(), foreign.end(), [](const ExtraEntry &a, const ExtraEntry &b) {
+        if (a.dest != b.dest) return a.dest < b.dest;
+        if (a.srcTile != b.srcTile) return a.srcTile < b.srcTile;
+        if (a.srcPos != b.srcPos) return a.srcPos < b.srcPos;
+        return a.sample < b.sample;
+    });
+    FilmExtras ex; memset(&ex, 0, sizeof(ex));
+    {
+        std::vector<uint32_t> begin(nPix + 1, 0), src(own.size()), smp(own.size()); std::vector<uint8_t> pre(own.size());
+        for (const ExtraEntry &e : own) ++begin[e.dest + 1];
+        for (uint32_t i = 0; i < nPix; ++i) begin[i + 1] += begin[i];
+        for (size_t i = 0; i < own.size(); ++i) { src[i] = own[i].srcPix; smp[i] = own[i].sample; pre[i] = own[i].pre; }
+        HIP_TRY(upload(s->exOwnBegin, begin)); HIP_TRY(upload(s->exOwnSrc, src)); HIP_TRY(upload(s->exOwnSample, smp)); HIP_TRY(upload(s->exOwnPre, pre));
+        ex.ownBegin = s->exOwnBegin.as<uint32_t>(); ex.ownSrcPix = s->exOwnSrc.as<uint32_t>(); ex.ownSample = s->exOwnSample.as<uint32_t>(); ex.ownIsPre = s->exOwnPre.as<uint8_t>();
+        std::vector<uint32_t> dest, destBegin, groupBegin, fsrc(foreign.size()), fsmp(foreign.size());
+        for (size_t i = 0; i < foreign.size(); ++i) {
+            const bool newDest = i == 0 || foreign[i].dest != foreign[i - 1].dest;
+            const bool newGroup = newDest || foreign[i].srcTile != foreign[i - 1].srcTile;
+            if (newDest) { dest.push_back(foreign[i].dest); destBegin.push_back((uint32_t)groupBegin.size()); }
+            if (newGroup) groupBegin.push_back((uint32_t)i);
+            fsrc[i] = foreign[i].srcPix; fsmp[i] = foreign[i].sample;
+        }
+        destBegin.push_back((uint32_t)groupBegin.size()); groupBegin.push_back((uint32_t)foreign.size());
+        HIP_TRY(upload(s->exFDest, dest)); HIP_TRY(upload(s->exFDestBegin, destBegin)); HIP_TRY(upload(s->exFGroupBegin, groupBegin));
+        HIP_TRY(upload(s->exFSrc, fsrc)); HIP_TRY(upload(s->exFSample, fsmp));
+        ex.nForeignDest = (uint32_t)dest.size();
+        ex.foreignDestFilmIndex = s->exFDest.as<uint32_t>(); ex.foreignDestBegin = s->exFDestBegin.as<uint32_t>(); ex.foreignGroupBegin = s->exFGroupBegin.as<uint32_t>();
+        ex.foreignSrcPix = s->exFSrc.as<uint32_t>(); ex.foreignSample = s->exFSample.as<uint32_t>();
+    }
+    // ---- batches ----
+    EventTimer ev; BatchTimers bt;
+    for (uint32_t s0 = 0; s0 < spp; s0 += chunk) {
+        const uint32_t c = std::min(chunk, spp - s0), nSlots = c * nPix;
+        rc = RunBatch(s, st, rp, ps, qa, qb, s0, nSlots, count, ev, &bt, stats);
+        if (rc != HPRT_OK) return rc;
+        LaunchStoreRadiance(st, ps, LallR, LallG, LallB, nPix, s0, nSlots);
+    }
+    LaunchFilmOwn(st, rp, f.fg, LallR, LallG, LallB, spp, ex, film);
+    LaunchFilmForeign(st, rp, f.fg, LallR, LallG, LallB, ex, film);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    stats->render_seconds = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - wall0).count();
+    stats->camera_rays = (uint64_t)nPix * spp;
+    stats->extend_seconds = bt.extendMs * 1e-3; stats->occluded_seconds = bt.occludedMs * 1e-3;
+    stats->extend_launches = bt.extendLaunches; stats->occluded_launches = bt.occludedLaunches;
+    stats->extend_rays = bt.extendRays; stats->occluded_rays = bt.occludedRays;
+    if (count) {
+        DevCounters c;
+        HIP_TRY(hipMemcpy(&c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+        stats->nodes_fetched = c.nodesFetched; stats->nodes_entered = c.nodesEntered; stats->tri_tests = c.triTests; stats->sphere_tests = c.sphereTests;
+        stats->nodes_fetched_p = c.nodesFetchedP; stats->nodes_entered_p = c.nodesEnteredP; stats->tri_tests_p = c.triTestsP; stats->sphere_tests_p = c.sphereTestsP;
+    }
+    return HPRT_OK;
+}
+
+int hprt_film_read(HprtScene *s, float *xyzw_out, size_t n_pixels) {
+    if (!s || !xyzw_out) return SetError(HPRT_E_INVALID, "hprt_film_read: null argument");
+    if (!s->film.p || n_pixels != s->filmPixels) return SetError(HPRT_E_INVALID, "hprt_film_read: no library-owned film of that size (render with d_film_xyzw == NULL first)");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpy(xyzw_out, s->film.p, 16 * n_pixels, hipMemcpyDeviceToHost));
+    return HPRT_OK;
+}
+
+int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, const int32_t *px, const int32_t *py, const int64_t *sample,
+                         float *L_out) {
+    if (!s || !opt || (n && (!px || !py || !sample || !L_out))) return SetError(HPRT_E_INVALID, "hprt_sample_radiance: null argument");
+    if (n == 0) return HPRT_OK;
+    if (n > (1u << 26)) return SetError(HPRT_E_INVALID, "hprt_sample_radiance: too many samples in one call");
+    HIP_TRY(hipSetDevice(s->device));
+    FrameSetup f;
+    int rc = SetupFrame(*opt, &f);
+    if (rc != HPRT_OK) return rc;
+    std::vector<uint32_t> xy(n); std::vector<uint64_t> off(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (px[i] < f.fg.sx0 || px[i] >= f.fg.sx1 || py[i] < f.fg.sy0 || py[i] >= f.fg.sy1 || sample[i] < 0)
+            return SetError(HPRT_E_INVALID, "hprt_sample_radiance: pixel outside the sample bounds");
+        xy[i] = (uint32_t)px[i] | ((uint32_t)py[i] << 16);
+        off[i] = (uint64_t)HaltonPixelOffset(f.hal, px[i], py[i]) + (uint64_t)sample[i] * (uint64_t)f.hal.sampleStride;
+    }
+    PathPlanes ps; QueueSet qa, qb;
+    rc = EnsureWorkspace(s, n, &ps, &qa, &qb);
+    if (rc != HPRT_OK) return rc;
+    HIP_TRY(upload(s->pixelXY, xy)); HIP_TRY(upload(s->pixelOffset, off));
+    HIP_TRY(s->Lall.alloc(12 * n));
+    RenderParams rp;
+    MakeCamera(*opt, &rp.cam);
+    rp.hal.baseScale1 = f.hal.baseScales[1]; rp.hal.baseExp0 = f.hal.baseExponents[0]; rp.hal.sampleStride = f.hal.sampleStride;
+    rp.hal.samplePixelCenter = opt->sample_pixel_center;
+    rp.pixelXY = s->pixelXY.as<uint32_t>(); rp.pixelOffset = s->pixelOffset.as<uint64_t>(); rp.nPix = (uint32_t)n;
+    rp.maxDepth = opt->max_depth; rp.rrThreshold = opt->rr_threshold;
+    EventTimer ev; BatchTimers bt; HprtRenderStats stats; memset(&stats, 0, sizeof(stats));
+    rc = RunBatch(s, nullptr, rp, ps, qa, qb, 0, (uint32_t)n, false, ev, &bt, &stats);
+    if (rc != HPRT_OK) return rc;
+    float *LR = s->Lall.as<float>();
+    LaunchStoreRadiance(nullptr, ps, LR, LR + n, LR + 2 * n, (uint32_t)n, 0, (uint32_t)n);
+    HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
+    std::vector<float> planes(3 * n);
+    HIP_TRY(hipMemcpy(planes.data(), LR, 12 * n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) { L_out[3 * i] = planes[i]; L_out[3 * i + 1] = planes[n + i]; L_out[3 * i + 2] = planes[2 * n + i]; }
+    return HPRT_OK;
+}
+
+}  // extern "C"

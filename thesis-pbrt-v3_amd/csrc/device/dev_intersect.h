@@ -1,0 +1,244 @@
+// hprt device side — ray/primitive tests and the ordered-stack BVH walk.
+// Restates, operation for operation: Bounds3::IntersectP (core/geometry.h:1754-1780),
+// Triangle::Intersect/IntersectP test part (shapes/triangle.cpp:193-292 / :431-530),
+// Sphere::Intersect/IntersectP test part with EFloat bounds (shapes/sphere.cpp:49-104,
+// core/efloat.h), BVHAccel::Intersect/IntersectP (accelerators/bvh.cpp:354-437).
+#pragma once
+#include "dev_scene.h"
+
+namespace hprt {
+
+struct DRay { vec3 o, d; float tMax; };
+
+// ---- triangle -------------------------------------------------------------
+__device__ __forceinline__ bool tri_test(vec3 p0, vec3 p1, vec3 p2, const DRay &ray, float *b0o, float *b1o,
+                                         float *b2o, float *to) {
+    vec3 p0t = p0 - ray.o, p1t = p1 - ray.o, p2t = p2 - ray.o;
+    int kz = max_dim(vabs(ray.d));
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    vec3 d(ray.d.get(kx), ray.d.get(ky), ray.d.get(kz));
+    p0t = vec3(p0t.get(kx), p0t.get(ky), p0t.get(kz));
+    p1t = vec3(p1t.get(kx), p1t.get(ky), p1t.get(kz));
+    p2t = vec3(p2t.get(kx), p2t.get(ky), p2t.get(kz));
+    float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1.f / d.z;
+    p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
+    p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
+    p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {   // double-precision fallback at edges
+        double p2txp1ty = (double)p2t.x * (double)p1t.y;
+        double p2typ1tx = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0t.x * (double)p2t.y;
+        double p0typ2tx = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1t.x * (double)p0t.y;
+        double p1typ0tx = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0) return false;
+    p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
+    float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0 && (tScaled >= 0 || tScaled < ray.tMax * det)) return false;
+    else if (det > 0 && (tScaled <= 0 || tScaled > ray.tMax * det)) return false;
+    float invDet = 1 / det;
+    float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
+    float t = tScaled * invDet;
+    float maxZt = max_comp(vabs(vec3(p0t.z, p1t.z, p2t.z)));
+    float deltaZ = gamma_n(3) * maxZt;
+    float maxXt = max_comp(vabs(vec3(p0t.x, p1t.x, p2t.x)));
+    float maxYt = max_comp(vabs(vec3(p0t.y, p1t.y, p2t.y)));
+    float deltaX = gamma_n(5) * (maxXt + maxZt);
+    float deltaY = gamma_n(5) * (maxYt + maxZt);
+    float deltaE = 2 * (gamma_n(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+    float maxE = max_comp(vabs(vec3(e0, e1, e2)));
+    float deltaT = 3 * (gamma_n(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * fabsf(invDet);
+    if (t <= deltaT) return false;
+    *b0o = b0; *b1o = b1; *b2o = b2; *to = t;
+    return true;
+}
+
+// ---- EFloat interval arithmetic (core/efloat.h, NDEBUG layout) --------------
+struct efloat { float v, lo, hi; };
+__device__ __forceinline__ efloat ef(float v) { efloat r; r.v = v; r.lo = v; r.hi = v; return r; }
+__device__ __forceinline__ efloat ef(float v, float err) {
+    efloat r; r.v = v;
+    if (err == 0.f) { r.lo = v; r.hi = v; } else { r.lo = next_down(v - err); r.hi = next_up(v + err); }
+    return r;
+}
+__device__ __forceinline__ efloat ef_add(efloat a, efloat b) { efloat r; r.v = a.v + b.v; r.lo = next_down(a.lo + b.lo); r.hi = next_up(a.hi + b.hi); return r; }
+__device__ __forceinline__ efloat ef_sub(efloat a, efloat b) { efloat r; r.v = a.v - b.v; r.lo = next_down(a.lo - b.hi); r.hi = next_up(a.hi - b.lo); return r; }
+__device__ __forceinline__ efloat ef_mul(efloat a, efloat b) {
+    efloat r; r.v = a.v * b.v;
+    float p0 = a.lo * b.lo, p1 = a.hi * b.lo, p2 = a.lo * b.hi, p3 = a.hi * b.hi;
+    r.lo = next_down(sel_min(sel_min(p0, p1), sel_min(p2, p3)));
+    r.hi = next_up(sel_max(sel_max(p0, p1), sel_max(p2, p3)));
+    return r;
+}
+__device__ __forceinline__ efloat ef_div(efloat a, efloat b) {
+    efloat r; r.v = a.v / b.v;
+    if (b.lo < 0 && b.hi > 0) { r.lo = -HPRT_INF; r.hi = HPRT_INF; }
+    else {
+        float d0 = a.lo / b.lo, d1 = a.hi / b.lo, d2 = a.lo / b.hi, d3 = a.hi / b.hi;
+        r.lo = next_down(sel_min(sel_min(d0, d1), sel_min(d2, d3)));
+        r.hi = next_up(sel_max(sel_max(d0, d1), sel_max(d2, d3)));
+    }
+    return r;
+}
+// core/efloat.h:267-288
+__device__ __forceinline__ bool ef_quadratic(efloat A, efloat B, efloat C, efloat *t0, efloat *t1) {
+    double discrim = (double)B.v * (double)B.v - 4. * (double)A.v * (double)C.v;
+    if (discrim < 0.) return false;
+    double rootDiscrim = sqrt(discrim);
+    efloat fr = ef((float)rootDiscrim, (float)((double)HPRT_MACHINE_EPS * rootDiscrim));
+    efloat q;
+    if (B.v < 0) q = ef_mul(ef(-.5f), ef_sub(B, fr));
+    else q = ef_mul(ef(-.5f), ef_add(B, fr));
+    *t0 = ef_div(q, A);
+    *t1 = ef_div(C, q);
+    if (t0->v > t1->v) { efloat tmp = *t0; *t0 = *t1; *t1 = tmp; }
+    return true;
+}
+
+// Quadric test shared by Sphere::Intersect and IntersectP (shapes/sphere.cpp:49-104 == :159-213).
+__device__ __noinline__ bool sphere_test(const DevSphere &s, const DRay &r, DRay *rayObj, vec3 *pHitOut, float *phiOut,
+                                         float *tOut) {
+    vec3 oErr, dErr;
+    // Transform::operator()(Ray, oError, dError), core/transform.h:349-360
+    vec3 o = xf_point_err(s.w2o, r.o, &oErr);
+    vec3 d = xf_vector_err(s.w2o, r.d, &dErr);
+    float len2 = length2(d);
+    if (len2 > 0) { float dt = dot(vabs(d), oErr) / len2; o = o + d * dt; }
+    DRay ray; ray.o = o; ray.d = d; ray.tMax = r.tMax;
+    efloat ox = ef(ray.o.x, oErr.x), oy = ef(ray.o.y, oErr.y), oz = ef(ray.o.z, oErr.z);
+    efloat dx = ef(ray.d.x, dErr.x), dy = ef(ray.d.y, dErr.y), dz = ef(ray.d.z, dErr.z);
+    efloat a = ef_add(ef_add(ef_mul(dx, dx), ef_mul(dy, dy)), ef_mul(dz, dz));
+    efloat b = ef_mul(ef(2.f), ef_add(ef_add(ef_mul(dx, ox), ef_mul(dy, oy)), ef_mul(dz, oz)));
+    efloat c = ef_sub(ef_add(ef_add(ef_mul(ox, ox), ef_mul(oy, oy)), ef_mul(oz, oz)), ef_mul(ef(s.radius), ef(s.radius)));
+    efloat t0, t1;
+    if (!ef_quadratic(a, b, c, &t0, &t1)) return false;
+    if (t0.hi > ray.tMax || t1.lo <= 0) return false;
+    efloat tHit = t0;
+    if (tHit.lo <= 0) { tHit = t1; if (tHit.hi > ray.tMax) return false; }
+    vec3 pHit = ray.o + ray.d * tHit.v;
+    pHit = pHit * (s.radius / dist(pHit, vec3(0, 0, 0)));
+    if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * s.radius;
+    float phi = det_atan2f(pHit.y, pHit.x);
+    if (phi < 0) phi += 2 * HPRT_PI;
+    if ((s.zMin > -s.radius && pHit.z < s.zMin) || (s.zMax < s.radius && pHit.z > s.zMax) || phi > s.phiMax) {
+        if (tHit.v == t1.v) return false;
+        if (t1.hi > ray.tMax) return false;
+        tHit = t1;
+        pHit = ray.o + ray.d * tHit.v;
+        pHit = pHit * (s.radius / dist(pHit, vec3(0, 0, 0)));
+        if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * s.radius;
+        phi = det_atan2f(pHit.y, pHit.x);
+        if (phi < 0) phi += 2 * HPRT_PI;
+        if ((s.zMin > -s.radius && pHit.z < s.zMin) || (s.zMax < s.radius && pHit.z > s.zMax) || phi > s.phiMax) return false;
+    }
+    *rayObj = ray; *pHitOut = pHit; *phiOut = phi; *tOut = tHit.v;
+    return true;
+}
+
+// ---- BVH walk ---------------------------------------------------------------
+// Per-lane traversal stack: the first LDS_STACK entries live in LDS, laid out
+// [entry][thread] so a wave's 64 lanes hit 64 consecutive dwords (no bank conflict);
+// deeper entries spill to a private array (the reference reserves 64 entries,
+// accelerators/bvh.cpp:362; the bundled scenes need <= 26).
+#define HPRT_LDS_STACK 24
+#define HPRT_SPILL_STACK 40
+#define HPRT_TRACE_BLOCK 256
+
+struct TraceCount { unsigned int fetched, entered, tri, sphere; };
+
+template <bool ANY_HIT, bool COUNT>
+__device__ __forceinline__ bool bvh_walk(const DevScene &sc, DRay &ray, int *ldsStack, int32_t *primOut, float *b0o,
+                                         float *b1o, float *b2o, TraceCount &cnt) {
+    bool hit = false;
+    if (sc.nNodes == 0) return false;
+    const vec3 invDir(1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z);
+    const int negX = invDir.x < 0, negY = invDir.y < 0, negZ = invDir.z < 0;
+    const float robust = 1 + 2 * gamma_n(3);
+    int spill[HPRT_SPILL_STACK];
+    int sp = 0, cur = 0;
+    const float4 *nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
+    while (true) {
+        const float4 n0 = nodes4[2 * cur], n1 = nodes4[2 * cur + 1];   // {min.xyz,max.x} {max.yz,offset,countAxis}
+        if (COUNT) ++cnt.fetched;
+        // Bounds3::IntersectP(ray, invDir, dirIsNeg)
+        const float bminx = n0.x, bminy = n0.y, bminz = n0.z, bmaxx = n0.w, bmaxy = n1.x, bmaxz = n1.y;
+        float tMin = ((negX ? bmaxx : bminx) - ray.o.x) * invDir.x;
+        float tMax = ((negX ? bminx : bmaxx) - ray.o.x) * invDir.x;
+        float tyMin = ((negY ? bmaxy : bminy) - ray.o.y) * invDir.y;
+        float tyMax = ((negY ? bminy : bmaxy) - ray.o.y) * invDir.y;
+        tMax *= robust; tyMax *= robust;
+        bool inside = !(tMin > tyMax || tyMin > tMax);
+        if (inside) {
+            if (tyMin > tMin) tMin = tyMin;
+            if (tyMax < tMax) tMax = tyMax;
+            float tzMin = ((negZ ? bmaxz : bminz) - ray.o.z) * invDir.z;
+            float tzMax = ((negZ ? bminz : bmaxz) - ray.o.z) * invDir.z;
+            tzMax *= robust;
+            inside = !(tMin > tzMax || tzMin > tMax);
+            if (inside) {
+                if (tzMin > tMin) tMin = tzMin;
+                if (tzMax < tMax) tMax = tzMax;
+                inside = (tMin < ray.tMax) && (tMax > 0);
+            }
+        }
+        const int32_t offset = __float_as_int(n1.z);
+        const uint32_t countAxis = __float_as_uint(n1.w);
+        bool popNext = true;
+        if (inside) {
+            if (COUNT) ++cnt.entered;
+            const uint32_t axis = countAxis & 3u;
+            if (axis == 3u) {
+                const uint32_t nP = countAxis >> 2;
+                for (uint32_t i = 0; i < nP; ++i) {
+                    const uint32_t pi = (uint32_t)offset + i;
+                    const float4 v0 = sc.tris[3 * pi], v1 = sc.tris[3 * pi + 1], v2 = sc.tris[3 * pi + 2];
+                    const uint32_t tag = __float_as_uint(v0.w);
+                    if ((tag & TAG_KIND_MASK) == 0u) {
+                        if (COUNT) ++cnt.tri;
+                        float b0, b1, b2, t;
+                        if (tri_test(vec3(v0.x, v0.y, v0.z), vec3(v1.x, v1.y, v1.z), vec3(v2.x, v2.y, v2.z), ray, &b0, &b1, &b2, &t)) {
+                            if (ANY_HIT) return true;
+                            if (!(tag & TAG_BOGUS)) {       // zero-area triangles: Triangle::Intersect rejects
+                                hit = true; ray.tMax = t; *primOut = (int32_t)pi; *b0o = b0; *b1o = b1; *b2o = b2;
+                            }
+                        }
+                    } else {
+                        if (COUNT) ++cnt.sphere;
+                        DRay ro; vec3 ph; float phi, t;
+                        if (sphere_test(sc.spheres[__float_as_uint(v2.w)], ray, &ro, &ph, &phi, &t)) {
+                            if (ANY_HIT) return true;
+                            hit = true; ray.tMax = t; *primOut = (int32_t)pi; *b0o = 0.f; *b1o = 0.f; *b2o = 0.f;
+                        }
+                    }
+                }
+            } else {
+                const int isNeg = axis == 0 ? negX : (axis == 1 ? negY : negZ);
+                int farNode, nearNode;
+                if (isNeg) { farNode = cur + 1; nearNode = offset; } else { farNode = offset; nearNode = cur + 1; }
+                if (sp < HPRT_LDS_STACK) ldsStack[sp * HPRT_TRACE_BLOCK] = farNode;
+                else if (sp - HPRT_LDS_STACK < HPRT_SPILL_STACK) spill[sp - HPRT_LDS_STACK] = farNode;
+                ++sp;
+                cur = nearNode;
+                popNext = false;
+            }
+        }
+        if (popNext) {
+            if (sp == 0) break;
+            --sp;
+            cur = (sp < HPRT_LDS_STACK) ? ldsStack[sp * HPRT_TRACE_BLOCK] : spill[sp - HPRT_LDS_STACK];
+        }
+    }
+    return hit;
+}
+
+}  // namespace hprt

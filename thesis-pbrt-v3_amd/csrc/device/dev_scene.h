@@ -1,0 +1,57 @@
+// hprt device side — plain-data view of the scene in HBM, passed to kernels by value.
+//
+// HBM layout (all arrays 16-byte aligned, allocated once per scene):
+//   nodes      BvhNode[nNodes]      32 B/node; byte-identical to the reference's
+//                                    LinearBVHNode[] (accelerators/bvh.cpp:123-152).  A
+//                                    traversal step reads one node as two float4 (one 32-B
+//                                    sector: whole 64-B cache lines hold 2 nodes, a parent and
+//                                    its first child are adjacent).
+//   tris       float4[3*nPrims]     48 B/primitive in BVH (ordered) order, vertices
+//                                    pre-gathered: {p0,tag} {p1,shape} {p2,aux}.  Replaces the
+//                                    reference's primitive -> shape -> mesh -> index -> vertex
+//                                    pointer chase (core/primitive.cpp:118-138) by one
+//                                    contiguous 48-B read per triangle test.  tag bits: 0-1
+//                                    kind (0 triangle, 1 sphere), bit 2 "bogus" (zero-area
+//                                    triangle: Triangle::Intersect returns false at
+//                                    shapes/triangle.cpp:309-316, IntersectP does not).
+//                                    For spheres aux = sphere index.
+//   primVtx    uint32[3*nPrims]     global vertex ids of the ordered triangle (shading only)
+//   vN/vUV/vS  float[3|2|3 * nVtx]  shading attributes; a shape's presence bits say which
+//   shapes, materials, lights, spheres, lightCdf: small tables.
+#pragma once
+#include "../hprt_math.h"
+
+namespace hprt {
+
+struct DevNode { float bmin[3], bmax[3]; int32_t offset; uint32_t countAxis; };
+
+enum : uint32_t { TAG_KIND_MASK = 3u, TAG_SPHERE = 1u, TAG_BOGUS = 4u };
+enum : uint32_t { SHAPE_FLIP = 1u, SHAPE_HAS_N = 2u, SHAPE_HAS_UV = 4u, SHAPE_HAS_S = 8u, SHAPE_REVERSE = 16u };
+
+struct DevShape { int32_t material, areaLight; uint32_t flags; int32_t sphere; };
+struct DevMaterial { int32_t type; float Kd[3]; float Ks[3]; float alpha; };   // alpha: RoughnessToAlpha applied on the host
+struct DevLight { int32_t type; float pos[3]; float I[3]; int32_t shape; int32_t twoSided; int32_t sphere; uint32_t shapeFlags; };
+struct DevSphere { mat4 o2w, w2o; float radius, zMin, zMax, thetaMin, thetaMax, phiMax; };
+
+struct DevScene {
+    const DevNode *nodes; uint32_t nNodes;
+    const float4 *tris; uint32_t nPrims;
+    const uint32_t *primVtx;
+    const float *vN, *vUV, *vS;
+    const DevShape *shapes; uint32_t nShapes;
+    const DevMaterial *materials;
+    const DevLight *lights; uint32_t nLights;
+    const DevSphere *spheres;
+    const float *lightFunc, *lightCdf; float lightFuncInt;      // Distribution1D (core/sampling.h:55-109)
+    float worldRadius;                                           // DistantLight::Preprocess
+    // Halton tables
+    const uint16_t *perms; const int32_t *primes; const int32_t *primeSums; const uint64_t *primeMagic;
+};
+
+// counters accumulated by the traversal kernels when counting is requested
+struct DevCounters {
+    unsigned long long nodesFetched, nodesEntered, triTests, sphereTests;         // closest hit
+    unsigned long long nodesFetchedP, nodesEnteredP, triTestsP, sphereTestsP;     // any hit
+};
+
+}  // namespace hprt

@@ -1,0 +1,527 @@
+// hprt device side — everything PathIntegrator::Li evaluates at a path vertex:
+// Halton sampler (samplers/halton.cpp, core/lowdiscrepancy.cpp), perspective camera
+// (cameras/perspective.cpp:95-144), surface-interaction fill for triangles and
+// spheres (shapes/triangle.cpp:294-425, shapes/sphere.cpp:106-157), matte/plastic
+// BSDFs (core/reflection.cpp, core/microfacet.cpp), point/distant/sphere-area lights
+// (lights/*.cpp, shapes/sphere.cpp:217-306) and ray spawning (core/interaction.h:64-78).
+#pragma once
+#include "dev_intersect.h"
+
+namespace hprt {
+
+// ---------------------------------------------------------------------------
+// Halton sampler
+// ---------------------------------------------------------------------------
+struct DevHalton {
+    int32_t baseScale1;       // baseScales[1] (power of 3)
+    int32_t baseExp0;         // baseExponents[0]
+    int32_t sampleStride;
+    int32_t samplePixelCenter;
+};
+
+// floor(a / base) for a < 2^32 via Lemire's 64-bit magic M = floor((2^64-1)/base)+1:
+// q = (M * a) >> 64, exact for every 32-bit a.
+__device__ __forceinline__ uint32_t div_magic32(uint32_t a, uint64_t M) {
+    uint64_t t = (uint64_t)(uint32_t)M * a;
+    uint64_t u = (M >> 32) * (uint64_t)a + (t >> 32);
+    return (uint32_t)(u >> 32);
+}
+__device__ __forceinline__ uint64_t reverse_bits64(uint64_t n) {
+    return ((uint64_t)__brev((uint32_t)n) << 32) | (uint64_t)__brev((uint32_t)(n >> 32));
+}
+// RadicalInverseSpecialized<base> / ScrambledRadicalInverseSpecialized<base>
+// (core/lowdiscrepancy.cpp:389-424); perm == nullptr selects the unscrambled form.
+__device__ __forceinline__ float radical_inverse_base(uint32_t base, uint64_t M, uint64_t a, const uint16_t *perm) {
+    const float invBase = 1.0f / (float)base;
+    uint64_t reversedDigits = 0;
+    float invBaseN = 1;
+    while (a) {
+        uint64_t next;
+        if (a <= 0xffffffffull) next = div_magic32((uint32_t)a, M);
+        else next = a / base;
+        uint32_t digit = (uint32_t)(a - next * base);
+        reversedDigits = reversedDigits * base + (perm ? (uint32_t)perm[digit] : digit);
+        invBaseN *= invBase;
+        a = next;
+    }
+    float v;
+    if (perm) v = invBaseN * ((float)reversedDigits + invBase * (float)perm[0] / (1 - invBase));
+    else v = (float)reversedDigits * invBaseN;
+    return sel_min(v, HPRT_ONE_MINUS_EPS);
+}
+// HaltonSampler::SampleDimension, samplers/halton.cpp:119-127
+__device__ __forceinline__ float halton_dim(const DevScene &sc, const DevHalton &h, uint64_t index, int dim) {
+    if (h.samplePixelCenter && (dim == 0 || dim == 1)) return 0.5f;
+    if (dim == 0) return (float)((double)reverse_bits64(index >> h.baseExp0) * 0x1p-64);
+    if (dim == 1) return radical_inverse_base(3u, sc.primeMagic[1], index / (uint64_t)h.baseScale1, nullptr);
+    return radical_inverse_base((uint32_t)sc.primes[dim], sc.primeMagic[dim], index, sc.perms + sc.primeSums[dim]);
+}
+
+// ---------------------------------------------------------------------------
+// Camera
+// ---------------------------------------------------------------------------
+struct DevCamera { mat4 rasterToCamera, cameraToWorld; float lensRadius, focalDistance; };
+
+// core/sampling.cpp:113-130
+__device__ __forceinline__ void concentric_disk(float ux, float uy, float *dx, float *dy) {
+    float ox = 2.f * ux - 1, oy = 2.f * uy - 1;
+    if (ox == 0 && oy == 0) { *dx = 0; *dy = 0; return; }
+    float theta, r;
+    if (fabsf(ox) > fabsf(oy)) { r = ox; theta = HPRT_PI_OVER_4 * (oy / ox); }
+    else { r = oy; theta = HPRT_PI_OVER_2 - HPRT_PI_OVER_4 * (ox / oy); }
+    *dx = r * det_cosf(theta); *dy = r * det_sinf(theta);
+}
+// PerspectiveCamera::GenerateRayDifferential main ray + CameraToWorld(ray) (transform.h:245-259)
+__device__ __forceinline__ void camera_ray(const DevCamera &cam, float fx, float fy, float lu, float lv, DRay *out) {
+    vec3 pCamera = xf_point(cam.rasterToCamera, vec3(fx, fy, 0));
+    vec3 ro(0, 0, 0), rd = normalize(vec3(pCamera.x, pCamera.y, pCamera.z));
+    if (cam.lensRadius > 0) {
+        float cx, cy; concentric_disk(lu, lv, &cx, &cy);
+        float lx = cam.lensRadius * cx, ly = cam.lensRadius * cy;
+        float ft = cam.focalDistance / rd.z;
+        vec3 pFocus = ro + rd * ft;
+        ro = vec3(lx, ly, 0);
+        rd = normalize(pFocus - ro);
+    }
+    vec3 oErr;
+    vec3 o = xf_point_err(cam.cameraToWorld, ro, &oErr);
+    vec3 d = xf_vector(cam.cameraToWorld, rd);
+    float len2 = length2(d), tMax = HPRT_INF;
+    if (len2 > 0) { float dt = dot(vabs(d), oErr) / len2; o = o + d * dt; tMax -= dt; }
+    out->o = o; out->d = d; out->tMax = tMax;
+}
+
+// ---------------------------------------------------------------------------
+// Surface interaction
+// ---------------------------------------------------------------------------
+struct DevSI { vec3 p, pErr, wo, n, ns, sdpdu; int32_t shape; };   // ns = shading.n, sdpdu = shading.dpdu
+
+// SurfaceInteraction::SetShadingGeometry with orientationIsAuthoritative (core/interaction.cpp:72-91)
+__device__ __forceinline__ void set_shading(DevSI *si, vec3 dpdus, vec3 dpdvs, bool flip) {
+    si->ns = normalize(cross(dpdus, dpdvs));
+    if (flip) si->ns = -si->ns;
+    si->n = face_forward(si->n, si->ns);
+    si->sdpdu = dpdus;
+}
+// Triangle::Intersect fill part, shapes/triangle.cpp:294-425.  The degenerate
+// (bogus) case was rejected during traversal via TAG_BOGUS.
+__device__ __forceinline__ void fill_triangle(const DevScene &sc, uint32_t prim, float b0, float b1, float b2, vec3 rayD, DevSI *si) {
+    const float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
+    const vec3 p0(v0.x, v0.y, v0.z), p1(v1.x, v1.y, v1.z), p2(v2.x, v2.y, v2.z);
+    const int shapeId = (int)__float_as_uint(v1.w);
+    const DevShape sh = sc.shapes[shapeId];
+    const bool flip = (sh.flags & SHAPE_FLIP) != 0;
+    const uint32_t i0 = sc.primVtx[3 * prim], i1 = sc.primVtx[3 * prim + 1], i2 = sc.primVtx[3 * prim + 2];
+    float uv0x = 0, uv0y = 0, uv1x = 1, uv1y = 0, uv2x = 1, uv2y = 1;   // triangle.h:114-118
+    if (sh.flags & SHAPE_HAS_UV) {
+        uv0x = sc.vUV[2 * i0]; uv0y = sc.vUV[2 * i0 + 1]; uv1x = sc.vUV[2 * i1]; uv1y = sc.vUV[2 * i1 + 1];
+        uv2x = sc.vUV[2 * i2]; uv2y = sc.vUV[2 * i2 + 1];
+    }
+    float duv02x = uv0x - uv2x, duv02y = uv0y - uv2y, duv12x = uv1x - uv2x, duv12y = uv1y - uv2y;
+    vec3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float determinant = duv02x * duv12y - duv02y * duv12x;
+    bool degenerateUV = fabsf(determinant) < 1e-8;     // float |det| compared against the double literal
+    vec3 dpdu, dpdv;
+    if (!degenerateUV) {
+        float invdet = 1 / determinant;
+        dpdu = (duv12y * dp02 - duv02y * dp12) * invdet;
+        dpdv = (-duv12x * dp02 + duv02x * dp12) * invdet;
+    }
+    if (degenerateUV || length2(cross(dpdu, dpdv)) == 0) {
+        vec3 ng = cross(p2 - p0, p1 - p0);
+        coordinate_system(normalize(ng), &dpdu, &dpdv);
+    }
+    float xAbs = (fabsf(b0 * p0.x) + fabsf(b1 * p1.x) + fabsf(b2 * p2.x));
+    float yAbs = (fabsf(b0 * p0.y) + fabsf(b1 * p1.y) + fabsf(b2 * p2.y));
+    float zAbs = (fabsf(b0 * p0.z) + fabsf(b1 * p1.z) + fabsf(b2 * p2.z));
+    si->pErr = gamma_n(7) * vec3(xAbs, yAbs, zAbs);
+    si->p = b0 * p0 + b1 * p1 + b2 * p2;
+    si->wo = normalize(-rayD);
+    si->shape = shapeId;
+    si->n = normalize(cross(dp02, dp12));
+    si->ns = si->n;
+    si->sdpdu = dpdu;
+    if (sh.flags & (SHAPE_HAS_N | SHAPE_HAS_S)) {
+        vec3 ns;
+        if (sh.flags & SHAPE_HAS_N) {
+            vec3 n0(sc.vN[3 * i0], sc.vN[3 * i0 + 1], sc.vN[3 * i0 + 2]), n1(sc.vN[3 * i1], sc.vN[3 * i1 + 1], sc.vN[3 * i1 + 2]),
+                n2(sc.vN[3 * i2], sc.vN[3 * i2 + 1], sc.vN[3 * i2 + 2]);
+            ns = (b0 * n0 + b1 * n1 + b2 * n2);
+            if (length2(ns) > 0) ns = normalize(ns); else ns = si->n;
+        } else ns = si->n;
+        vec3 ss;
+        if (sh.flags & SHAPE_HAS_S) {
+            vec3 s0(sc.vS[3 * i0], sc.vS[3 * i0 + 1], sc.vS[3 * i0 + 2]), s1(sc.vS[3 * i1], sc.vS[3 * i1 + 1], sc.vS[3 * i1 + 2]),
+                s2(sc.vS[3 * i2], sc.vS[3 * i2 + 1], sc.vS[3 * i2 + 2]);
+            ss = (b0 * s0 + b1 * s1 + b2 * s2);
+            if (length2(ss) > 0) ss = normalize(ss); else ss = normalize(dpdu);
+        } else ss = normalize(dpdu);
+        vec3 ts = cross(ss, ns);
+        if (length2(ts) > 0.f) { ts = normalize(ts); ss = cross(ts, ns); }
+        else coordinate_system(ns, &ss, &ts);
+        set_shading(si, ss, ts, flip);
+    }
+    if (sh.flags & SHAPE_HAS_N) si->n = face_forward(si->n, si->ns);
+    else if (flip) { si->n = -si->n; si->ns = si->n; }
+}
+// Sphere::Intersect fill part + (*ObjectToWorld)(SurfaceInteraction)
+// (shapes/sphere.cpp:106-157, core/transform.cpp:262-297).  Returns false if the
+// quadric test fails (cannot happen for a primitive the traversal reported).
+__device__ __noinline__ bool fill_sphere(const DevScene &sc, int shapeId, const DRay &r, DevSI *si, float *tOut) {
+    const DevShape sh = sc.shapes[shapeId];
+    const DevSphere &s = sc.spheres[sh.sphere];
+    DRay ray; vec3 pHit; float phi, t;
+    if (!sphere_test(s, r, &ray, &pHit, &phi, &t)) return false;
+    float theta = det_acosf(clampf(pHit.z / s.radius, -1, 1));
+    float zRadius = sqrtf(pHit.x * pHit.x + pHit.y * pHit.y);
+    float invZRadius = 1 / zRadius;
+    float cosPhi = pHit.x * invZRadius, sinPhi = pHit.y * invZRadius;
+    vec3 dpdu(-s.phiMax * pHit.y, s.phiMax * pHit.x, 0);
+    vec3 dpdv = (s.thetaMax - s.thetaMin) * vec3(pHit.z * cosPhi, pHit.z * sinPhi, -s.radius * det_sinf(theta));
+    vec3 pErrObj = gamma_n(5) * vabs(pHit);
+    // SurfaceInteraction ctor (core/interaction.cpp:43-70)
+    const bool flip = (sh.flags & SHAPE_FLIP) != 0;
+    vec3 nObj = normalize(cross(dpdu, dpdv));
+    vec3 nsObj = nObj;
+    if (flip) { nObj = -nObj; nsObj = -nsObj; }
+    vec3 woObj = normalize(-ray.d);
+    si->p = xf_point_err_in(s.o2w, pHit, pErrObj, &si->pErr);
+    si->n = normalize(xf_normal(s.w2o, nObj));
+    si->wo = normalize(xf_vector(s.o2w, woObj));
+    si->ns = normalize(xf_normal(s.w2o, nsObj));
+    si->sdpdu = xf_vector(s.o2w, dpdu);
+    si->ns = face_forward(si->ns, si->n);
+    si->shape = shapeId;
+    *tOut = t;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// BSDF: up to two lobes (Lambertian, Trowbridge-Reitz microfacet with
+// FresnelDielectric(1.5, 1)), as MatteMaterial / PlasticMaterial build them
+// (materials/matte.cpp:45-62, materials/plastic.cpp:45-70).
+// ---------------------------------------------------------------------------
+enum : int { BX_REFLECTION = 1, BX_TRANSMISSION = 2, BX_DIFFUSE = 4, BX_GLOSSY = 8, BX_SPECULAR = 16, BX_ALL = 31 };
+
+struct DevBsdf {
+    vec3 ns, ng, ss, ts;
+    int nLobes;            // 0..2
+    int kind[2];           // 0 lambert, 1 microfacet
+    rgb R[2];
+    float alpha;           // microfacet lobe
+};
+__device__ __forceinline__ float cos_theta(vec3 w) { return w.z; }
+__device__ __forceinline__ float cos2_theta(vec3 w) { return w.z * w.z; }
+__device__ __forceinline__ float abs_cos_theta(vec3 w) { return fabsf(w.z); }
+__device__ __forceinline__ float sin2_theta(vec3 w) { return sel_max(0.f, 1.0f - cos2_theta(w)); }
+__device__ __forceinline__ float sin_theta(vec3 w) { return sqrtf(sin2_theta(w)); }
+__device__ __forceinline__ float tan_theta(vec3 w) { return sin_theta(w) / cos_theta(w); }
+__device__ __forceinline__ float tan2_theta(vec3 w) { return sin2_theta(w) / cos2_theta(w); }
+__device__ __forceinline__ float cos_phi(vec3 w) { float s = sin_theta(w); return (s == 0) ? 1 : clampf(w.x / s, -1, 1); }
+__device__ __forceinline__ float sin_phi(vec3 w) { float s = sin_theta(w); return (s == 0) ? 0 : clampf(w.y / s, -1, 1); }
+__device__ __forceinline__ float cos2_phi(vec3 w) { return cos_phi(w) * cos_phi(w); }
+__device__ __forceinline__ float sin2_phi(vec3 w) { return sin_phi(w) * sin_phi(w); }
+__device__ __forceinline__ bool same_hemisphere(vec3 w, vec3 wp) { return w.z * wp.z > 0; }
+
+// core/reflection.cpp:47-68
+__device__ __forceinline__ float fr_dielectric(float cosThetaI, float etaI, float etaT) {
+    cosThetaI = clampf(cosThetaI, -1, 1);
+    bool entering = cosThetaI > 0.f;
+    if (!entering) { float tmp = etaI; etaI = etaT; etaT = tmp; cosThetaI = fabsf(cosThetaI); }
+    float sinThetaI = sqrtf(sel_max(0.f, 1 - cosThetaI * cosThetaI));
+    float sinThetaT = etaI / etaT * sinThetaI;
+    if (sinThetaT >= 1) return 1;
+    float cosThetaT = sqrtf(sel_max(0.f, 1 - sinThetaT * sinThetaT));
+    float Rparl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
+    float Rperp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+    return (Rparl * Rparl + Rperp * Rperp) / 2;
+}
+// TrowbridgeReitzDistribution (core/microfacet.cpp:163-193, 238-344), alphax == alphay == a
+__device__ __forceinline__ float tr_D(float a, vec3 wh) {
+    float tan2Theta = tan2_theta(wh);
+    if (is_inf(tan2Theta)) return 0.;
+    const float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
+    float e = (cos2_phi(wh) / (a * a) + sin2_phi(wh) / (a * a)) * tan2Theta;
+    return 1 / (HPRT_PI * a * a * cos4Theta * (1 + e) * (1 + e));
+}
+__device__ __forceinline__ float tr_lambda(float a, vec3 w) {
+    float absTanTheta = fabsf(tan_theta(w));
+    if (is_inf(absTanTheta)) return 0.;
+    float alpha = sqrtf(cos2_phi(w) * a * a + sin2_phi(w) * a * a);
+    float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
+    return (-1 + sqrtf(1.f + alpha2Tan2Theta)) / 2;
+}
+__device__ __forceinline__ float tr_G1(float a, vec3 w) { return 1 / (1 + tr_lambda(a, w)); }
+__device__ __forceinline__ float tr_G(float a, vec3 wo, vec3 wi) { return 1 / (1 + tr_lambda(a, wo) + tr_lambda(a, wi)); }
+__device__ __forceinline__ float tr_pdf(float a, vec3 wo, vec3 wh) { return tr_D(a, wh) * tr_G1(a, wo) * absdot(wo, wh) / abs_cos_theta(wo); }
+__device__ __forceinline__ void tr_sample11(float cosTheta, float U1, float U2, float *slope_x, float *slope_y) {
+    if ((double)cosTheta > .9999) {
+        float r = sqrtf(U1 / (1 - U1));
+        float phi = (float)(6.28318530718 * (double)U2);
+        *slope_x = (float)((double)r * det_cos((double)phi));   // float * ::cos(double) -> double -> float
+        *slope_y = (float)((double)r * det_sin((double)phi));
+        return;
+    }
+    float sinTheta = sqrtf(sel_max(0.f, 1.0f - cosTheta * cosTheta));
+    float tanTheta = sinTheta / cosTheta;
+    float a = 1 / tanTheta;
+    float G1 = 2 / (1 + sqrtf(1.f + 1.f / (a * a)));
+    float A = 2 * U1 / G1 - 1;
+    float tmp = 1.f / (A * A - 1.f);
+    if ((double)tmp > 1e10) tmp = (float)1e10;
+    float B = tanTheta;
+    float D = sqrtf(sel_max(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.f));
+    float slope_x_1 = B * tmp - D;
+    float slope_x_2 = B * tmp + D;
+    *slope_x = (A < 0 || slope_x_2 > 1.f / tanTheta) ? slope_x_1 : slope_x_2;
+    float S;
+    if (U2 > 0.5f) { S = 1.f; U2 = 2.f * (U2 - .5f); }
+    else { S = -1.f; U2 = 2.f * (.5f - U2); }
+    float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) /
+              (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+    *slope_y = S * z * sqrtf(1.f + *slope_x * *slope_x);
+}
+__device__ __forceinline__ vec3 tr_sample_wh(float a, vec3 wo, float u0, float u1) {
+    bool flip = wo.z < 0;
+    vec3 wi = flip ? -wo : wo;
+    vec3 wiS = normalize(vec3(a * wi.x, a * wi.y, wi.z));
+    float sx, sy;
+    tr_sample11(cos_theta(wiS), u0, u1, &sx, &sy);
+    float tmp = cos_phi(wiS) * sx - sin_phi(wiS) * sy;
+    sy = sin_phi(wiS) * sx + cos_phi(wiS) * sy;
+    sx = tmp;
+    sx = a * sx; sy = a * sy;
+    vec3 wh = normalize(vec3(-sx, -sy, 1.f));
+    if (flip) wh = -wh;
+    return wh;
+}
+
+__device__ __forceinline__ int lobe_type(int kind) { return kind == 0 ? (BX_REFLECTION | BX_DIFFUSE) : (BX_REFLECTION | BX_GLOSSY); }
+__device__ __forceinline__ bool lobe_matches(int kind, int flags) { int t = lobe_type(kind); return (t & flags) == t; }
+
+__device__ __forceinline__ rgb lobe_f(const DevBsdf &b, int i, vec3 wo, vec3 wi) {
+    if (b.kind[i] == 0) return b.R[i] * HPRT_INV_PI;
+    float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
+    vec3 wh = wi + wo;
+    if (cosThetaI == 0 || cosThetaO == 0) return rgb(0.f);
+    if (wh.x == 0 && wh.y == 0 && wh.z == 0) return rgb(0.f);
+    wh = normalize(wh);
+    rgb F(fr_dielectric(dot(wi, wh), 1.5f, 1.f));
+    return b.R[i] * tr_D(b.alpha, wh) * tr_G(b.alpha, wo, wi) * F / (4 * cosThetaI * cosThetaO);
+}
+__device__ __forceinline__ float lobe_pdf(const DevBsdf &b, int i, vec3 wo, vec3 wi) {
+    if (b.kind[i] == 0) return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * HPRT_INV_PI : 0;
+    if (!same_hemisphere(wo, wi)) return 0;
+    vec3 wh = normalize(wo + wi);
+    return tr_pdf(b.alpha, wo, wh) / (4 * dot(wo, wh));
+}
+// BxDF::Sample_f (cosine) / MicrofacetReflection::Sample_f.  *pdf untouched when 0 is
+// returned early, like the reference.
+__device__ __forceinline__ rgb lobe_sample(const DevBsdf &b, int i, vec3 wo, vec3 *wi, float u0, float u1, float *pdf) {
+    if (b.kind[i] == 0) {
+        float dx, dy; concentric_disk(u0, u1, &dx, &dy);
+        float z = sqrtf(sel_max(0.f, 1 - dx * dx - dy * dy));
+        *wi = vec3(dx, dy, z);
+        if (wo.z < 0) wi->z *= -1;
+        *pdf = lobe_pdf(b, i, wo, *wi);
+        return lobe_f(b, i, wo, *wi);
+    }
+    if (wo.z == 0) return rgb(0.f);
+    vec3 wh = tr_sample_wh(b.alpha, wo, u0, u1);
+    *wi = -wo + 2 * dot(wo, wh) * wh;
+    if (!same_hemisphere(wo, *wi)) return rgb(0.f);
+    *pdf = tr_pdf(b.alpha, wo, wh) / (4 * dot(wo, wh));
+    return lobe_f(b, i, wo, *wi);
+}
+
+__device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, DevBsdf *b) {
+    b->ns = si.ns; b->ng = si.n;
+    b->ss = normalize(si.sdpdu);
+    b->ts = cross(b->ns, b->ss);
+    b->nLobes = 0; b->alpha = 0;
+    const DevMaterial m = sc.materials[sc.shapes[si.shape].material];
+    rgb kd = clamp0(rgb(m.Kd[0], m.Kd[1], m.Kd[2]));
+    if (!is_black(kd)) { b->kind[b->nLobes] = 0; b->R[b->nLobes] = kd; ++b->nLobes; }
+    if (m.type == 1) {
+        rgb ks = clamp0(rgb(m.Ks[0], m.Ks[1], m.Ks[2]));
+        if (!is_black(ks)) { b->kind[b->nLobes] = 1; b->R[b->nLobes] = ks; b->alpha = m.alpha; ++b->nLobes; }
+    }
+}
+__device__ __forceinline__ vec3 to_local(const DevBsdf &b, vec3 v) { return vec3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
+__device__ __forceinline__ vec3 to_world(const DevBsdf &b, vec3 v) {
+    return vec3(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
+                b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
+}
+__device__ __forceinline__ int bsdf_num(const DevBsdf &b, int flags) {
+    int n = 0;
+    for (int i = 0; i < 2; ++i) if (i < b.nLobes && lobe_matches(b.kind[i], flags)) ++n;
+    return n;
+}
+// BSDF::f, core/reflection.cpp:670-684 (all lobes here are reflective)
+__device__ __forceinline__ rgb bsdf_f(const DevBsdf &b, vec3 woW, vec3 wiW, int flags) {
+    vec3 wi = to_local(b, wiW), wo = to_local(b, woW);
+    if (wo.z == 0) return rgb(0.f);
+    bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
+    rgb f(0.f);
+    for (int i = 0; i < 2; ++i)
+        if (i < b.nLobes && lobe_matches(b.kind[i], flags) && reflect) f = f + lobe_f(b, i, wo, wi);
+    return f;
+}
+// BSDF::Pdf, core/reflection.cpp:764-778
+__device__ __forceinline__ float bsdf_pdf(const DevBsdf &b, vec3 woW, vec3 wiW, int flags) {
+    if (b.nLobes == 0) return 0.f;
+    vec3 wo = to_local(b, woW), wi = to_local(b, wiW);
+    if (wo.z == 0) return 0.f;
+    float pdf = 0.f; int matching = 0;
+    for (int i = 0; i < 2; ++i)
+        if (i < b.nLobes && lobe_matches(b.kind[i], flags)) { ++matching; pdf += lobe_pdf(b, i, wo, wi); }
+    return matching > 0 ? pdf / matching : 0.f;
+}
+// BSDF::Sample_f, core/reflection.cpp:703-762.  *pdf keeps its incoming value on the
+// "wo.z == 0" early return, as in the reference.
+__device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW, float u0, float u1, float *pdf, int flags, int *sampledType) {
+    int matching = bsdf_num(b, flags);
+    if (matching == 0) { *pdf = 0; *sampledType = 0; return rgb(0.f); }
+    int comp = sel_min((int)floorf(u0 * matching), matching - 1);
+    int chosen = -1, count = comp;
+    for (int i = 0; i < 2; ++i)
+        if (chosen < 0 && i < b.nLobes && lobe_matches(b.kind[i], flags) && count-- == 0) chosen = i;
+    float ur0 = sel_min(u0 * matching - comp, HPRT_ONE_MINUS_EPS);
+    vec3 wi, wo = to_local(b, woW);
+    if (wo.z == 0) return rgb(0.f);
+    *pdf = 0;
+    *sampledType = lobe_type(b.kind[chosen]);
+    rgb f = lobe_sample(b, chosen, wo, &wi, ur0, u1, pdf);
+    if (*pdf == 0) { *sampledType = 0; return rgb(0.f); }
+    *wiW = to_world(b, wi);
+    if (matching > 1)
+        for (int i = 0; i < 2; ++i)
+            if (i != chosen && i < b.nLobes && lobe_matches(b.kind[i], flags)) *pdf += lobe_pdf(b, i, wo, wi);
+    if (matching > 1) *pdf /= matching;
+    bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
+    f = rgb(0.f);
+    for (int i = 0; i < 2; ++i)
+        if (i < b.nLobes && lobe_matches(b.kind[i], flags) && reflect) f = f + lobe_f(b, i, wo, wi);
+    return f;
+}
+
+// ---------------------------------------------------------------------------
+// Lights
+// ---------------------------------------------------------------------------
+struct DevIt { vec3 p, pErr, n; };   // Interaction subset
+
+__device__ __forceinline__ vec3 spherical_dir(float sinTheta, float cosTheta, float phi, vec3 x, vec3 y, vec3 z) {
+    return sinTheta * det_cosf(phi) * x + sinTheta * det_sinf(phi) * y + cosTheta * z;
+}
+// Sphere::Sample(u) (shapes/sphere.cpp:217-230)
+__device__ __forceinline__ DevIt sphere_sample_area(const DevSphere &s, bool reverse, float u0, float u1, float *pdf) {
+    float z = 1 - 2 * u0;
+    float r = sqrtf(sel_max(0.f, 1.0f - z * z));
+    float phi = 2 * HPRT_PI * u1;
+    vec3 pObj = vec3(0, 0, 0) + s.radius * vec3(r * det_cosf(phi), r * det_sinf(phi), z);
+    DevIt it;
+    it.n = normalize(xf_normal(s.w2o, pObj));
+    if (reverse) it.n = it.n * -1.f;
+    pObj = pObj * (s.radius / dist(pObj, vec3(0, 0, 0)));
+    vec3 pObjErr = gamma_n(5) * vabs(pObj);
+    it.p = xf_point_err_in(s.o2w, pObj, pObjErr, &it.pErr);
+    *pdf = 1 / (s.phiMax * s.radius * (s.zMax - s.zMin));
+    return it;
+}
+// Sphere::Sample(ref, u) (shapes/sphere.cpp:232-292)
+__device__ __noinline__ DevIt sphere_sample(const DevSphere &s, bool reverse, const DevIt &ref, float u0, float u1, float *pdf) {
+    vec3 pCenter = xf_point(s.o2w, vec3(0, 0, 0));
+    vec3 pOrigin = offset_ray_origin(ref.p, ref.pErr, ref.n, pCenter - ref.p);
+    if (dist2(pOrigin, pCenter) <= s.radius * s.radius) {
+        DevIt intr = sphere_sample_area(s, reverse, u0, u1, pdf);
+        vec3 wi = intr.p - ref.p;
+        if (length2(wi) == 0) *pdf = 0;
+        else { wi = normalize(wi); *pdf *= dist2(ref.p, intr.p) / absdot(intr.n, -wi); }
+        if (is_inf(*pdf)) *pdf = 0.f;
+        return intr;
+    }
+    vec3 wc = normalize(pCenter - ref.p), wcX, wcY;
+    coordinate_system(wc, &wcX, &wcY);
+    float sinThetaMax2 = s.radius * s.radius / dist2(ref.p, pCenter);
+    float cosThetaMax = sqrtf(sel_max(0.f, 1 - sinThetaMax2));
+    float cosTheta = (1 - u0) + u0 * cosThetaMax;
+    float sinTheta = sqrtf(sel_max(0.f, 1 - cosTheta * cosTheta));
+    float phi = u1 * 2 * HPRT_PI;
+    float dc = dist(ref.p, pCenter);
+    float ds = dc * cosTheta - sqrtf(sel_max(0.f, s.radius * s.radius - dc * dc * sinTheta * sinTheta));
+    float cosAlpha = (dc * dc + s.radius * s.radius - ds * ds) / (2 * dc * s.radius);
+    float sinAlpha = sqrtf(sel_max(0.f, 1 - cosAlpha * cosAlpha));
+    vec3 nWorld = spherical_dir(sinAlpha, cosAlpha, phi, -wcX, -wcY, -wc);
+    vec3 pWorld = pCenter + s.radius * vec3(nWorld.x, nWorld.y, nWorld.z);
+    DevIt it;
+    it.p = pWorld;
+    it.pErr = gamma_n(5) * vabs(pWorld);
+    it.n = nWorld;
+    if (reverse) it.n = it.n * -1.f;
+    *pdf = 1 / (2 * HPRT_PI * (1 - cosThetaMax));
+    return it;
+}
+__device__ __forceinline__ rgb area_L(const DevLight &l, vec3 n, vec3 w) {   // lights/diffuse.h:56-58
+    return (l.twoSided || dot(n, w) > 0) ? rgb(l.I[0], l.I[1], l.I[2]) : rgb(0.f);
+}
+// Light::Sample_Li (lights/point.cpp:44-53, distant.cpp:49-59, diffuse.cpp:68-81)
+__device__ __forceinline__ rgb light_sample(const DevScene &sc, const DevLight &l, const DevIt &ref, float u0, float u1, vec3 *wi,
+                                            float *pdf, DevIt *pLight) {
+    vec3 lp(l.pos[0], l.pos[1], l.pos[2]);
+    if (l.type == 0) {
+        *wi = normalize(lp - ref.p);
+        *pdf = 1.f;
+        pLight->p = lp; pLight->pErr = vec3(); pLight->n = vec3();
+        return rgb(l.I[0], l.I[1], l.I[2]) / dist2(lp, ref.p);
+    } else if (l.type == 1) {
+        *wi = lp;
+        *pdf = 1;
+        pLight->p = ref.p + lp * (2 * sc.worldRadius); pLight->pErr = vec3(); pLight->n = vec3();
+        return rgb(l.I[0], l.I[1], l.I[2]);
+    }
+    DevIt ps = sphere_sample(sc.spheres[l.sphere], (l.shapeFlags & SHAPE_REVERSE) != 0, ref, u0, u1, pdf);
+    if (*pdf == 0 || length2(ps.p - ref.p) == 0) { *pdf = 0; return rgb(0.f); }
+    *wi = normalize(ps.p - ref.p);
+    *pLight = ps;
+    return area_L(l, ps.n, -*wi);
+}
+// Light::Pdf_Li for area lights = Sphere::Pdf (shapes/sphere.cpp:294-306; inside case
+// Shape::Pdf, core/shape.cpp:72-88)
+__device__ __noinline__ float light_pdf(const DevScene &sc, const DevLight &l, const DevIt &ref, vec3 wi) {
+    if (l.type != 2) return 0;
+    const DevSphere &s = sc.spheres[l.sphere];
+    vec3 pCenter = xf_point(s.o2w, vec3(0, 0, 0));
+    vec3 pOrigin = offset_ray_origin(ref.p, ref.pErr, ref.n, pCenter - ref.p);
+    if (dist2(pOrigin, pCenter) <= s.radius * s.radius) {
+        DRay ray; ray.o = offset_ray_origin(ref.p, ref.pErr, ref.n, wi); ray.d = wi; ray.tMax = HPRT_INF;
+        DevSI isl; float tHit;
+        if (!fill_sphere(sc, l.shape, ray, &isl, &tHit)) return 0;
+        float area = s.phiMax * s.radius * (s.zMax - s.zMin);
+        float pdf = dist2(ref.p, isl.p) / (absdot(isl.n, -wi) * area);
+        if (is_inf(pdf)) pdf = 0.f;
+        return pdf;
+    }
+    float sinThetaMax2 = s.radius * s.radius / dist2(ref.p, pCenter);
+    float cosThetaMax = sqrtf(sel_max(0.f, 1 - sinThetaMax2));
+    return 1 / (2 * HPRT_PI * (1 - cosThetaMax));
+}
+// Distribution1D::SampleDiscrete (core/sampling.h:86-96) with FindInterval (core/pbrt.h:403-415)
+__device__ __forceinline__ int light_pick(const DevScene &sc, float u, float *pdf) {
+    int size = (int)sc.nLights + 1;
+    int first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (sc.lightCdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    int offset = first - 1;
+    if (offset < 0) offset = 0; else if (offset > size - 2) offset = size - 2;
+    *pdf = (sc.lightFuncInt > 0) ? sc.lightFunc[offset] / (sc.lightFuncInt * (int)sc.nLights) : 0;
+    return offset;
+}
+__device__ __forceinline__ float power_heuristic(float fPdf, float gPdf) {   // core/sampling.h:171-174, nf = ng = 1
+    float f = 1 * fPdf, g = 1 * gPdf;
+    return (f * f) / (f * f + g * g);
+}
+
+}  // namespace hprt

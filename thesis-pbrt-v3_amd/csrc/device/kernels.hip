@@ -1,0 +1,458 @@
+// hprt device side — the wavefront path-tracing kernels (gfx950, wave64).
+//
+// One camera sample ("path") owns one SLOT in a set of SoA planes in HBM; kernels
+// communicate through queues of slot numbers built with wave-level ballot/prefix
+// compaction (one atomic per wave).  Per bounce:
+//     k_trace<closest>  path rays            BVHAccel::Intersect + Triangle::Intersect
+//     k_shade           Li loop body         PathIntegrator::Li (integrators/path.cpp:64-204),
+//                                            UniformSampleOneLight/EstimateDirect set-up
+//                                            (core/integrator.cpp:86-217)
+//     k_trace<any>      shadow rays          BVHAccel::IntersectP (VisibilityTester::Unoccluded)
+//     k_trace<closest>  MIS rays             scene.Intersect at core/integrator.cpp:195
+//     k_resolve         L += beta * Ld / lightPdf, in bounce order
+// and once per batch k_generate (Render loop head, core/integrator.cpp:281-293) and
+// k_store_radiance (radiance guards, :300-321).  The film (FilmTile::AddSample /
+// MergeFilmTile, core/film.h:130-170, core/film.cpp:118-132) is folded per pixel in
+// exact sample order by k_film_*.
+//
+// Built with -ffp-contract=off: every float operation below is a single IEEE
+// rounding in the order the reference's scalar code performs it.
+#include <hip/hip_runtime.h>
+#include "dev_shading.h"
+#include "kernels.h"
+
+namespace hprt {
+
+// ---------------------------------------------------------------------------
+// wave-level queue append: returns the position for lanes with pred, one atomic per wave
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool pred) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    const uint32_t lane = __lane_id();
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0u;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + prefix;
+}
+
+__device__ __forceinline__ void wave_count_add(DevCounters *c, bool anyHit, const TraceCount &t) {
+    // per-wave reduction, then one atomic per counter per wave
+    unsigned int f = t.fetched, e = t.entered, tr = t.tri, sp = t.sphere;
+    for (int off = 32; off > 0; off >>= 1) {
+        f += __shfl_down(f, off); e += __shfl_down(e, off); tr += __shfl_down(tr, off); sp += __shfl_down(sp, off);
+    }
+    if (__lane_id() == 0) {
+        if (!anyHit) { atomicAdd(&c->nodesFetched, (unsigned long long)f); atomicAdd(&c->nodesEntered, (unsigned long long)e);
+                       atomicAdd(&c->triTests, (unsigned long long)tr); atomicAdd(&c->sphereTests, (unsigned long long)sp); }
+        else { atomicAdd(&c->nodesFetchedP, (unsigned long long)f); atomicAdd(&c->nodesEnteredP, (unsigned long long)e);
+               atomicAdd(&c->triTestsP, (unsigned long long)tr); atomicAdd(&c->sphereTestsP, (unsigned long long)sp); }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_trace: one lane per ray.  queue == nullptr means "slot = thread index".
+// Rays are read from SoA planes indexed by slot; tmax == nullptr means Infinity.
+// Closest hit writes t, prim (ordered index or -1) and b0,b1,b2; any hit writes a byte.
+// ---------------------------------------------------------------------------
+template <bool ANY_HIT, bool COUNT>
+__global__ __launch_bounds__(HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
+                                                            uint32_t countImm, RayPlanes rays, HitPlanes hits, uint8_t *occ,
+                                                            DevCounters *counters) {
+    __shared__ int stackMem[HPRT_LDS_STACK * HPRT_TRACE_BLOCK];
+    const uint32_t n = countPtr ? *countPtr : countImm;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    TraceCount cnt = {0u, 0u, 0u, 0u};
+    if (i < n) {
+        const uint32_t slot = queue ? queue[i] : i;
+        DRay ray;
+        ray.o = vec3(rays.ox[slot], rays.oy[slot], rays.oz[slot]);
+        ray.d = vec3(rays.dx[slot], rays.dy[slot], rays.dz[slot]);
+        ray.tMax = rays.tmax ? rays.tmax[slot] : HPRT_INF;
+        int32_t prim = -1; float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        const bool hit = bvh_walk<ANY_HIT, COUNT>(sc, ray, &stackMem[threadIdx.x], &prim, &b0, &b1, &b2, cnt);
+        if (ANY_HIT) occ[slot] = hit ? 1 : 0;
+        else {
+            hits.t[slot] = ray.tMax; hits.prim[slot] = hit ? prim : -1;
+            if (hits.b0) { hits.b0[slot] = b0; hits.b1[slot] = b1; hits.b2[slot] = b2; }
+        }
+    }
+    if (COUNT) wave_count_add(counters, ANY_HIT, cnt);
+}
+
+// ---------------------------------------------------------------------------
+// k_generate: Sampler::GetCameraSample (core/sampler.cpp:46-52) + GenerateRayDifferential.
+// slot = sampleInChunk * nPix + pixelIndex, so consecutive lanes are consecutive pixels
+// of a 16x16 tile (coherent primary rays).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, PathPlanes ps, uint32_t s0, uint32_t nSlots) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nSlots) return;
+    const uint32_t pix = slot % rp.nPix, sIdx = slot / rp.nPix;
+    const uint32_t pxy = rp.pixelXY[pix];
+    const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
+    const uint64_t index = (uint64_t)rp.pixelOffset[pix] + (uint64_t)(s0 + sIdx) * (uint64_t)rp.hal.sampleStride;
+    const float u0 = halton_dim(sc, rp.hal, index, 0), u1 = halton_dim(sc, rp.hal, index, 1);
+    const float fx = (float)px + u0, fy = (float)py + u1;
+    float lu = 0.f, lv = 0.f;
+    if (rp.cam.lensRadius > 0) { lu = halton_dim(sc, rp.hal, index, 3); lv = halton_dim(sc, rp.hal, index, 4); }
+    DRay ray;
+    camera_ray(rp.cam, fx, fy, lu, lv, &ray);
+    ps.ray.ox[slot] = ray.o.x; ps.ray.oy[slot] = ray.o.y; ps.ray.oz[slot] = ray.o.z;
+    ps.ray.dx[slot] = ray.d.x; ps.ray.dy[slot] = ray.d.y; ps.ray.dz[slot] = ray.d.z;
+    ps.ray.tmax[slot] = ray.tMax;
+    ps.betaR[slot] = 1.f; ps.betaG[slot] = 1.f; ps.betaB[slot] = 1.f;
+    ps.LR[slot] = 0.f; ps.LG[slot] = 0.f; ps.LB[slot] = 0.f;
+    ps.state[slot] = 5u;          // sampler dimension 5 (after pFilm, time, pLens), bounce 0
+}
+
+// ---------------------------------------------------------------------------
+// k_shade: one lane per active path.  Consumes the closest hit of the path ray.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, RenderParams rp, PathPlanes ps, const uint32_t *queue,
+                                               const uint32_t *countPtr, uint32_t countImm, uint32_t s0, QueueSet q) {
+    const uint32_t n = countPtr ? *countPtr : countImm;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool wantNext = false, wantShadow = false, wantMis = false, wantResolve = false;
+    uint32_t slot = 0;
+    if (i < n) {
+        slot = queue ? queue[i] : i;
+        const uint32_t st = ps.state[slot];
+        int dim = (int)(st & 0xffu);
+        const int bounces = (int)((st >> 8) & 0xffu);
+        const uint32_t pix = slot % rp.nPix, sIdx = slot / rp.nPix;
+        const uint64_t index = (uint64_t)rp.pixelOffset[pix] + (uint64_t)(s0 + sIdx) * (uint64_t)rp.hal.sampleStride;
+        const int32_t prim = ps.hit.prim[slot];
+        const vec3 rayO(ps.ray.ox[slot], ps.ray.oy[slot], ps.ray.oz[slot]);
+        const vec3 rayD(ps.ray.dx[slot], ps.ray.dy[slot], ps.ray.dz[slot]);
+        rgb beta(ps.betaR[slot], ps.betaG[slot], ps.betaB[slot]);
+        const bool found = prim >= 0;
+        DevSI si;
+        if (found) {
+            const float4 v0 = sc.tris[3 * prim];
+            if ((__float_as_uint(v0.w) & TAG_KIND_MASK) == 0u)
+                fill_triangle(sc, (uint32_t)prim, ps.hit.b0[slot], ps.hit.b1[slot], ps.hit.b2[slot], rayD, &si);
+            else {
+                DRay r0; r0.o = rayO; r0.d = rayD; r0.tMax = ps.ray.tmax[slot];
+                float tt;
+                fill_sphere(sc, (int)__float_as_uint(sc.tris[3 * prim + 1].w), r0, &si, &tt);
+            }
+            // emitted radiance at the first vertex (path.cpp:97-107; no specular lobes exist here)
+            if (bounces == 0) {
+                const int al = sc.shapes[si.shape].areaLight;
+                if (al >= 0) {
+                    rgb Le = area_L(sc.lights[al], si.n, -rayD);
+                    rgb add = beta * Le;
+                    ps.LR[slot] = ps.LR[slot] + add.r; ps.LG[slot] = ps.LG[slot] + add.g; ps.LB[slot] = ps.LB[slot] + add.b;
+                } else {
+                    // L += beta * Spectrum(0): adds +0 (or -0) and leaves L's value unchanged
+                }
+            }
+        }
+        if (found && bounces < rp.maxDepth) {
+            DevBsdf bsdf;
+            bsdf_init(sc, si, &bsdf);
+            // ---- direct lighting (UniformSampleOneLight + EstimateDirect) ----
+            if (bsdf_num(bsdf, BX_ALL & ~BX_SPECULAR) > 0 && sc.nLights > 0) {
+                float pickPdf;
+                const int lightNum = light_pick(sc, halton_dim(sc, rp.hal, index, dim), &pickPdf);
+                dim += 1;
+                if (pickPdf != 0) {
+                    const float ul0 = halton_dim(sc, rp.hal, index, dim), ul1 = halton_dim(sc, rp.hal, index, dim + 1);
+                    const float us0 = halton_dim(sc, rp.hal, index, dim + 2), us1 = halton_dim(sc, rp.hal, index, dim + 3);
+                    dim += 4;
+                    const DevLight light = sc.lights[lightNum];
+                    const int flagsNS = BX_ALL & ~BX_SPECULAR;
+                    const bool isDelta = light.type != 2;
+                    vec3 wi;
+                    float lightPdf = 0, scatteringPdf = 0;
+                    DevIt it; it.p = si.p; it.pErr = si.pErr; it.n = si.n;
+                    DevIt pl;
+                    rgb Li = light_sample(sc, light, it, ul0, ul1, &wi, &lightPdf, &pl);
+                    rgb pendLight(0.f), pendMis(0.f);
+                    if (lightPdf > 0 && !is_black(Li)) {
+                        rgb f = bsdf_f(bsdf, si.wo, wi, flagsNS) * absdot(wi, si.ns);
+                        scatteringPdf = bsdf_pdf(bsdf, si.wo, wi, flagsNS);
+                        if (!is_black(f)) {
+                            // shadow ray: Interaction::SpawnRayTo(it) (core/interaction.h:73-78)
+                            vec3 origin = offset_ray_origin(it.p, it.pErr, it.n, pl.p - it.p);
+                            vec3 target = offset_ray_origin(pl.p, pl.pErr, pl.n, origin - pl.p);
+                            vec3 d = target - origin;
+                            ps.sh.ox[slot] = origin.x; ps.sh.oy[slot] = origin.y; ps.sh.oz[slot] = origin.z;
+                            ps.sh.dx[slot] = d.x; ps.sh.dy[slot] = d.y; ps.sh.dz[slot] = d.z;
+                            ps.sh.tmax[slot] = 1 - HPRT_SHADOW_EPS;
+                            if (isDelta) pendLight = f * Li / lightPdf;
+                            else { float w = power_heuristic(lightPdf, scatteringPdf); pendLight = f * Li * w / lightPdf; }
+                            wantShadow = true;
+                        }
+                    }
+                    if (!isDelta) {
+                        int sampledType = 0;
+                        rgb f = bsdf_sample(bsdf, si.wo, &wi, us0, us1, &scatteringPdf, flagsNS, &sampledType);
+                        f = f * absdot(wi, si.ns);
+                        if (!is_black(f) && scatteringPdf > 0) {
+                            float lp = light_pdf(sc, light, it, wi);
+                            if (lp != 0) {     // "if (lightPdf == 0) return Ld;" keeps the light-sampling term only
+                                float w = power_heuristic(scatteringPdf, lp);
+                                vec3 o = offset_ray_origin(si.p, si.pErr, si.n, wi);
+                                ps.mis.ox[slot] = o.x; ps.mis.oy[slot] = o.y; ps.mis.oz[slot] = o.z;
+                                ps.mis.dx[slot] = wi.x; ps.mis.dy[slot] = wi.y; ps.mis.dz[slot] = wi.z;
+                                // contribution if the ray reaches the light's emitting side: f * Li * Tr * weight / pdf
+                                rgb Lemit(light.I[0], light.I[1], light.I[2]);
+                                pendMis = f * Lemit * rgb(1.f) * w / scatteringPdf;
+                                wantMis = true;
+                            }
+                        }
+                    }
+                    if (wantShadow || wantMis) {
+                        ps.pendLightR[slot] = pendLight.r; ps.pendLightG[slot] = pendLight.g; ps.pendLightB[slot] = pendLight.b;
+                        ps.pendMisR[slot] = pendMis.r; ps.pendMisG[slot] = pendMis.g; ps.pendMisB[slot] = pendMis.b;
+                        ps.pendBetaR[slot] = beta.r; ps.pendBetaG[slot] = beta.g; ps.pendBetaB[slot] = beta.b;
+                        ps.pendPdf[slot] = pickPdf;
+                        ps.pendInfo[slot] = (uint32_t)lightNum | (wantShadow ? 0x40000000u : 0u) | (wantMis ? 0x80000000u : 0u);
+                        wantResolve = true;
+                    }
+                    // neither ray: Ld == 0, "L += beta * 0 / pdf" leaves L unchanged
+                }
+            }
+            // ---- sample the BSDF for the next path segment (path.cpp:141-164) ----
+            const float ub0 = halton_dim(sc, rp.hal, index, dim), ub1 = halton_dim(sc, rp.hal, index, dim + 1);
+            dim += 2;
+            vec3 wo = -rayD, wi;
+            float pdf = 0; int flags = 0;
+            rgb f = bsdf_sample(bsdf, wo, &wi, ub0, ub1, &pdf, BX_ALL, &flags);
+            if (!(is_black(f) || pdf == 0.f)) {
+                beta = beta * (f * absdot(wi, si.ns) / pdf);
+                vec3 o = offset_ray_origin(si.p, si.pErr, si.n, wi);
+                bool alive = true;
+                // Russian roulette (path.cpp:191-199); etaScale == 1 without transmission
+                rgb rrBeta = beta * 1.0f;
+                if (max_value(rrBeta) < rp.rrThreshold && bounces > 3) {
+                    float qv = sel_max(.05f, 1 - max_value(rrBeta));
+                    float u = halton_dim(sc, rp.hal, index, dim);
+                    dim += 1;
+                    if (u < qv) alive = false;
+                    else beta = beta / (1 - qv);
+                }
+                if (alive) {
+                    ps.ray.ox[slot] = o.x; ps.ray.oy[slot] = o.y; ps.ray.oz[slot] = o.z;
+                    ps.ray.dx[slot] = wi.x; ps.ray.dy[slot] = wi.y; ps.ray.dz[slot] = wi.z;
+                    ps.ray.tmax[slot] = HPRT_INF;
+                    ps.betaR[slot] = beta.r; ps.betaG[slot] = beta.g; ps.betaB[slot] = beta.b;
+                    ps.state[slot] = (uint32_t)dim | ((uint32_t)(bounces + 1) << 8);
+                    wantNext = true;
+                }
+            }
+        }
+    }
+    // queue appends in wave-uniform control flow
+    uint32_t pos;
+    pos = wave_append(q.nextCount, wantNext); if (wantNext) q.next[pos] = slot;
+    pos = wave_append(q.shadowCount, wantShadow); if (wantShadow) q.shadow[pos] = slot;
+    pos = wave_append(q.misCount, wantMis); if (wantMis) q.mis[pos] = slot;
+    pos = wave_append(q.resolveCount, wantResolve); if (wantResolve) q.resolve[pos] = slot;
+}
+
+// ---------------------------------------------------------------------------
+// k_resolve: Ld = [unoccluded ? light term] + [MIS ray reached the light ? bsdf term];
+// L += beta * (Ld / lightPickPdf)   (core/integrator.cpp:106, integrators/path.cpp:132-137)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resolve(DevScene sc, PathPlanes ps, const uint32_t *queue, const uint32_t *countPtr) {
+    const uint32_t n = *countPtr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = queue[i];
+    const uint32_t info = ps.pendInfo[slot];
+    const int lightNum = (int)(info & 0x3fffffffu);
+    rgb Ld(0.f);
+    if ((info & 0x40000000u) && !ps.occluded[slot]) Ld = Ld + rgb(ps.pendLightR[slot], ps.pendLightG[slot], ps.pendLightB[slot]);
+    if (info & 0x80000000u) {
+        const int32_t prim = ps.misHit.prim[slot];
+        if (prim >= 0) {
+            const int shapeId = (int)__float_as_uint(sc.tris[3 * prim + 1].w);
+            if (sc.shapes[shapeId].areaLight == lightNum) {
+                // lightIsect.Le(-wi): the normal of the emitter at the hit (sphere emitters)
+                DRay r; r.o = vec3(ps.mis.ox[slot], ps.mis.oy[slot], ps.mis.oz[slot]);
+                r.d = vec3(ps.mis.dx[slot], ps.mis.dy[slot], ps.mis.dz[slot]); r.tMax = HPRT_INF;
+                DevSI li; float tt;
+                if (fill_sphere(sc, shapeId, r, &li, &tt)) {
+                    const DevLight light = sc.lights[lightNum];
+                    if (light.twoSided || dot(li.n, -r.d) > 0) Ld = Ld + rgb(ps.pendMisR[slot], ps.pendMisG[slot], ps.pendMisB[slot]);
+                }
+            }
+        }
+    }
+    rgb add = rgb(ps.pendBetaR[slot], ps.pendBetaG[slot], ps.pendBetaB[slot]) * (Ld / ps.pendPdf[slot]);
+    ps.LR[slot] = ps.LR[slot] + add.r; ps.LG[slot] = ps.LG[slot] + add.g; ps.LB[slot] = ps.LB[slot] + add.b;
+}
+
+// ---------------------------------------------------------------------------
+// k_store_radiance: radiance guards (core/integrator.cpp:300-321) and transfer of the
+// finished batch into the per-sample radiance store Lall[channel][sample][pixel].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_store_radiance(PathPlanes ps, float *LallR, float *LallG, float *LallB, uint32_t nPix,
+                                                         uint32_t s0, uint32_t nSlots) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nSlots) return;
+    rgb L(ps.LR[slot], ps.LG[slot], ps.LB[slot]);
+    const float y = luminance(L);
+    if (is_nan(L.r) || is_nan(L.g) || is_nan(L.b)) L = rgb(0.f);
+    else if ((double)y < -1e-5) L = rgb(0.f);
+    else if (is_inf(y)) L = rgb(0.f);
+    const size_t o = (size_t)s0 * nPix + slot;   // slot = sIdx*nPix + pix
+    LallR[o] = L.r; LallG[o] = L.g; LallB[o] = L.b;
+}
+
+// ---------------------------------------------------------------------------
+// Film.  k_find_irregular lists the camera samples whose box-filter footprint is not
+// exactly their own pixel (pFilm fraction 0, or pixel + u rounding up to the next
+// integer: FilmTile::AddSample, core/film.h:136-143).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void footprint(const FilmGeom &fg, int px, int py, float fx, float fy, int *x0, int *x1, int *y0, int *y1) {
+    // tile pixel bounds of the tile that samples (px,py): Film::GetFilmTile, core/film.cpp:96-107
+    const int tx0 = fg.sx0 + ((px - fg.sx0) / 16) * 16, ty0 = fg.sy0 + ((py - fg.sy0) / 16) * 16;
+    const int tx1 = sel_min(tx0 + 16, fg.sx1), ty1 = sel_min(ty0 + 16, fg.sy1);
+    const int bx0 = sel_max((int)ceilf((float)tx0 - 0.5f - fg.rx), fg.cx0), by0 = sel_max((int)ceilf((float)ty0 - 0.5f - fg.ry), fg.cy0);
+    const int bx1 = sel_min((int)floorf((float)tx1 - 0.5f + fg.rx) + 1, fg.cx1), by1 = sel_min((int)floorf((float)ty1 - 0.5f + fg.ry) + 1, fg.cy1);
+    const float dxf = fx - 0.5f, dyf = fy - 0.5f;
+    *x0 = sel_max((int)ceilf(dxf - fg.rx), bx0); *y0 = sel_max((int)ceilf(dyf - fg.ry), by0);
+    *x1 = sel_min((int)floorf(dxf + fg.rx) + 1, bx1); *y1 = sel_min((int)floorf(dyf + fg.ry) + 1, by1);
+}
+__global__ __launch_bounds__(256) void k_find_irregular(DevScene sc, RenderParams rp, FilmGeom fg, uint32_t spp, uint32_t *count,
+                                                        uint32_t capacity, IrregularSample *out) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)rp.nPix * spp;
+    bool irregular = false;
+    IrregularSample rec;
+    if (g < total) {
+        const uint32_t pix = (uint32_t)(g % rp.nPix), s = (uint32_t)(g / rp.nPix);
+        const uint32_t pxy = rp.pixelXY[pix];
+        const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
+        const uint64_t index = (uint64_t)rp.pixelOffset[pix] + (uint64_t)s * (uint64_t)rp.hal.sampleStride;
+        const float fx = (float)px + halton_dim(sc, rp.hal, index, 0), fy = (float)py + halton_dim(sc, rp.hal, index, 1);
+        int x0, x1, y0, y1;
+        footprint(fg, px, py, fx, fy, &x0, &x1, &y0, &y1);
+        irregular = !(x0 == px && x1 == px + 1 && y0 == py && y1 == py + 1);
+        rec.pix = pix; rec.sample = s; rec.x0 = (int16_t)x0; rec.x1 = (int16_t)x1; rec.y0 = (int16_t)y0; rec.y1 = (int16_t)y1;
+    }
+    const uint32_t pos = wave_append(count, irregular);
+    if (irregular && pos < capacity) out[pos] = rec;
+}
+
+__device__ __forceinline__ rgb clamp_luminance(rgb L, float maxY) {   // core/film.h:133-134
+    float y = luminance(L);
+    if (y > maxY) { float s = maxY / luminance(L); L = L * s; }
+    return L;
+}
+__device__ __forceinline__ void rgb_to_xyz(rgb c, float xyz[3]) {     // core/spectrum.h:62-66
+    xyz[0] = 0.412453f * c.r + 0.357580f * c.g + 0.180423f * c.b;
+    xyz[1] = 0.212671f * c.r + 0.715160f * c.g + 0.072169f * c.b;
+    xyz[2] = 0.019334f * c.r + 0.119193f * c.g + 0.950227f * c.b;
+}
+// One thread per local pixel: contribSum = pre-extras, own samples, post-extras, in the
+// order the reference's tile loop produces them; then MergeFilmTile's RGB->XYZ.
+__global__ __launch_bounds__(256) void k_film_own(RenderParams rp, FilmGeom fg, const float *LallR, const float *LallG,
+                                                  const float *LallB, uint32_t spp, FilmExtras ex, float *filmXYZW) {
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= rp.nPix) return;
+    rgb c(0.f); float w = 0.f;
+    const uint32_t eBeg = ex.ownBegin ? ex.ownBegin[pix] : 0u, eEnd = ex.ownBegin ? ex.ownBegin[pix + 1] : 0u;
+    uint32_t e = eBeg;
+    for (; e < eEnd && ex.ownIsPre[e]; ++e) {
+        const size_t o = (size_t)ex.ownSample[e] * rp.nPix + ex.ownSrcPix[e];
+        c = c + clamp_luminance(rgb(LallR[o], LallG[o], LallB[o]), fg.maxSampleLuminance) * 1.0f * 1.0f;
+        w += 1.f;
+    }
+    for (uint32_t s = 0; s < spp; ++s) {
+        const size_t o = (size_t)s * rp.nPix + pix;
+        c = c + clamp_luminance(rgb(LallR[o], LallG[o], LallB[o]), fg.maxSampleLuminance) * 1.0f * 1.0f;
+        w += 1.f;
+    }
+    for (; e < eEnd; ++e) {
+        const size_t o = (size_t)ex.ownSample[e] * rp.nPix + ex.ownSrcPix[e];
+        c = c + clamp_luminance(rgb(LallR[o], LallG[o], LallB[o]), fg.maxSampleLuminance) * 1.0f * 1.0f;
+        w += 1.f;
+    }
+    float xyz[3];
+    rgb_to_xyz(c, xyz);
+    const uint32_t pxy = rp.pixelXY[pix];
+    const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
+    const size_t fo = 4 * ((size_t)(py - fg.cy0) * (size_t)(fg.cx1 - fg.cx0) + (size_t)(px - fg.cx0));
+    // Film::pixels start at zero: 0 + v
+    filmXYZW[fo] = 0.f + xyz[0]; filmXYZW[fo + 1] = 0.f + xyz[1]; filmXYZW[fo + 2] = 0.f + xyz[2]; filmXYZW[fo + 3] = 0.f + w;
+}
+// One thread per destination pixel that receives samples from OTHER tiles: each source
+// tile's FilmTile pixel is folded on its own, converted to XYZ and merged.
+__global__ __launch_bounds__(64) void k_film_foreign(RenderParams rp, FilmGeom fg, const float *LallR, const float *LallG,
+                                                     const float *LallB, FilmExtras ex, float *filmXYZW) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= ex.nForeignDest) return;
+    const size_t fo = 4 * (size_t)ex.foreignDestFilmIndex[d];
+    for (uint32_t g = ex.foreignDestBegin[d]; g < ex.foreignDestBegin[d + 1]; ++g) {
+        rgb c(0.f); float w = 0.f;
+        for (uint32_t e = ex.foreignGroupBegin[g]; e < ex.foreignGroupBegin[g + 1]; ++e) {
+            const size_t o = (size_t)ex.foreignSample[e] * rp.nPix + ex.foreignSrcPix[e];
+            c = c + clamp_luminance(rgb(LallR[o], LallG[o], LallB[o]), fg.maxSampleLuminance) * 1.0f * 1.0f;
+            w += 1.f;
+        }
+        float xyz[3];
+        rgb_to_xyz(c, xyz);
+        filmXYZW[fo] += xyz[0]; filmXYZW[fo + 1] += xyz[1]; filmXYZW[fo + 2] += xyz[2]; filmXYZW[fo + 3] += w;
+    }
+}
+
+__global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static inline uint32_t blocks_for(size_t n, uint32_t bs) { return (uint32_t)((n + bs - 1) / bs); }
+
+void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
+                 uint32_t countImm, uint32_t gridItems, const RayPlanes &rays, const HitPlanes &hits, uint8_t *occ,
+                 DevCounters *counters) {
+    if (gridItems == 0) return;
+    dim3 grid(blocks_for(gridItems, HPRT_TRACE_BLOCK)), block(HPRT_TRACE_BLOCK);
+    if (anyHit) {
+        if (count) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters);
+        else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters);
+    } else {
+        if (count) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters);
+        else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters);
+    }
+}
+void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, uint32_t s0, uint32_t nSlots) {
+    if (nSlots) hipLaunchKernelGGL(k_generate, dim3(blocks_for(nSlots, 256)), dim3(256), 0, st, sc, rp, ps, s0, nSlots);
+}
+void LaunchShade(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, const uint32_t *queue,
+                 const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, uint32_t s0, const QueueSet &q) {
+    if (gridItems) hipLaunchKernelGGL(k_shade, dim3(blocks_for(gridItems, 256)), dim3(256), 0, st, sc, rp, ps, queue, countPtr, countImm, s0, q);
+}
+void LaunchResolve(hipStream_t st, const DevScene &sc, const PathPlanes &ps, const uint32_t *queue, const uint32_t *countPtr,
+                   uint32_t gridItems) {
+    if (gridItems) hipLaunchKernelGGL(k_resolve, dim3(blocks_for(gridItems, 256)), dim3(256), 0, st, sc, ps, queue, countPtr);
+}
+void LaunchStoreRadiance(hipStream_t st, const PathPlanes &ps, float *LallR, float *LallG, float *LallB, uint32_t nPix, uint32_t s0,
+                         uint32_t nSlots) {
+    if (nSlots) hipLaunchKernelGGL(k_store_radiance, dim3(blocks_for(nSlots, 256)), dim3(256), 0, st, ps, LallR, LallG, LallB, nPix, s0, nSlots);
+}
+void LaunchFindIrregular(hipStream_t st, const DevScene &sc, const RenderParams &rp, const FilmGeom &fg, uint32_t spp, uint32_t *count,
+                         uint32_t capacity, IrregularSample *out) {
+    const size_t total = (size_t)rp.nPix * spp;
+    if (total) hipLaunchKernelGGL(k_find_irregular, dim3(blocks_for(total, 256)), dim3(256), 0, st, sc, rp, fg, spp, count, capacity, out);
+}
+void LaunchFilmOwn(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, const float *LallR, const float *LallG, const float *LallB,
+                   uint32_t spp, const FilmExtras &ex, float *film) {
+    if (rp.nPix) hipLaunchKernelGGL(k_film_own, dim3(blocks_for(rp.nPix, 256)), dim3(256), 0, st, rp, fg, LallR, LallG, LallB, spp, ex, film);
+}
+void LaunchFilmForeign(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, const float *LallR, const float *LallG,
+                       const float *LallB, const FilmExtras &ex, float *film) {
+    if (ex.nForeignDest) hipLaunchKernelGGL(k_film_foreign, dim3(blocks_for(ex.nForeignDest, 64)), dim3(64), 0, st, rp, fg, LallR, LallG, LallB, ex, film);
+}
+
+}  // namespace hprt
