@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel per GPU (BASELINE config[1]: 256)")
     ap.add_argument("--spp-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=16)
+    ap.add_argument("--cpu-spp", type=int, default=128)
     args = ap.parse_args()
 
     import numpy as np
@@ -61,6 +61,7 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     hprt = importlib.import_module("thesis-pbrt-v3_amd")
+    tiles = importlib.import_module("thesis-pbrt-v3_amd.tiles")
     model = hprt.Model.load(FIXTURE)
     bvh = hprt.Bvh(model)
     scene = hprt.Scene(model, bvh, device=dev.index)
@@ -72,10 +73,10 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step(count_work=False):
-        _, st = scene.render(opt, tile_begin=rank, tile_end=0, tile_stride=max(1, world), spp_chunk=args.spp_chunk,
-                             count_work=count_work, film_ptr=film.data_ptr(), stream=stream)
+        _, st = scene.render(opt, spp_chunk=args.spp_chunk, count_work=count_work, film_ptr=film.data_ptr(), stream=stream,
+                             **tiles.shard(rank, max(1, world)))
         if dist is not None:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)   # Film tiles -> rank 0 (RCCL over xGMI); addends are disjoint
+            tiles.gather_film(film, dist, dst=0)             # Film tiles -> rank 0 (RCCL over xGMI); addends are disjoint
         return st
 
     def barrier():

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <string>
 #include "orc_integrator.h"
+#include "orc_selftests.h"
 
 namespace orc { bool g_use_libm = false; }
 using namespace orc;
@@ -168,6 +169,14 @@ int orc_render(void *h, int spp, int nThreads, float *rgb, uint64_t *counters13,
     if (seconds) *seconds = r->renderSeconds;
     return r->nThreads;
 }
+// Render only tiles tile_begin, tile_begin+stride, ... (one rank of a tile-sharded job); film state only
+int orc_render_tiles(void *h, int spp, int nThreads, int tileBegin, int tileStride, uint64_t *counters13) {
+    Renderer *r = (Renderer *)h;
+    r->nThreads = nThreads > 0 ? nThreads : (int)std::thread::hardware_concurrency();
+    r->Render(spp, tileBegin, tileStride > 0 ? tileStride : 1);
+    if (counters13) export_counters(r->total, counters13);
+    return r->nThreads;
+}
 // Raw film state (xyz + weight per pixel) for exact film comparisons
 void orc_film_raw(void *h, float *xyzw) {
     Renderer *r = (Renderer *)h;
@@ -176,6 +185,28 @@ void orc_film_raw(void *h, float *xyzw) {
         xyzw[4 * i + 2] = r->film.pixels[i].xyz[2]; xyzw[4 * i + 3] = r->film.pixels[i].filterWeightSum;
     }
 }
+
+float orc_scrambled_radical_inverse_perm(int baseIndex, uint64_t a, const uint16_t *perm) {
+    return ScrambledRadicalInverse(baseIndex, a, perm);
+}
+int orc_prime(int i) { return Primes()[i]; }
+// single-triangle Triangle::Intersect (mesh without N/uv/S)
+int orc_triangle_intersect(const float *p9, const float *o, const float *d, float tmax, float *tHit) {
+    Mesh m; m.nTris = 1; m.nVerts = 3; m.hasN = m.hasUV = m.hasS = false;
+    m.idx = {0, 1, 2};
+    for (int i = 0; i < 3; ++i) m.p.push_back(V3(p9[3 * i], p9[3 * i + 1], p9[3 * i + 2]));
+    TriRef tr{&m, m.idx.data(), false};
+    Ray ray(V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), tmax);
+    SurfaceInteraction si; Counters c; Float t = 0;
+    bool hit = TriangleIntersect(tr, ray, &t, &si, c);
+    if (tHit) *tHit = t;
+    return hit ? 1 : 0;
+}
+// the reference's own property tests, restated over the oracle (orc_selftests.h)
+int orc_selftest_watertight(int nRays) { return SelfTestWatertight(nRays); }
+int orc_selftest_reintersect(int nTriangles, int nRaysPerTriangle, int *nTested) { return SelfTestReintersect(nTriangles, nRaysPerTriangle, nTested); }
+int orc_selftest_radical_inverse() { return SelfTestRadicalInverse(); }
+int orc_selftest_scrambled_radical_inverse() { return SelfTestScrambledRadicalInverse(); }
 
 // detmath probes
 float orc_det_sinf(float x) { return (float)det::sin_d((double)x); }

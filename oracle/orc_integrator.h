@@ -477,7 +477,7 @@ struct Renderer {
     }
 
     // SamplerIntegrator::Render, core/integrator.cpp:230-360.  spp<=0 uses the scene's.
-    void Render(int sppOverride = 0) {
+    void Render(int sppOverride = 0, int tileBegin = 0, int tileStride = 1) {
         int spp = sppOverride > 0 ? sppOverride : scene.prm.spp;
         int sx0, sy0, sx1, sy1;
         film.GetSampleBounds(&sx0, &sy0, &sx1, &sy1);
@@ -492,7 +492,7 @@ struct Renderer {
             Counters ctr;
             HaltonSampler sampler(spp, sx0, sy0, sx1, sy1, scene.prm.samplePixelCenter != 0);
             while (true) {
-                int t = next.fetch_add(1);
+                int t = tileBegin + tileStride * next.fetch_add(1);   // tile subset: what one GPU of a tile-sharded job renders
                 if (t >= ntx * nty) break;
                 int tx = t % ntx, ty = t / ntx;
                 int x0 = sx0 + tx * tileSize, x1 = smin(x0 + tileSize, sx1);

@@ -11,6 +11,15 @@ namespace orc {
 struct RNG {
     uint64_t state, inc;
     RNG() : state(0x853c49e6748fea9bULL), inc(0xda3e39cb94b95bdbULL) {}
+    explicit RNG(uint64_t sequenceIndex) { SetSequence(sequenceIndex); }
+    void SetSequence(uint64_t initseq) {       // core/rng.h:130-136
+        state = 0u;
+        inc = (initseq << 1u) | 1u;
+        UniformUInt32();
+        state += 0x853c49e6748fea9bULL;
+        UniformUInt32();
+    }
+    Float UniformFloat() { return smin(OneMinusEpsilon, Float(UniformUInt32() * 0x1p-32f)); }   // core/rng.h:78-85
     uint32_t UniformUInt32() {
         uint64_t oldstate = state;
         state = oldstate * 0x5851f42d4c957f2dULL + inc;

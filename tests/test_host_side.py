@@ -1,0 +1,205 @@
+"""CPU tests of the product's host side: the C ABI surface, the pbrt front-end, the
+BVH builder (byte-identical to the oracle's independent restatement of
+accelerators/bvh.cpp), Halton tables, baked scenes, film resolve.  No GPU needed."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, KILLEROO, ROOT
+
+
+def _parse_text(hprt, tmp_path, text, name="scene.pbrt", subst=None):
+    p = tmp_path / name
+    p.write_text(text)
+    return hprt.Model.parse(str(p), subst or {})
+
+
+HEADER = """LookAt 3 4 1.5  .5 .5 0  0 0 1
+Camera "perspective" "float fov" [45]
+Film "image" "integer xresolution" [64] "integer yresolution" [48]
+Sampler "halton" "integer pixelsamples" [4]
+Integrator "path" "integer maxdepth" [3]
+Accelerator "bvh"
+WorldBegin
+LightSource "point" "point from" [0 0 5] "color I" [10 10 10]
+"""
+
+
+def _mesh_scene(P, idx, extra=""):
+    return (HEADER + extra + 'Shape "trianglemesh" "integer indices" [' + " ".join(str(int(i)) for i in idx.ravel()) +
+            '] "point P" [' + " ".join(repr(float(v)) for v in P.ravel()) + "]\nWorldEnd\n")
+
+
+def test_every_header_symbol_is_exported(hprt):
+    header = open(os.path.join(ROOT, "include", "hprt.h")).read()
+    declared = sorted(set(re.findall(r"\b(hprt_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 25
+    lib = C.CDLL(hprt.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "include/hprt.h declares %s but libhprt.so does not export it" % name
+    assert sorted(hprt.EXPORTS) == declared
+
+
+def test_device_entry_points_fail_loudly_without_gpu(hprt, killeroo_model, killeroo_bvh):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(hprt.HprtError) as e:
+        hprt.Scene(killeroo_model, killeroo_bvh)
+    assert e.value.code == hprt.E_NO_DEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_builder_matches_oracle_on_killeroo(killeroo_bvh, killeroo_oracle):
+    n1, o1 = killeroo_oracle.bvh_arrays()
+    n2, o2 = killeroo_bvh.arrays()
+    assert np.array_equal(n1, n2) and np.array_equal(o1, o2)
+    i = killeroo_bvh.info()
+    assert (i["nodes"], i["prims"], i["leaves"], i["max_depth"]) == (126655, 66533, 63328, 24)
+
+
+def _random_soup(rng, n, scale=1.0, quantize=None):
+    c = rng.uniform(-10, 10, (n, 1, 3))
+    P = (c + rng.normal(0, scale, (n, 3, 3))).astype(np.float32)
+    if quantize:
+        P = (np.round(P / quantize) * quantize).astype(np.float32)   # many equal centroids / coplanar boxes
+    return P.reshape(-1, 3), np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+
+
+@pytest.mark.parametrize("case", ["random", "quantized", "degenerate", "single", "identical", "maxprims1"])
+def test_builder_matches_oracle_on_synthetic_meshes(hprt, orc, tmp_path, case):
+    rng = np.random.default_rng(hash(case) % 1000)
+    extra = ""
+    if case == "random":
+        P, idx = _random_soup(rng, 3000)
+    elif case == "quantized":
+        P, idx = _random_soup(rng, 2000, quantize=2.0)
+    elif case == "degenerate":       # zero-area triangles and flat boxes: totalSA == 0 leaves (bvh.cpp:236-241,291)
+        P, idx = _random_soup(rng, 300)
+        P[: 3 * 40] = np.repeat(P[: 3 * 40 : 3], 3, axis=0)
+        P[3 * 40 : 3 * 80, 2] = 0.0
+    elif case == "single":
+        P, idx = _random_soup(rng, 1)
+    elif case == "identical":        # every primitive has the same bounds: tie-break by primitive number only
+        tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+        P = np.tile(tri, (37, 1)); idx = np.arange(111, dtype=np.int32).reshape(-1, 3)
+    else:
+        P, idx = _random_soup(rng, 500)
+        extra = ""
+    text = _mesh_scene(P, idx)
+    if case == "maxprims1":
+        text = text.replace('Accelerator "bvh"', 'Accelerator "bvh" "integer maxnodeprims" [1] "integer intersectcost" [2] "integer traversalcost" [3]')
+    m = _parse_text(hprt, tmp_path, text)
+    baked = str(tmp_path / "s.hprt")
+    m.save(baked)
+    b = hprt.Bvh(m)
+    o = orc.OracleScene(baked)
+    n1, o1 = o.bvh_arrays()
+    n2, o2 = b.arrays()
+    assert np.array_equal(n1, n2), case
+    assert np.array_equal(o1, o2), case
+    assert sorted(o2.tolist()) == list(range(len(o2)))
+    assert b.info()["max_depth"] == o.bvh_info()["max_depth"]
+
+
+def test_frontend_transforms_materials_and_lights(hprt, tmp_path):
+    text = """LookAt 400 20 30   0 63 -110   0 0 1
+Rotate -5 0 0 1
+Camera "perspective" "float fov" [39]
+Film "image" "integer xresolution" [700] "integer yresolution" [700] "string filename" "x.exr"
+# a comment
+Sampler "halton" "integer pixelsamples" [8]
+Accelerator $acc "integer nbDirections" [$accnr]
+Integrator "path" "integer maxdepth" [5]
+WorldBegin
+AttributeBegin
+Material "matte" "color Kd" [0 0 0]
+Translate 150 0  20
+Translate 0 120 0
+AreaLightSource "area"  "color L" [2000 2000 2000] "integer nsamples" [8]
+Shape "sphere" "float radius" [3]
+AttributeEnd
+AttributeBegin
+  Material "plastic" "color Kd" [.4 .2 .2] "color Ks" [.5 .5 .5] "float roughness" [.025]
+  Scale .5 .5 .5
+  Shape "trianglemesh" "point P" [ -1 -1 0 1 -1 0 1 1 0 -1 1 0 ] "float uv" [ 0 0 5 0 5 5 0 5 ] "integer indices" [ 0 1 2 2 3 0]
+AttributeEnd
+LightSource "distant" "point from" [0 0 1] "point to" [0 0 0] "color L" [3 3 3]
+WorldEnd
+"""
+    m = _parse_text(hprt, tmp_path, text)
+    c = m.counts()
+    assert c == {"shapes": 2, "primitives": 3, "triangles": 2, "spheres": 1, "materials": 2, "lights": 2}
+    o = m.options
+    assert (o.xres, o.yres, o.spp, o.max_depth) == (700, 700, 8, 5)
+    assert abs(o.fov - 39.0) < 1e-6 and o.max_node_prims == 4 and o.isect_cost == 8 and o.trav_cost == 1
+    # same camera as the baked killeroo-simple fixture (same LookAt/Rotate arithmetic)
+    k = hprt.Model.load(KILLEROO).options
+    assert list(o.camera_to_world) == list(k.camera_to_world) and list(o.world_to_camera) == list(k.world_to_camera)
+    assert m.warnings() == []
+
+
+def test_frontend_rejects_and_warns(hprt, tmp_path):
+    with pytest.raises(hprt.HprtError) as e:
+        _parse_text(hprt, tmp_path, HEADER + 'Shape "trianglemesh" "integer indices" [0 1 5] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n')
+    assert e.value.code == hprt.E_PARSE and "out-of-bounds" in str(e.value)
+    with pytest.raises(hprt.HprtError):
+        _parse_text(hprt, tmp_path, HEADER + "Bogus 1 2 3\nWorldEnd\n")
+    with pytest.raises(hprt.HprtError):
+        hprt.Model.parse(str(tmp_path / "missing.pbrt"))
+    m = _parse_text(hprt, tmp_path, HEADER + 'Material "glass"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nShape "cone"\nWorldEnd\n')
+    w = " ".join(m.warnings())
+    assert "glass" in w and "cone" in w
+
+
+def test_loop_subdivision_of_a_closed_and_an_open_mesh(hprt, tmp_path):
+    # octahedron (closed, valence-4 vertices) and a single quad (boundary rules)
+    octa = ('Shape "loopsubdiv" "integer nlevels" [2] "integer indices" [0 2 4 2 1 4 1 3 4 3 0 4 2 0 5 1 2 5 3 1 5 0 3 5] '
+            '"point P" [1 0 0 -1 0 0 0 1 0 0 -1 0 0 0 1 0 0 -1]\n')
+    m = _parse_text(hprt, tmp_path, HEADER + octa + "WorldEnd\n")
+    assert m.counts()["triangles"] == 8 * 16
+    quad = 'Shape "loopsubdiv" "integer nlevels" [1] "integer indices" [0 1 2 0 2 3] "point P" [0 0 0 1 0 0 1 1 0 0 1 0]\n'
+    m2 = _parse_text(hprt, tmp_path, HEADER + quad + "WorldEnd\n", name="q.pbrt")
+    assert m2.counts()["triangles"] == 8
+    # the bundled killeroo (nlevels 1): 8316 control faces -> 33264 triangles per copy, two copies + 2 quads
+    assert hprt.Model.load(KILLEROO).counts()["triangles"] == 2 * 33264 + 4
+
+
+def test_baked_scene_roundtrip_and_corruption(hprt, tmp_path):
+    m = hprt.Model.load(KILLEROO)
+    out = str(tmp_path / "copy.hprt")
+    m.save(out)
+    assert open(out, "rb").read() == open(KILLEROO, "rb").read()
+    data = bytearray(open(KILLEROO, "rb").read())
+    (tmp_path / "trunc.hprt").write_bytes(bytes(data[: len(data) // 2]))
+    with pytest.raises(hprt.HprtError):
+        hprt.Model.load(str(tmp_path / "trunc.hprt"))
+    data[0:4] = b"XXXX"
+    (tmp_path / "magic.hprt").write_bytes(bytes(data))
+    with pytest.raises(hprt.HprtError):
+        hprt.Model.load(str(tmp_path / "magic.hprt"))
+
+
+def test_halton_tables_match_oracle(hprt, orc):
+    mine = hprt.halton_permutations()
+    buf = np.zeros(mine.size, np.uint16)
+    n = orc.lib.orc_perm_table(buf.ctypes.data_as(C.c_void_p), buf.size)
+    assert n == mine.size == 3682913 and np.array_equal(mine, buf)
+
+
+def test_film_resolve_and_pfm(hprt, killeroo_oracle, tmp_path):
+    crop = (0.45, 0.45 + 48 / 700.0, 0.5, 0.5 + 32 / 700.0)
+    killeroo_oracle.set_film(crop=crop, spp=2)
+    rgb0, film0, _, _, _ = killeroo_oracle.render(spp=2, threads=4)
+    killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
+    rgb1 = hprt.film_resolve(film0, 1.0)
+    assert np.array_equal(rgb0.view(np.uint32), rgb1.view(np.uint32))
+    p = str(tmp_path / "o.pfm")
+    hprt.write_pfm(p, rgb1)
+    raw = open(p, "rb").read()
+    head, rest = raw.split(b"\n", 3)[:3], raw.split(b"\n", 3)[3]
+    assert head[0] == b"PF" and head[1] == b"%d %d" % (rgb1.shape[1], rgb1.shape[0]) and float(head[2]) < 0
+    back = np.frombuffer(rest, np.float32).reshape(rgb1.shape)[::-1]
+    assert np.array_equal(back, rgb1)
