@@ -82,6 +82,10 @@ const char *hprt_model_warnings(const HprtModel *m);
 /* ------------------------------------------------------------------------ */
 typedef struct HprtBvh HprtBvh;
 int hprt_bvh_build(const HprtModel *m, HprtBvh **out);
+/* The same from the primitives' world bounds (Primitive::WorldBound(), core/primitive.h:55):
+ * bmin/bmax hold 3 floats per primitive in creation order. */
+int hprt_bvh_build_from_bounds(size_t n_prims, const float *bmin, const float *bmax, int max_node_prims, int isect_cost,
+                               int trav_cost, HprtBvh **out);
 void hprt_bvh_destroy(HprtBvh *b);
 /* info[0..3] = nodes, primitives, leaves, max depth; bounds6 = root pMin,pMax
  * (BVHAccel::WorldBound, accelerators/bvh.cpp:187-189) */

@@ -92,6 +92,7 @@ def _load():
         "hprt_model_counts": (C.c_int, [vp, P(u64)]),
         "hprt_model_warnings": (cp, [vp]),
         "hprt_bvh_build": (C.c_int, [vp, P(vp)]),
+        "hprt_bvh_build_from_bounds": (C.c_int, [sz, vp, vp, C.c_int, C.c_int, C.c_int, P(vp)]),
         "hprt_bvh_destroy": (None, [vp]),
         "hprt_bvh_info": (C.c_int, [vp, P(u32), P(C.c_float)]),
         "hprt_bvh_copy": (C.c_int, [vp, vp, vp]),
@@ -185,10 +186,18 @@ class Model:
 class Bvh:
     """Flattened BVH (host): CreateBVHAccelerator(prims, params)."""
 
-    def __init__(self, model):
+    def __init__(self, model=None, handle=None):
+        if handle is None:
+            handle = C.c_void_p()
+            _check(lib.hprt_bvh_build(model._h, C.byref(handle)))
+        self._h = handle
+
+    @staticmethod
+    def from_bounds(bmin, bmax, max_node_prims=4, isect_cost=8, trav_cost=1):
+        bmin = np.ascontiguousarray(bmin, np.float32); bmax = np.ascontiguousarray(bmax, np.float32)
         h = C.c_void_p()
-        _check(lib.hprt_bvh_build(model._h, C.byref(h)))
-        self._h = h
+        _check(lib.hprt_bvh_build_from_bounds(bmin.shape[0], _ptr(bmin), _ptr(bmax), max_node_prims, isect_cost, trav_cost, C.byref(h)))
+        return Bvh(handle=h)
 
     def info(self):
         i = (C.c_uint32 * 4)()

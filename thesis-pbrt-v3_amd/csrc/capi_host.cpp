@@ -108,6 +108,15 @@ int hprt_bvh_build(const HprtModel *m, HprtBvh **out) {
     *out = b;
     return HPRT_OK;
 }
+int hprt_bvh_build_from_bounds(size_t n, const float *bmin, const float *bmax, int maxNodePrims, int isectCost, int travCost,
+                               HprtBvh **out) {
+    if (!out || (n && (!bmin || !bmax))) return SetError(HPRT_E_INVALID, "hprt_bvh_build_from_bounds: null argument");
+    if (n > 0x7fffffffull) return SetError(HPRT_E_UNSUPPORTED, "more than 2^31 primitives");
+    HprtBvh *b = new HprtBvh();
+    BuildBvh(n, bmin, bmax, maxNodePrims, isectCost, travCost, &b->tree);
+    *out = b;
+    return HPRT_OK;
+}
 void hprt_bvh_destroy(HprtBvh *b) { delete b; }
 int hprt_bvh_info(const HprtBvh *b, uint32_t info[4], float bounds6[6]) {
     if (!b || !info) return SetError(HPRT_E_INVALID, "hprt_bvh_info: null argument");
