@@ -78,6 +78,17 @@ void orc_intersect(void *h, size_t n, const float *o, const float *d, const floa
     }
     if (counters13) export_counters(ctr, counters13);
 }
+// Per-ray work of the closest-hit walk: nodes fetched and primitive tests (for SIMT-efficiency studies)
+void orc_intersect_work(void *h, size_t n, const float *o, const float *d, const float *tmax, uint32_t *nodes, uint32_t *prims) {
+    Renderer *r = (Renderer *)h;
+    for (size_t i = 0; i < n; ++i) {
+        Counters ctr;
+        Ray ray(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]);
+        SurfaceInteraction si;
+        r->bvh.Intersect(ray, &si, ctr);
+        nodes[i] = (uint32_t)ctr.nodesFetched; prims[i] = (uint32_t)(ctr.triTests + ctr.sphereTests);
+    }
+}
 // Same, also returning the SurfaceInteraction fill (p, pError, n, shading.n, shading.dpdu)
 void orc_intersect_full(void *h, size_t n, const float *o, const float *d, const float *tmax, float *t,
                         int32_t *prim, float *si15) {

@@ -54,7 +54,7 @@ struct HprtScene {
     int device = 0;
     DevScene dev;
     DevBuf nodes, tris, primVtx, vN, vUV, vS, shapes, materials, lights, spheres, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
-    DevBuf counters;
+    DevBuf counters, workCounter;
     // render-time state
     DevBuf planes; size_t planeCapacity = 0;         // PathPlanes backing store
     DevBuf queues, queueCounts;
@@ -340,6 +340,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     HIP_TRY(upload(sc->primeMagic, magic));
     HIP_TRY(sc->counters.alloc(sizeof(DevCounters)));
     HIP_TRY(hipMemset(sc->counters.p, 0, sizeof(DevCounters)));
+    HIP_TRY(sc->workCounter.alloc(64));
     DevScene &dv = sc->dev;
     dv.nodes = sc->nodes.as<DevNode>(); dv.nNodes = d->n_nodes;
     dv.tris = sc->tris.as<float4>(); dv.nPrims = d->n_prims;
@@ -437,7 +438,7 @@ int hprt_intersect_device(HprtScene *s, size_t n, const float *d_rays7, float *d
     HIP_TRY(hipSetDevice(s->device));
     HitPlanes h; h.t = d_t; h.prim = d_prim;
     h.b0 = d_bary3; h.b1 = d_bary3 ? d_bary3 + n : nullptr; h.b2 = d_bary3 ? d_bary3 + 2 * n : nullptr;
-    LaunchTrace((hipStream_t)stream, s->dev, false, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(d_rays7, n), h, nullptr, nullptr);
+    LaunchTrace((hipStream_t)stream, s->dev, false, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(d_rays7, n), h, nullptr, nullptr, s->workCounter.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     return HPRT_OK;
 }
@@ -446,7 +447,7 @@ int hprt_occluded_device(HprtScene *s, size_t n, const float *d_rays7, uint8_t *
     if (n > 0xfffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
     HIP_TRY(hipSetDevice(s->device));
     HitPlanes h; h.t = nullptr; h.prim = nullptr; h.b0 = h.b1 = h.b2 = nullptr;
-    LaunchTrace((hipStream_t)stream, s->dev, true, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(d_rays7, n), h, d_occ, nullptr);
+    LaunchTrace((hipStream_t)stream, s->dev, true, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(d_rays7, n), h, d_occ, nullptr, s->workCounter.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     return HPRT_OK;
 }
@@ -471,7 +472,7 @@ static int TraceHost(HprtScene *s, bool anyHit, size_t n, const float *o, const 
         HIP_TRY(outT.alloc(4 * n)); HIP_TRY(outPrim.alloc(4 * n)); HIP_TRY(outB.alloc(12 * n));
         HitPlanes h; h.t = outT.as<float>(); h.prim = outPrim.as<int32_t>();
         h.b0 = outB.as<float>(); h.b1 = h.b0 + n; h.b2 = h.b0 + 2 * n;
-        LaunchTrace(nullptr, s->dev, false, count, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(rays.as<float>(), n), h, nullptr, s->counters.as<DevCounters>());
+        LaunchTrace(nullptr, s->dev, false, count, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(rays.as<float>(), n), h, nullptr, s->counters.as<DevCounters>(), s->workCounter.as<uint32_t>());
         HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
         if (t_out) HIP_TRY(hipMemcpy(t_out, outT.p, 4 * n, hipMemcpyDeviceToHost));
         if (prim_out) HIP_TRY(hipMemcpy(prim_out, outPrim.p, 4 * n, hipMemcpyDeviceToHost));
@@ -483,7 +484,7 @@ static int TraceHost(HprtScene *s, bool anyHit, size_t n, const float *o, const 
     } else {
         HIP_TRY(outOcc.alloc(n));
         HitPlanes h; h.t = nullptr; h.prim = nullptr; h.b0 = h.b1 = h.b2 = nullptr;
-        LaunchTrace(nullptr, s->dev, true, count, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(rays.as<float>(), n), h, outOcc.as<uint8_t>(), s->counters.as<DevCounters>());
+        LaunchTrace(nullptr, s->dev, true, count, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(rays.as<float>(), n), h, outOcc.as<uint8_t>(), s->counters.as<DevCounters>(), s->workCounter.as<uint32_t>());
         HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
         if (occ_out) HIP_TRY(hipMemcpy(occ_out, outOcc.p, n, hipMemcpyDeviceToHost));
     }
@@ -517,7 +518,7 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const PathPla
         const QueueSet &cur = q[bounce & 1];
         hipEvent_t e0 = ev.get(), e1 = ev.get();
         HIP_TRY(hipEventRecord(e0, st));
-        LaunchTrace(st, s->dev, false, count, activeQ, nullptr, active, active, ps.ray, ps.hit, nullptr, ctr);
+        LaunchTrace(st, s->dev, false, count, activeQ, nullptr, active, active, ps.ray, ps.hit, nullptr, ctr, s->workCounter.as<uint32_t>());
         HIP_TRY(hipEventRecord(e1, st));
         evExt.push_back({e0, e1}); bt->extendRays += active; ++bt->extendLaunches;
         stats->rays += active;
@@ -530,7 +531,7 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const PathPla
             hipEvent_t a = ev.get(), b = ev.get();
             HIP_TRY(hipEventRecord(a, st));
             HitPlanes none; none.t = nullptr; none.prim = nullptr; none.b0 = none.b1 = none.b2 = nullptr;
-            LaunchTrace(st, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, ps.sh, none, ps.occluded, ctr);
+            LaunchTrace(st, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, ps.sh, none, ps.occluded, ctr, s->workCounter.as<uint32_t>());
             HIP_TRY(hipEventRecord(b, st));
             evOcc.push_back({a, b}); bt->occludedRays += nShadow; ++bt->occludedLaunches;
             stats->shadow_rays += nShadow;
@@ -538,7 +539,7 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const PathPla
         if (nMis) {
             hipEvent_t a = ev.get(), b = ev.get();
             HIP_TRY(hipEventRecord(a, st));
-            LaunchTrace(st, s->dev, false, count, cur.mis, nullptr, nMis, nMis, ps.mis, ps.misHit, nullptr, ctr);
+            LaunchTrace(st, s->dev, false, count, cur.mis, nullptr, nMis, nMis, ps.mis, ps.misHit, nullptr, ctr, s->workCounter.as<uint32_t>());
             HIP_TRY(hipEventRecord(b, st));
             evExt.push_back({a, b}); bt->extendRays += nMis; ++bt->extendLaunches;
             stats->rays += nMis;

@@ -11,17 +11,30 @@ namespace hprt {
 struct DRay { vec3 o, d; float tMax; };
 
 // ---- triangle -------------------------------------------------------------
-__device__ __forceinline__ bool tri_test(vec3 p0, vec3 p1, vec3 p2, const DRay &ray, float *b0o, float *b1o,
-                                         float *b2o, float *to) {
-    vec3 p0t = p0 - ray.o, p1t = p1 - ray.o, p2t = p2 - ray.o;
-    int kz = max_dim(vabs(ray.d));
-    int kx = kz + 1; if (kx == 3) kx = 0;
-    int ky = kx + 1; if (ky == 3) ky = 0;
-    vec3 d(ray.d.get(kx), ray.d.get(ky), ray.d.get(kz));
-    p0t = vec3(p0t.get(kx), p0t.get(ky), p0t.get(kz));
-    p1t = vec3(p1t.get(kx), p1t.get(ky), p1t.get(kz));
-    p2t = vec3(p2t.get(kx), p2t.get(ky), p2t.get(kz));
-    float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1.f / d.z;
+// Ray-only part of the watertight test (shapes/triangle.cpp:207-221): the permutation
+// and the shear coefficients depend on the ray alone, so they are computed once per ray
+// (same operations, same values) instead of once per triangle test.
+struct RayShear { int kx, ky, kz; float Sx, Sy, Sz; };
+__device__ __forceinline__ RayShear ray_shear(vec3 rd) {
+    RayShear s;
+    s.kz = max_dim(vabs(rd));
+    s.kx = s.kz + 1; if (s.kx == 3) s.kx = 0;
+    s.ky = s.kx + 1; if (s.ky == 3) s.ky = 0;
+    const float dx = rd.get(s.kx), dy = rd.get(s.ky), dz = rd.get(s.kz);
+    s.Sx = -dx / dz; s.Sy = -dy / dz; s.Sz = 1.f / dz;
+    return s;
+}
+__device__ __forceinline__ vec3 permute3(vec3 v, int kx, int ky, int kz) {
+    // kz == 0: (y,z,x); kz == 1: (z,x,y); kz == 2: (x,y,z)
+    return kz == 0 ? vec3(v.y, v.z, v.x) : (kz == 1 ? vec3(v.z, v.x, v.y) : v);
+}
+__device__ __forceinline__ bool tri_test(vec3 p0, vec3 p1, vec3 p2, vec3 rayO, float rayTMax, const RayShear &sh, float *b0o,
+                                         float *b1o, float *b2o, float *to) {
+    vec3 p0t = p0 - rayO, p1t = p1 - rayO, p2t = p2 - rayO;
+    p0t = permute3(p0t, sh.kx, sh.ky, sh.kz);
+    p1t = permute3(p1t, sh.kx, sh.ky, sh.kz);
+    p2t = permute3(p2t, sh.kx, sh.ky, sh.kz);
+    const float Sx = sh.Sx, Sy = sh.Sy, Sz = sh.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
     p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
@@ -44,8 +57,8 @@ __device__ __forceinline__ bool tri_test(vec3 p0, vec3 p1, vec3 p2, const DRay &
     if (det == 0) return false;
     p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
     float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
-    if (det < 0 && (tScaled >= 0 || tScaled < ray.tMax * det)) return false;
-    else if (det > 0 && (tScaled <= 0 || tScaled > ray.tMax * det)) return false;
+    if (det < 0 && (tScaled >= 0 || tScaled < rayTMax * det)) return false;
+    else if (det > 0 && (tScaled <= 0 || tScaled > rayTMax * det)) return false;
     float invDet = 1 / det;
     float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
     float t = tScaled * invDet;
@@ -156,6 +169,13 @@ __device__ __noinline__ bool sphere_test(const DevSphere &s, const DRay &r, DRay
 
 struct TraceCount { unsigned int fetched, entered, tri, sphere; };
 
+// "while-while" form of the reference's single loop (accelerators/bvh.cpp:363-394):
+// every lane walks interior nodes until it reaches a leaf that passes the slab test,
+// parks it, and the wave tests the parked leaves' primitives together.  Each lane still
+// performs exactly the reference's sequence of slab tests and primitive tests (the next
+// node is fetched only after the parked leaf has been processed, so a shrunken tMax is
+// seen by every later test) — only the interleaving across lanes changes, which is what
+// keeps the 64 lanes of a wavefront on the same instruction stream.
 template <bool ANY_HIT, bool COUNT>
 __device__ __forceinline__ bool bvh_walk(const DevScene &sc, DRay &ray, int *ldsStack, int32_t *primOut, float *b0o,
                                          float *b1o, float *b2o, TraceCount &cnt) {
@@ -164,78 +184,81 @@ __device__ __forceinline__ bool bvh_walk(const DevScene &sc, DRay &ray, int *lds
     const vec3 invDir(1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z);
     const int negX = invDir.x < 0, negY = invDir.y < 0, negZ = invDir.z < 0;
     const float robust = 1 + 2 * gamma_n(3);
+    const RayShear shear = ray_shear(ray.d);
     int spill[HPRT_SPILL_STACK];
     int sp = 0, cur = 0;
     const float4 *nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
-    while (true) {
-        const float4 n0 = nodes4[2 * cur], n1 = nodes4[2 * cur + 1];   // {min.xyz,max.x} {max.yz,offset,countAxis}
-        if (COUNT) ++cnt.fetched;
-        // Bounds3::IntersectP(ray, invDir, dirIsNeg)
-        const float bminx = n0.x, bminy = n0.y, bminz = n0.z, bmaxx = n0.w, bmaxy = n1.x, bmaxz = n1.y;
-        float tMin = ((negX ? bmaxx : bminx) - ray.o.x) * invDir.x;
-        float tMax = ((negX ? bminx : bmaxx) - ray.o.x) * invDir.x;
-        float tyMin = ((negY ? bmaxy : bminy) - ray.o.y) * invDir.y;
-        float tyMax = ((negY ? bminy : bmaxy) - ray.o.y) * invDir.y;
-        tMax *= robust; tyMax *= robust;
-        bool inside = !(tMin > tyMax || tyMin > tMax);
-        if (inside) {
-            if (tyMin > tMin) tMin = tyMin;
-            if (tyMax < tMax) tMax = tyMax;
-            float tzMin = ((negZ ? bmaxz : bminz) - ray.o.z) * invDir.z;
-            float tzMax = ((negZ ? bminz : bmaxz) - ray.o.z) * invDir.z;
-            tzMax *= robust;
-            inside = !(tMin > tzMax || tzMin > tMax);
+    while (cur >= 0) {
+        uint32_t leafBegin = 0, leafEnd = 0;
+        // ---- phase 1: interior nodes until a leaf is entered or the stack runs dry ----
+        while (cur >= 0) {
+            const float4 n0 = nodes4[2 * cur], n1 = nodes4[2 * cur + 1];   // {min.xyz,max.x} {max.yz,offset,countAxis}
+            if (COUNT) ++cnt.fetched;
+            // Bounds3::IntersectP(ray, invDir, dirIsNeg), core/geometry.h:1754-1780
+            const float bminx = n0.x, bminy = n0.y, bminz = n0.z, bmaxx = n0.w, bmaxy = n1.x, bmaxz = n1.y;
+            float tMin = ((negX ? bmaxx : bminx) - ray.o.x) * invDir.x;
+            float tMax = ((negX ? bminx : bmaxx) - ray.o.x) * invDir.x;
+            float tyMin = ((negY ? bmaxy : bminy) - ray.o.y) * invDir.y;
+            float tyMax = ((negY ? bminy : bmaxy) - ray.o.y) * invDir.y;
+            tMax *= robust; tyMax *= robust;
+            bool inside = !(tMin > tyMax || tyMin > tMax);
             if (inside) {
-                if (tzMin > tMin) tMin = tzMin;
-                if (tzMax < tMax) tMax = tzMax;
-                inside = (tMin < ray.tMax) && (tMax > 0);
-            }
-        }
-        const int32_t offset = __float_as_int(n1.z);
-        const uint32_t countAxis = __float_as_uint(n1.w);
-        bool popNext = true;
-        if (inside) {
-            if (COUNT) ++cnt.entered;
-            const uint32_t axis = countAxis & 3u;
-            if (axis == 3u) {
-                const uint32_t nP = countAxis >> 2;
-                for (uint32_t i = 0; i < nP; ++i) {
-                    const uint32_t pi = (uint32_t)offset + i;
-                    const float4 v0 = sc.tris[3 * pi], v1 = sc.tris[3 * pi + 1], v2 = sc.tris[3 * pi + 2];
-                    const uint32_t tag = __float_as_uint(v0.w);
-                    if ((tag & TAG_KIND_MASK) == 0u) {
-                        if (COUNT) ++cnt.tri;
-                        float b0, b1, b2, t;
-                        if (tri_test(vec3(v0.x, v0.y, v0.z), vec3(v1.x, v1.y, v1.z), vec3(v2.x, v2.y, v2.z), ray, &b0, &b1, &b2, &t)) {
-                            if (ANY_HIT) return true;
-                            if (!(tag & TAG_BOGUS)) {       // zero-area triangles: Triangle::Intersect rejects
-                                hit = true; ray.tMax = t; *primOut = (int32_t)pi; *b0o = b0; *b1o = b1; *b2o = b2;
-                            }
-                        }
-                    } else {
-                        if (COUNT) ++cnt.sphere;
-                        DRay ro; vec3 ph; float phi, t;
-                        if (sphere_test(sc.spheres[__float_as_uint(v2.w)], ray, &ro, &ph, &phi, &t)) {
-                            if (ANY_HIT) return true;
-                            hit = true; ray.tMax = t; *primOut = (int32_t)pi; *b0o = 0.f; *b1o = 0.f; *b2o = 0.f;
-                        }
-                    }
+                if (tyMin > tMin) tMin = tyMin;
+                if (tyMax < tMax) tMax = tyMax;
+                float tzMin = ((negZ ? bmaxz : bminz) - ray.o.z) * invDir.z;
+                float tzMax = ((negZ ? bminz : bmaxz) - ray.o.z) * invDir.z;
+                tzMax *= robust;
+                inside = !(tMin > tzMax || tzMin > tMax);
+                if (inside) {
+                    if (tzMin > tMin) tMin = tzMin;
+                    if (tzMax < tMax) tMax = tzMax;
+                    inside = (tMin < ray.tMax) && (tMax > 0);
                 }
-            } else {
+            }
+            const int32_t offset = __float_as_int(n1.z);
+            const uint32_t countAxis = __float_as_uint(n1.w);
+            const uint32_t axis = countAxis & 3u;
+            if (inside && axis != 3u) {
+                if (COUNT) ++cnt.entered;
                 const int isNeg = axis == 0 ? negX : (axis == 1 ? negY : negZ);
-                int farNode, nearNode;
-                if (isNeg) { farNode = cur + 1; nearNode = offset; } else { farNode = offset; nearNode = cur + 1; }
+                const int farNode = isNeg ? cur + 1 : offset;
+                const int nearNode = isNeg ? offset : cur + 1;
                 if (sp < HPRT_LDS_STACK) ldsStack[sp * HPRT_TRACE_BLOCK] = farNode;
                 else if (sp - HPRT_LDS_STACK < HPRT_SPILL_STACK) spill[sp - HPRT_LDS_STACK] = farNode;
                 ++sp;
                 cur = nearNode;
-                popNext = false;
+                continue;
+            }
+            // leaf entered, or node missed: the next node comes off the stack
+            if (sp == 0) cur = -1;
+            else { --sp; cur = (sp < HPRT_LDS_STACK) ? ldsStack[sp * HPRT_TRACE_BLOCK] : spill[sp - HPRT_LDS_STACK]; }
+            if (inside) {
+                if (COUNT) ++cnt.entered;
+                leafBegin = (uint32_t)offset; leafEnd = (uint32_t)offset + (countAxis >> 2);
+                break;
             }
         }
-        if (popNext) {
-            if (sp == 0) break;
-            --sp;
-            cur = (sp < HPRT_LDS_STACK) ? ldsStack[sp * HPRT_TRACE_BLOCK] : spill[sp - HPRT_LDS_STACK];
+        // ---- phase 2: primitives of the parked leaf ----
+        for (uint32_t pi = leafBegin; pi < leafEnd; ++pi) {
+            const float4 v0 = sc.tris[3 * pi], v1 = sc.tris[3 * pi + 1], v2 = sc.tris[3 * pi + 2];
+            const uint32_t tag = __float_as_uint(v0.w);
+            if ((tag & TAG_KIND_MASK) == 0u) {
+                if (COUNT) ++cnt.tri;
+                float b0, b1, b2, t;
+                if (tri_test(vec3(v0.x, v0.y, v0.z), vec3(v1.x, v1.y, v1.z), vec3(v2.x, v2.y, v2.z), ray.o, ray.tMax, shear, &b0, &b1, &b2, &t)) {
+                    if (ANY_HIT) return true;
+                    if (!(tag & TAG_BOGUS)) {       // zero-area triangles: Triangle::Intersect rejects
+                        hit = true; ray.tMax = t; *primOut = (int32_t)pi; *b0o = b0; *b1o = b1; *b2o = b2;
+                    }
+                }
+            } else {
+                if (COUNT) ++cnt.sphere;
+                DRay ro; vec3 ph; float phi, t;
+                if (sphere_test(sc.spheres[__float_as_uint(v2.w)], ray, &ro, &ph, &phi, &t)) {
+                    if (ANY_HIT) return true;
+                    hit = true; ray.tMax = t; *primOut = (int32_t)pi; *b0o = 0.f; *b1o = 0.f; *b2o = 0.f;
+                }
+            }
         }
     }
     return hit;

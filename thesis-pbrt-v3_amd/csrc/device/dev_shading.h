@@ -31,7 +31,9 @@ __device__ __forceinline__ uint64_t reverse_bits64(uint64_t n) {
 }
 // RadicalInverseSpecialized<base> / ScrambledRadicalInverseSpecialized<base>
 // (core/lowdiscrepancy.cpp:389-424); perm == nullptr selects the unscrambled form.
-__device__ __forceinline__ float radical_inverse_base(uint32_t base, uint64_t M, uint64_t a, const uint16_t *perm) {
+// PermPtr is `const uint16_t *` (HBM table) or an LDS pointer (staged copy).
+template <typename PermPtr>
+__device__ __forceinline__ float radical_inverse_base(uint32_t base, uint64_t M, uint64_t a, PermPtr perm, bool scrambled) {
     const float invBase = 1.0f / (float)base;
     uint64_t reversedDigits = 0;
     float invBaseN = 1;
@@ -40,21 +42,42 @@ __device__ __forceinline__ float radical_inverse_base(uint32_t base, uint64_t M,
         if (a <= 0xffffffffull) next = div_magic32((uint32_t)a, M);
         else next = a / base;
         uint32_t digit = (uint32_t)(a - next * base);
-        reversedDigits = reversedDigits * base + (perm ? (uint32_t)perm[digit] : digit);
+        reversedDigits = reversedDigits * base + (scrambled ? (uint32_t)perm[digit] : digit);
         invBaseN *= invBase;
         a = next;
     }
     float v;
-    if (perm) v = invBaseN * ((float)reversedDigits + invBase * (float)perm[0] / (1 - invBase));
+    if (scrambled) v = invBaseN * ((float)reversedDigits + invBase * (float)perm[0] / (1 - invBase));
     else v = (float)reversedDigits * invBaseN;
     return sel_min(v, HPRT_ONE_MINUS_EPS);
 }
+// Per-block LDS copy of the tables of the first HPRT_HALTON_LDS_DIMS dimensions (digit
+// permutations: 8,893 uint16 = sum of the first 64 primes; bases; division magics).
+// A maxdepth-5 path consumes at most 5 + 6*8 = 53 dimensions, so the scattered 2-byte
+// permutation lookups of the digit loops are served from LDS instead of L2.
+#define HPRT_HALTON_LDS_DIMS 64
+#define HPRT_HALTON_LDS_PERMS 8893
+struct HaltonLds {
+    uint64_t magic[HPRT_HALTON_LDS_DIMS];
+    int32_t prime[HPRT_HALTON_LDS_DIMS];
+    int32_t primeSum[HPRT_HALTON_LDS_DIMS];
+    uint16_t perm[HPRT_HALTON_LDS_PERMS + 3];
+};
+__device__ __forceinline__ void halton_lds_load(const DevScene &sc, HaltonLds *h) {
+    for (int i = threadIdx.x; i < HPRT_HALTON_LDS_DIMS; i += blockDim.x) {
+        h->magic[i] = sc.primeMagic[i]; h->prime[i] = sc.primes[i]; h->primeSum[i] = sc.primeSums[i];
+    }
+    for (int i = threadIdx.x; i < HPRT_HALTON_LDS_PERMS; i += blockDim.x) h->perm[i] = sc.perms[i];
+    __syncthreads();
+}
 // HaltonSampler::SampleDimension, samplers/halton.cpp:119-127
-__device__ __forceinline__ float halton_dim(const DevScene &sc, const DevHalton &h, uint64_t index, int dim) {
+__device__ __forceinline__ float halton_dim(const DevScene &sc, const DevHalton &h, uint64_t index, int dim, const HaltonLds *lds = nullptr) {
     if (h.samplePixelCenter && (dim == 0 || dim == 1)) return 0.5f;
     if (dim == 0) return (float)((double)reverse_bits64(index >> h.baseExp0) * 0x1p-64);
-    if (dim == 1) return radical_inverse_base(3u, sc.primeMagic[1], index / (uint64_t)h.baseScale1, nullptr);
-    return radical_inverse_base((uint32_t)sc.primes[dim], sc.primeMagic[dim], index, sc.perms + sc.primeSums[dim]);
+    if (dim == 1) return radical_inverse_base<const uint16_t *>(3u, sc.primeMagic[1], index / (uint64_t)h.baseScale1, nullptr, false);
+    if (lds && dim < HPRT_HALTON_LDS_DIMS)
+        return radical_inverse_base<const uint16_t *>((uint32_t)lds->prime[dim], lds->magic[dim], index, lds->perm + lds->primeSum[dim], true);
+    return radical_inverse_base<const uint16_t *>((uint32_t)sc.primes[dim], sc.primeMagic[dim], index, sc.perms + sc.primeSums[dim], true);
 }
 
 // ---------------------------------------------------------------------------

@@ -54,7 +54,7 @@ struct FilmExtras {
 
 void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
                  uint32_t countImm, uint32_t gridItems, const RayPlanes &rays, const HitPlanes &hits, uint8_t *occ,
-                 DevCounters *counters);
+                 DevCounters *counters, uint32_t *workCounter);
 void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, uint32_t s0, uint32_t nSlots);
 void LaunchShade(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, const uint32_t *queue,
                  const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, uint32_t s0, const QueueSet &q);

@@ -18,6 +18,7 @@
 // Built with -ffp-contract=off: every float operation below is a single IEEE
 // rounding in the order the reference's scalar code performs it.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "dev_shading.h"
 #include "kernels.h"
 
@@ -53,30 +54,172 @@ __device__ __forceinline__ void wave_count_add(DevCounters *c, bool anyHit, cons
 }
 
 // ---------------------------------------------------------------------------
-// k_trace: one lane per ray.  queue == nullptr means "slot = thread index".
-// Rays are read from SoA planes indexed by slot; tmax == nullptr means Infinity.
-// Closest hit writes t, prim (ordered index or -1) and b0,b1,b2; any hit writes a byte.
+// k_trace: persistent wavefronts with dynamic ray fetch.
+//
+// Incoherent rays have very uneven traversal lengths (killeroo-simple bounce rays: median
+// 7 nodes, mean 25, per-64-ray maximum 78), so a one-ray-per-lane kernel keeps ~1/3 of a
+// wavefront's lanes busy.  Here a wave owns 64 lane slots for its whole life: whenever
+// fewer than HPRT_REFILL_BELOW lanes still have a ray, the idle lanes draw the next rays
+// from the queue with ONE atomic per wave (ballot + mbcnt prefix) and join the walk.
+// Each lane runs the reference's loop (accelerators/bvh.cpp:363-394) unchanged, in the
+// "while-while" arrangement: interior nodes until a leaf is entered, then the wave tests
+// its parked leaves together.  A lane fetches its next node only after its parked leaf
+// has been processed, so every later slab/primitive test sees the shrunken tMax exactly
+// as in the reference.
+//
+// queue == nullptr means "slot = ray index"; tmax == nullptr means Infinity.  Closest hit
+// writes t, prim (ordered index or -1) and b0,b1,b2; any hit writes one byte.
 // ---------------------------------------------------------------------------
+#define HPRT_REFILL_BELOW 44
+
 template <bool ANY_HIT, bool COUNT>
-__global__ __launch_bounds__(HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
+__global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayPlanes rays, HitPlanes hits, uint8_t *occ,
-                                                            DevCounters *counters) {
+                                                            DevCounters *counters, uint32_t *workCounter) {
     __shared__ int stackMem[HPRT_LDS_STACK * HPRT_TRACE_BLOCK];
+    int *const ldsStack = &stackMem[threadIdx.x];
     const uint32_t n = countPtr ? *countPtr : countImm;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = __lane_id();
+    const float4 *const nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
+    const float robust = 1 + 2 * gamma_n(3);
     TraceCount cnt = {0u, 0u, 0u, 0u};
-    if (i < n) {
-        const uint32_t slot = queue ? queue[i] : i;
-        DRay ray;
-        ray.o = vec3(rays.ox[slot], rays.oy[slot], rays.oz[slot]);
-        ray.d = vec3(rays.dx[slot], rays.dy[slot], rays.dz[slot]);
-        ray.tMax = rays.tmax ? rays.tmax[slot] : HPRT_INF;
-        int32_t prim = -1; float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-        const bool hit = bvh_walk<ANY_HIT, COUNT>(sc, ray, &stackMem[threadIdx.x], &prim, &b0, &b1, &b2, cnt);
-        if (ANY_HIT) occ[slot] = hit ? 1 : 0;
-        else {
-            hits.t[slot] = ray.tMax; hits.prim[slot] = hit ? prim : -1;
-            if (hits.b0) { hits.b0[slot] = b0; hits.b1[slot] = b1; hits.b2[slot] = b2; }
+    // per-lane ray state
+    bool active = false, hit = false;
+    uint32_t slot = 0;
+    vec3 ro, invDir;
+    float rayTMax = 0.f;
+    RayShear shear; shear.kx = shear.ky = shear.kz = 0; shear.Sx = shear.Sy = shear.Sz = 0.f;
+    int negX = 0, negY = 0, negZ = 0;
+    int sp = 0, cur = -1;
+    int32_t prim = -1; float hb0 = 0.f, hb1 = 0.f, hb2 = 0.f;
+    int spill[HPRT_SPILL_STACK];
+    bool moreWork = n > 0 && sc.nNodes > 0;
+    if (sc.nNodes == 0 && n > 0) {
+        // empty aggregate: every ray misses (accelerators/bvh.cpp:355)
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const uint32_t s = queue ? queue[i] : i;
+            if (ANY_HIT) occ[s] = 0;
+            else { hits.t[s] = rays.tmax ? rays.tmax[s] : HPRT_INF; hits.prim[s] = -1; if (hits.b0) { hits.b0[s] = 0.f; hits.b1[s] = 0.f; hits.b2[s] = 0.f; } }
+        }
+    }
+    while (true) {
+        // ---- refill idle lanes from the queue ----
+        if (moreWork) {
+            const unsigned long long idle = __ballot(!active);
+            if (idle != 0ull) {
+                const uint32_t want = (uint32_t)__popcll(idle);
+                const int leader = __ffsll((long long)idle) - 1;
+                uint32_t base = 0u;
+                if ((int)lane == leader) base = atomicAdd(workCounter, want);
+                base = __shfl(base, leader);
+                if (base + want >= n) moreWork = false;
+                if (!active) {
+                    const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    if (idx < n) {
+                        slot = queue ? queue[idx] : idx;
+                        ro = vec3(rays.ox[slot], rays.oy[slot], rays.oz[slot]);
+                        const vec3 rd(rays.dx[slot], rays.dy[slot], rays.dz[slot]);
+                        rayTMax = rays.tmax ? rays.tmax[slot] : HPRT_INF;
+                        invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
+                        negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
+                        shear = ray_shear(rd);
+                        sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
+                        active = true;
+                    }
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) break;
+        // ---- walk until too few lanes are busy (or, with the queue drained, until all are done) ----
+        while (true) {
+            uint32_t leafBegin = 0, leafEnd = 0;
+            if (active) {
+                // phase 1: interior nodes until a leaf is entered or the stack runs dry
+                while (cur >= 0) {
+                    const float4 n0 = nodes4[2 * cur], n1 = nodes4[2 * cur + 1];   // {min.xyz,max.x} {max.yz,offset,countAxis}
+                    if (COUNT) ++cnt.fetched;
+                    // Bounds3::IntersectP(ray, invDir, dirIsNeg), core/geometry.h:1754-1780
+                    const float bminx = n0.x, bminy = n0.y, bminz = n0.z, bmaxx = n0.w, bmaxy = n1.x, bmaxz = n1.y;
+                    float tMin = ((negX ? bmaxx : bminx) - ro.x) * invDir.x;
+                    float tMax = ((negX ? bminx : bmaxx) - ro.x) * invDir.x;
+                    float tyMin = ((negY ? bmaxy : bminy) - ro.y) * invDir.y;
+                    float tyMax = ((negY ? bminy : bmaxy) - ro.y) * invDir.y;
+                    tMax *= robust; tyMax *= robust;
+                    bool inside = !(tMin > tyMax || tyMin > tMax);
+                    if (inside) {
+                        if (tyMin > tMin) tMin = tyMin;
+                        if (tyMax < tMax) tMax = tyMax;
+                        float tzMin = ((negZ ? bmaxz : bminz) - ro.z) * invDir.z;
+                        float tzMax = ((negZ ? bminz : bmaxz) - ro.z) * invDir.z;
+                        tzMax *= robust;
+                        inside = !(tMin > tzMax || tzMin > tMax);
+                        if (inside) {
+                            if (tzMin > tMin) tMin = tzMin;
+                            if (tzMax < tMax) tMax = tzMax;
+                            inside = (tMin < rayTMax) && (tMax > 0);
+                        }
+                    }
+                    const int32_t offset = __float_as_int(n1.z);
+                    const uint32_t countAxis = __float_as_uint(n1.w);
+                    const uint32_t axis = countAxis & 3u;
+                    if (inside && axis != 3u) {
+                        if (COUNT) ++cnt.entered;
+                        const int isNeg = axis == 0 ? negX : (axis == 1 ? negY : negZ);
+                        const int farNode = isNeg ? cur + 1 : offset;
+                        const int nearNode = isNeg ? offset : cur + 1;
+                        if (sp < HPRT_LDS_STACK) ldsStack[sp * HPRT_TRACE_BLOCK] = farNode;
+                        else if (sp - HPRT_LDS_STACK < HPRT_SPILL_STACK) spill[sp - HPRT_LDS_STACK] = farNode;
+                        ++sp;
+                        cur = nearNode;
+                        continue;
+                    }
+                    // leaf entered, or node missed: the next node comes off the stack
+                    if (sp == 0) cur = -1;
+                    else { --sp; cur = (sp < HPRT_LDS_STACK) ? ldsStack[sp * HPRT_TRACE_BLOCK] : spill[sp - HPRT_LDS_STACK]; }
+                    if (inside) {
+                        if (COUNT) ++cnt.entered;
+                        leafBegin = (uint32_t)offset; leafEnd = (uint32_t)offset + (countAxis >> 2);
+                        break;
+                    }
+                }
+            }
+            // phase 2: primitives of the parked leaves
+            bool done = false;
+            if (active) {
+                for (uint32_t pi = leafBegin; pi < leafEnd; ++pi) {
+                    const float4 v0 = sc.tris[3 * pi], v1 = sc.tris[3 * pi + 1], v2 = sc.tris[3 * pi + 2];
+                    const uint32_t tag = __float_as_uint(v0.w);
+                    if ((tag & TAG_KIND_MASK) == 0u) {
+                        if (COUNT) ++cnt.tri;
+                        float b0, b1, b2, t;
+                        if (tri_test(vec3(v0.x, v0.y, v0.z), vec3(v1.x, v1.y, v1.z), vec3(v2.x, v2.y, v2.z), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
+                            if (ANY_HIT) { hit = true; break; }
+                            if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = b0; hb1 = b1; hb2 = b2; }
+                        }
+                    } else {
+                        if (COUNT) ++cnt.sphere;
+                        DRay rr; rr.o = ro; rr.tMax = rayTMax;
+                        rr.d = vec3(rays.dx[slot], rays.dy[slot], rays.dz[slot]);
+                        DRay robj; vec3 ph; float phi, t;
+                        if (sphere_test(sc.spheres[__float_as_uint(v2.w)], rr, &robj, &ph, &phi, &t)) {
+                            if (ANY_HIT) { hit = true; break; }
+                            hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = 0.f; hb1 = 0.f; hb2 = 0.f;
+                        }
+                    }
+                }
+                done = (cur < 0) || (ANY_HIT && hit);
+                if (done) {
+                    if (ANY_HIT) occ[slot] = hit ? 1 : 0;
+                    else {
+                        hits.t[slot] = rayTMax; hits.prim[slot] = hit ? prim : -1;
+                        if (hits.b0) { hits.b0[slot] = hb0; hits.b1[slot] = hb1; hits.b2[slot] = hb2; }
+                    }
+                    active = false;
+                }
+            }
+            const int busy = __popcll(__ballot(active));
+            if (busy == 0) break;
+            if (moreWork && busy < HPRT_REFILL_BELOW) break;
         }
     }
     if (COUNT) wave_count_add(counters, ANY_HIT, cnt);
@@ -113,6 +256,8 @@ __global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_shade(DevScene sc, RenderParams rp, PathPlanes ps, const uint32_t *queue,
                                                const uint32_t *countPtr, uint32_t countImm, uint32_t s0, QueueSet q) {
+    __shared__ HaltonLds hl;
+    halton_lds_load(sc, &hl);
     const uint32_t n = countPtr ? *countPtr : countImm;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool wantNext = false, wantShadow = false, wantMis = false, wantResolve = false;
@@ -157,11 +302,11 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RenderParams rp, Pat
             // ---- direct lighting (UniformSampleOneLight + EstimateDirect) ----
             if (bsdf_num(bsdf, BX_ALL & ~BX_SPECULAR) > 0 && sc.nLights > 0) {
                 float pickPdf;
-                const int lightNum = light_pick(sc, halton_dim(sc, rp.hal, index, dim), &pickPdf);
+                const int lightNum = light_pick(sc, halton_dim(sc, rp.hal, index, dim, &hl), &pickPdf);
                 dim += 1;
                 if (pickPdf != 0) {
-                    const float ul0 = halton_dim(sc, rp.hal, index, dim), ul1 = halton_dim(sc, rp.hal, index, dim + 1);
-                    const float us0 = halton_dim(sc, rp.hal, index, dim + 2), us1 = halton_dim(sc, rp.hal, index, dim + 3);
+                    const float ul0 = halton_dim(sc, rp.hal, index, dim, &hl), ul1 = halton_dim(sc, rp.hal, index, dim + 1, &hl);
+                    const float us0 = halton_dim(sc, rp.hal, index, dim + 2, &hl), us1 = halton_dim(sc, rp.hal, index, dim + 3, &hl);
                     dim += 4;
                     const DevLight light = sc.lights[lightNum];
                     const int flagsNS = BX_ALL & ~BX_SPECULAR;
@@ -218,7 +363,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RenderParams rp, Pat
                 }
             }
             // ---- sample the BSDF for the next path segment (path.cpp:141-164) ----
-            const float ub0 = halton_dim(sc, rp.hal, index, dim), ub1 = halton_dim(sc, rp.hal, index, dim + 1);
+            const float ub0 = halton_dim(sc, rp.hal, index, dim, &hl), ub1 = halton_dim(sc, rp.hal, index, dim + 1, &hl);
             dim += 2;
             vec3 wo = -rayD, wi;
             float pdf = 0; int flags = 0;
@@ -231,7 +376,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RenderParams rp, Pat
                 rgb rrBeta = beta * 1.0f;
                 if (max_value(rrBeta) < rp.rrThreshold && bounces > 3) {
                     float qv = sel_max(.05f, 1 - max_value(rrBeta));
-                    float u = halton_dim(sc, rp.hal, index, dim);
+                    float u = halton_dim(sc, rp.hal, index, dim, &hl);
                     dim += 1;
                     if (u < qv) alive = false;
                     else beta = beta / (1 - qv);
@@ -415,15 +560,18 @@ static inline uint32_t blocks_for(size_t n, uint32_t bs) { return (uint32_t)((n 
 
 void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
                  uint32_t countImm, uint32_t gridItems, const RayPlanes &rays, const HitPlanes &hits, uint8_t *occ,
-                 DevCounters *counters) {
+                 DevCounters *counters, uint32_t *workCounter) {
     if (gridItems == 0) return;
-    dim3 grid(blocks_for(gridItems, HPRT_TRACE_BLOCK)), block(HPRT_TRACE_BLOCK);
+    (void)hipMemsetAsync(workCounter, 0, sizeof(uint32_t), st);
+    // persistent waves: enough blocks to fill 256 CUs at this kernel's occupancy, never more than the rays need
+    const uint32_t maxBlocks = 256u * 5u;
+    dim3 grid(std::min(blocks_for(gridItems, HPRT_TRACE_BLOCK), maxBlocks)), block(HPRT_TRACE_BLOCK);
     if (anyHit) {
-        if (count) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters);
-        else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters);
+        if (count) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter);
+        else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter);
     } else {
-        if (count) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters);
-        else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters);
+        if (count) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter);
+        else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter);
     }
 }
 void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, uint32_t s0, uint32_t nSlots) {
