@@ -89,6 +89,24 @@ void orc_intersect_work(void *h, size_t n, const float *o, const float *d, const
         nodes[i] = (uint32_t)ctr.nodesFetched; prims[i] = (uint32_t)(ctr.triTests + ctr.sphereTests);
     }
 }
+// Per-ray fetch traces, concatenated; offsets[n+1] (study aid for SIMT scheduling)
+size_t orc_intersect_trace(void *h, size_t n, const float *o, const float *d, const float *tmax, uint8_t *trace, size_t cap, uint64_t *offsets) {
+    Renderer *r = (Renderer *)h;
+    std::vector<uint8_t> tr;
+    r->bvh.fetchTrace = &tr;
+    size_t pos = 0;
+    for (size_t i = 0; i < n; ++i) {
+        tr.clear();
+        Counters ctr; SurfaceInteraction si;
+        Ray ray(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]);
+        r->bvh.Intersect(ray, &si, ctr);
+        offsets[i] = pos;
+        for (uint8_t v : tr) { if (pos < cap) trace[pos] = v; ++pos; }
+    }
+    offsets[n] = pos;
+    r->bvh.fetchTrace = nullptr;
+    return pos;
+}
 // Same, also returning the SurfaceInteraction fill (p, pError, n, shading.n, shading.dpdu)
 void orc_intersect_full(void *h, size_t n, const float *o, const float *d, const float *tmax, float *t,
                         int32_t *prim, float *si15) {

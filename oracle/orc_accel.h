@@ -574,6 +574,8 @@ struct BVH {
     }
 
     // accelerators/bvh.cpp:354-396
+    // optional per-fetch trace (0 = node step without entering a leaf, k = leaf entered with k prims); study aid
+    mutable std::vector<uint8_t> *fetchTrace = nullptr;
     bool Intersect(const Ray &ray, SurfaceInteraction *isect, Counters &ctr, int *orderedHit = nullptr) const {
         if (nodes.empty()) return false;
         bool hit = false;
@@ -584,7 +586,9 @@ struct BVH {
         while (true) {
             const LinearBVHNode *node = &nodes[currentNodeIndex];
             ++ctr.nodesFetched;
-            if (SlabTest(node, ray, invDir, dirIsNeg)) {
+            const bool slabHit = SlabTest(node, ray, invDir, dirIsNeg);
+            if (fetchTrace) fetchTrace->push_back((slabHit && node->IsLeaf()) ? (uint8_t)node->nPrimitives() : (uint8_t)0);
+            if (slabHit) {
                 ++ctr.nodesEntered;
                 if (node->IsLeaf()) {
                     for (uint32_t i = 0; i < node->nPrimitives(); ++i)

@@ -508,7 +508,7 @@ struct BatchTimers { double extendMs = 0, occludedMs = 0; uint64_t extendLaunche
 
 // Runs the bounce loop for one batch of nSlots freshly generated paths.
 int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const PathPlanes &ps, const QueueSet &qa, const QueueSet &qb,
-             uint32_t s0, uint32_t nSlots, bool count, EventTimer &ev, BatchTimers *bt, HprtRenderStats *stats) {
+             const BinSet &bins, uint32_t s0, uint32_t nSlots, bool count, EventTimer &ev, BatchTimers *bt, HprtRenderStats *stats) {
     LaunchGenerate(st, s->dev, rp, ps, s0, nSlots);
     const uint32_t *activeQ = nullptr; uint32_t active = nSlots;
     QueueSet q[2] = {qa, qb};
@@ -523,7 +523,11 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const PathPla
         evExt.push_back({e0, e1}); bt->extendRays += active; ++bt->extendLaunches;
         stats->rays += active;
         HIP_TRY(hipMemsetAsync(cur.nextCount, 0, 4 * sizeof(uint32_t), st));   // the four counters are contiguous
-        LaunchShade(st, s->dev, rp, ps, activeQ, nullptr, active, active, s0, cur);
+        HIP_TRY(hipMemsetAsync(bins.count, 0, 4 * sizeof(uint32_t), st));
+        LaunchBin(st, s->dev, ps, activeQ, nullptr, active, active, rp.maxDepth, bins);
+        // one launch per material bin; grids are sized for the upper bound, surplus blocks exit on *count
+        for (int mode = 0; mode < 3; ++mode)
+            LaunchShade(st, mode, s->dev, rp, ps, bins.q[mode], bins.count + mode, 0, active, s0, cur, bins);
         HIP_TRY(hipMemcpyAsync(s->hostCounts, cur.nextCount, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const uint32_t nNext = s->hostCounts[0], nShadow = s->hostCounts[1], nMis = s->hostCounts[2], nResolve = s->hostCounts[3];
@@ -556,10 +560,10 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const PathPla
     return HPRT_OK;
 }
 
-int EnsureWorkspace(HprtScene *s, size_t nSlots, PathPlanes *ps, QueueSet *qa, QueueSet *qb) {
+int EnsureWorkspace(HprtScene *s, size_t nSlots, PathPlanes *ps, QueueSet *qa, QueueSet *qb, BinSet *bins) {
     HIP_TRY(s->planes.alloc(PlaneBytes(nSlots)));
     CarvePlanes(s->planes.as<char>(), nSlots, ps);
-    HIP_TRY(s->queues.alloc(8 * nSlots * sizeof(uint32_t) + 4096));
+    HIP_TRY(s->queues.alloc(11 * nSlots * sizeof(uint32_t) + 4096));
     HIP_TRY(s->queueCounts.alloc(64 * sizeof(uint32_t)));
     uint32_t *qbase = s->queues.as<uint32_t>(), *cbase = s->queueCounts.as<uint32_t>();
     QueueSet *qs[2] = {qa, qb};
@@ -568,6 +572,8 @@ int EnsureWorkspace(HprtScene *s, size_t nSlots, PathPlanes *ps, QueueSet *qa, Q
         qs[k]->mis = qbase + (4 * k + 2) * nSlots; qs[k]->resolve = qbase + (4 * k + 3) * nSlots;
         qs[k]->nextCount = cbase + 16 * k; qs[k]->shadowCount = cbase + 16 * k + 1; qs[k]->misCount = cbase + 16 * k + 2; qs[k]->resolveCount = cbase + 16 * k + 3;
     }
+    for (int k = 0; k < 3; ++k) bins->q[k] = qbase + (8 + k) * nSlots;
+    bins->count = cbase + 32;
     return HPRT_OK;
 }
 
@@ -608,8 +614,8 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     chunk = std::min(chunk, spp);
     if ((uint64_t)chunk * nPix > 0x7fffffffull) chunk = (uint32_t)(0x7fffffffull / nPix);
     const size_t maxSlots = (size_t)chunk * nPix;
-    PathPlanes ps; QueueSet qa, qb;
-    rc = EnsureWorkspace(s, maxSlots, &ps, &qa, &qb);
+    PathPlanes ps; QueueSet qa, qb; BinSet bins;
+    rc = EnsureWorkspace(s, maxSlots, &ps, &qa, &qb, &bins);
     if (rc != HPRT_OK) return rc;
     HIP_TRY(s->Lall.alloc(lallBytes));
     float *LallR = s->Lall.as<float>(), *LallG = LallR + (size_t)spp * nPix, *LallB = LallG + (size_t)spp * nPix;
@@ -694,7 +700,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     EventTimer ev; BatchTimers bt;
     for (uint32_t s0 = 0; s0 < spp; s0 += chunk) {
         const uint32_t c = std::min(chunk, spp - s0), nSlots = c * nPix;
-        rc = RunBatch(s, st, rp, ps, qa, qb, s0, nSlots, count, ev, &bt, stats);
+        rc = RunBatch(s, st, rp, ps, qa, qb, bins, s0, nSlots, count, ev, &bt, stats);
         if (rc != HPRT_OK) return rc;
         LaunchStoreRadiance(st, ps, LallR, LallG, LallB, nPix, s0, nSlots);
     }
@@ -740,8 +746,8 @@ int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, c
         xy[i] = (uint32_t)px[i] | ((uint32_t)py[i] << 16);
         off[i] = (uint64_t)HaltonPixelOffset(f.hal, px[i], py[i]) + (uint64_t)sample[i] * (uint64_t)f.hal.sampleStride;
     }
-    PathPlanes ps; QueueSet qa, qb;
-    rc = EnsureWorkspace(s, n, &ps, &qa, &qb);
+    PathPlanes ps; QueueSet qa, qb; BinSet bins;
+    rc = EnsureWorkspace(s, n, &ps, &qa, &qb, &bins);
     if (rc != HPRT_OK) return rc;
     HIP_TRY(upload(s->pixelXY, xy)); HIP_TRY(upload(s->pixelOffset, off));
     HIP_TRY(s->Lall.alloc(12 * n));
@@ -752,7 +758,7 @@ int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, c
     rp.pixelXY = s->pixelXY.as<uint32_t>(); rp.pixelOffset = s->pixelOffset.as<uint64_t>(); rp.nPix = (uint32_t)n;
     rp.maxDepth = opt->max_depth; rp.rrThreshold = opt->rr_threshold;
     EventTimer ev; BatchTimers bt; HprtRenderStats stats; memset(&stats, 0, sizeof(stats));
-    rc = RunBatch(s, nullptr, rp, ps, qa, qb, 0, (uint32_t)n, false, ev, &bt, &stats);
+    rc = RunBatch(s, nullptr, rp, ps, qa, qb, bins, 0, (uint32_t)n, false, ev, &bt, &stats);
     if (rc != HPRT_OK) return rc;
     float *LR = s->Lall.as<float>();
     LaunchStoreRadiance(nullptr, ps, LR, LR + n, LR + 2 * n, (uint32_t)n, 0, (uint32_t)n);

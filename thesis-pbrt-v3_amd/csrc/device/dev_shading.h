@@ -226,12 +226,12 @@ __device__ __noinline__ bool fill_sphere(const DevScene &sc, int shapeId, const 
 // ---------------------------------------------------------------------------
 enum : int { BX_REFLECTION = 1, BX_TRANSMISSION = 2, BX_DIFFUSE = 4, BX_GLOSSY = 8, BX_SPECULAR = 16, BX_ALL = 31 };
 
+// No arrays here on purpose: a run-time-indexed member array would live in scratch memory.
 struct DevBsdf {
     vec3 ns, ng, ss, ts;
-    int nLobes;            // 0..2
-    int kind[2];           // 0 lambert, 1 microfacet
-    rgb R[2];
-    float alpha;           // microfacet lobe
+    rgb Rd, Rs;            // Lambertian reflectance (lobe 0 when present), microfacet reflectance (the following lobe)
+    float alpha;           // Trowbridge-Reitz alpha of the microfacet lobe
+    bool hasD, hasS;
 };
 __device__ __forceinline__ float cos_theta(vec3 w) { return w.z; }
 __device__ __forceinline__ float cos2_theta(vec3 w) { return w.z * w.z; }
@@ -319,55 +319,38 @@ __device__ __forceinline__ vec3 tr_sample_wh(float a, vec3 wo, float u0, float u
     return wh;
 }
 
-__device__ __forceinline__ int lobe_type(int kind) { return kind == 0 ? (BX_REFLECTION | BX_DIFFUSE) : (BX_REFLECTION | BX_GLOSSY); }
-__device__ __forceinline__ bool lobe_matches(int kind, int flags) { int t = lobe_type(kind); return (t & flags) == t; }
-
-__device__ __forceinline__ rgb lobe_f(const DevBsdf &b, int i, vec3 wo, vec3 wi) {
-    if (b.kind[i] == 0) return b.R[i] * HPRT_INV_PI;
+// LambertianReflection (core/reflection.cpp:178-180) with BxDF::Sample_f / BxDF::Pdf (:378-389)
+__device__ __forceinline__ rgb lambert_f(const DevBsdf &b) { return b.Rd * HPRT_INV_PI; }
+__device__ __forceinline__ float lambert_pdf(vec3 wo, vec3 wi) { return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * HPRT_INV_PI : 0; }
+// MicrofacetReflection::f / Pdf (core/reflection.cpp:226-236, 416-420), FresnelDielectric(1.5, 1)
+__device__ __forceinline__ rgb mf_f(const DevBsdf &b, vec3 wo, vec3 wi) {
     float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
     vec3 wh = wi + wo;
     if (cosThetaI == 0 || cosThetaO == 0) return rgb(0.f);
     if (wh.x == 0 && wh.y == 0 && wh.z == 0) return rgb(0.f);
     wh = normalize(wh);
     rgb F(fr_dielectric(dot(wi, wh), 1.5f, 1.f));
-    return b.R[i] * tr_D(b.alpha, wh) * tr_G(b.alpha, wo, wi) * F / (4 * cosThetaI * cosThetaO);
+    return b.Rs * tr_D(b.alpha, wh) * tr_G(b.alpha, wo, wi) * F / (4 * cosThetaI * cosThetaO);
 }
-__device__ __forceinline__ float lobe_pdf(const DevBsdf &b, int i, vec3 wo, vec3 wi) {
-    if (b.kind[i] == 0) return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * HPRT_INV_PI : 0;
+__device__ __forceinline__ float mf_pdf(const DevBsdf &b, vec3 wo, vec3 wi) {
     if (!same_hemisphere(wo, wi)) return 0;
     vec3 wh = normalize(wo + wi);
     return tr_pdf(b.alpha, wo, wh) / (4 * dot(wo, wh));
 }
-// BxDF::Sample_f (cosine) / MicrofacetReflection::Sample_f.  *pdf untouched when 0 is
-// returned early, like the reference.
-__device__ __forceinline__ rgb lobe_sample(const DevBsdf &b, int i, vec3 wo, vec3 *wi, float u0, float u1, float *pdf) {
-    if (b.kind[i] == 0) {
-        float dx, dy; concentric_disk(u0, u1, &dx, &dy);
-        float z = sqrtf(sel_max(0.f, 1 - dx * dx - dy * dy));
-        *wi = vec3(dx, dy, z);
-        if (wo.z < 0) wi->z *= -1;
-        *pdf = lobe_pdf(b, i, wo, *wi);
-        return lobe_f(b, i, wo, *wi);
-    }
-    if (wo.z == 0) return rgb(0.f);
-    vec3 wh = tr_sample_wh(b.alpha, wo, u0, u1);
-    *wi = -wo + 2 * dot(wo, wh) * wh;
-    if (!same_hemisphere(wo, *wi)) return rgb(0.f);
-    *pdf = tr_pdf(b.alpha, wo, wh) / (4 * dot(wo, wh));
-    return lobe_f(b, i, wo, *wi);
-}
 
+// materials/matte.cpp:45-62, materials/plastic.cpp:45-70: lobes are added in the order
+// diffuse, specular; a black reflectance adds no lobe.
 __device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, DevBsdf *b) {
     b->ns = si.ns; b->ng = si.n;
     b->ss = normalize(si.sdpdu);
     b->ts = cross(b->ns, b->ss);
-    b->nLobes = 0; b->alpha = 0;
+    b->alpha = 0; b->hasD = false; b->hasS = false; b->Rd = rgb(0.f); b->Rs = rgb(0.f);
     const DevMaterial m = sc.materials[sc.shapes[si.shape].material];
     rgb kd = clamp0(rgb(m.Kd[0], m.Kd[1], m.Kd[2]));
-    if (!is_black(kd)) { b->kind[b->nLobes] = 0; b->R[b->nLobes] = kd; ++b->nLobes; }
+    if (!is_black(kd)) { b->hasD = true; b->Rd = kd; }
     if (m.type == 1) {
         rgb ks = clamp0(rgb(m.Ks[0], m.Ks[1], m.Ks[2]));
-        if (!is_black(ks)) { b->kind[b->nLobes] = 1; b->R[b->nLobes] = ks; b->alpha = m.alpha; ++b->nLobes; }
+        if (!is_black(ks)) { b->hasS = true; b->Rs = ks; b->alpha = m.alpha; }
     }
 }
 __device__ __forceinline__ vec3 to_local(const DevBsdf &b, vec3 v) { return vec3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
@@ -375,56 +358,62 @@ __device__ __forceinline__ vec3 to_world(const DevBsdf &b, vec3 v) {
     return vec3(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
                 b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
 }
-__device__ __forceinline__ int bsdf_num(const DevBsdf &b, int flags) {
-    int n = 0;
-    for (int i = 0; i < 2; ++i) if (i < b.nLobes && lobe_matches(b.kind[i], flags)) ++n;
-    return n;
-}
+// Both lobe types (REFLECTION|DIFFUSE, REFLECTION|GLOSSY) match BSDF_ALL and
+// BSDF_ALL & ~BSDF_SPECULAR, the only flag sets PathIntegrator passes (path.cpp:129,144;
+// integrator.cpp:114), so NumComponents(flags) is the lobe count.
+__device__ __forceinline__ int bsdf_num(const DevBsdf &b) { return (b.hasD ? 1 : 0) + (b.hasS ? 1 : 0); }
 // BSDF::f, core/reflection.cpp:670-684 (all lobes here are reflective)
-__device__ __forceinline__ rgb bsdf_f(const DevBsdf &b, vec3 woW, vec3 wiW, int flags) {
+__device__ __forceinline__ rgb bsdf_f(const DevBsdf &b, vec3 woW, vec3 wiW) {
     vec3 wi = to_local(b, wiW), wo = to_local(b, woW);
     if (wo.z == 0) return rgb(0.f);
     bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
     rgb f(0.f);
-    for (int i = 0; i < 2; ++i)
-        if (i < b.nLobes && lobe_matches(b.kind[i], flags) && reflect) f = f + lobe_f(b, i, wo, wi);
+    if (b.hasD && reflect) f = f + lambert_f(b);
+    if (b.hasS && reflect) f = f + mf_f(b, wo, wi);
     return f;
 }
 // BSDF::Pdf, core/reflection.cpp:764-778
-__device__ __forceinline__ float bsdf_pdf(const DevBsdf &b, vec3 woW, vec3 wiW, int flags) {
-    if (b.nLobes == 0) return 0.f;
+__device__ __forceinline__ float bsdf_pdf(const DevBsdf &b, vec3 woW, vec3 wiW) {
+    const int matching = bsdf_num(b);
+    if (matching == 0) return 0.f;
     vec3 wo = to_local(b, woW), wi = to_local(b, wiW);
     if (wo.z == 0) return 0.f;
-    float pdf = 0.f; int matching = 0;
-    for (int i = 0; i < 2; ++i)
-        if (i < b.nLobes && lobe_matches(b.kind[i], flags)) { ++matching; pdf += lobe_pdf(b, i, wo, wi); }
-    return matching > 0 ? pdf / matching : 0.f;
+    float pdf = 0.f;
+    if (b.hasD) pdf += lambert_pdf(wo, wi);
+    if (b.hasS) pdf += mf_pdf(b, wo, wi);
+    return pdf / matching;
 }
 // BSDF::Sample_f, core/reflection.cpp:703-762.  *pdf keeps its incoming value on the
 // "wo.z == 0" early return, as in the reference.
-__device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW, float u0, float u1, float *pdf, int flags, int *sampledType) {
-    int matching = bsdf_num(b, flags);
+__device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW, float u0, float u1, float *pdf, int *sampledType) {
+    const int matching = bsdf_num(b);
     if (matching == 0) { *pdf = 0; *sampledType = 0; return rgb(0.f); }
-    int comp = sel_min((int)floorf(u0 * matching), matching - 1);
-    int chosen = -1, count = comp;
-    for (int i = 0; i < 2; ++i)
-        if (chosen < 0 && i < b.nLobes && lobe_matches(b.kind[i], flags) && count-- == 0) chosen = i;
-    float ur0 = sel_min(u0 * matching - comp, HPRT_ONE_MINUS_EPS);
+    const int comp = sel_min((int)floorf(u0 * matching), matching - 1);
+    const bool pickSpec = (matching == 2) ? (comp == 1) : b.hasS;
+    const float ur0 = sel_min(u0 * matching - comp, HPRT_ONE_MINUS_EPS);
     vec3 wi, wo = to_local(b, woW);
     if (wo.z == 0) return rgb(0.f);
     *pdf = 0;
-    *sampledType = lobe_type(b.kind[chosen]);
-    rgb f = lobe_sample(b, chosen, wo, &wi, ur0, u1, pdf);
+    *sampledType = pickSpec ? (BX_REFLECTION | BX_GLOSSY) : (BX_REFLECTION | BX_DIFFUSE);
+    if (!pickSpec) {      // BxDF::Sample_f: cosine-weighted hemisphere
+        float dx, dy; concentric_disk(ur0, u1, &dx, &dy);
+        float z = sqrtf(sel_max(0.f, 1 - dx * dx - dy * dy));
+        wi = vec3(dx, dy, z);
+        if (wo.z < 0) wi.z *= -1;
+        *pdf = lambert_pdf(wo, wi);
+    } else {              // MicrofacetReflection::Sample_f, core/reflection.cpp:402-414 (wo.z != 0 here)
+        vec3 wh = tr_sample_wh(b.alpha, wo, ur0, u1);
+        wi = -wo + 2 * dot(wo, wh) * wh;
+        if (same_hemisphere(wo, wi)) *pdf = tr_pdf(b.alpha, wo, wh) / (4 * dot(wo, wh));
+    }
     if (*pdf == 0) { *sampledType = 0; return rgb(0.f); }
     *wiW = to_world(b, wi);
-    if (matching > 1)
-        for (int i = 0; i < 2; ++i)
-            if (i != chosen && i < b.nLobes && lobe_matches(b.kind[i], flags)) *pdf += lobe_pdf(b, i, wo, wi);
+    if (matching > 1) *pdf += pickSpec ? lambert_pdf(wo, wi) : mf_pdf(b, wo, wi);
     if (matching > 1) *pdf /= matching;
     bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
-    f = rgb(0.f);
-    for (int i = 0; i < 2; ++i)
-        if (i < b.nLobes && lobe_matches(b.kind[i], flags) && reflect) f = f + lobe_f(b, i, wo, wi);
+    rgb f(0.f);
+    if (b.hasD && reflect) f = f + lambert_f(b);
+    if (b.hasS && reflect) f = f + mf_f(b, wo, wi);
     return f;
 }
 
@@ -451,11 +440,19 @@ __device__ __forceinline__ DevIt sphere_sample_area(const DevSphere &s, bool rev
     *pdf = 1 / (s.phiMax * s.radius * (s.zMax - s.zMin));
     return it;
 }
-// Sphere::Sample(ref, u) (shapes/sphere.cpp:232-292)
-__device__ __noinline__ DevIt sphere_sample(const DevSphere &s, bool reverse, const DevIt &ref, float u0, float u1, float *pdf) {
+// The "reference point inside the sphere" test shared by Sphere::Sample(ref,u) and
+// Sphere::Pdf (shapes/sphere.cpp:236-239, 297-300): same operands, same result.
+__device__ __forceinline__ bool sphere_ref_inside(const DevSphere &s, const DevIt &ref) {
     vec3 pCenter = xf_point(s.o2w, vec3(0, 0, 0));
     vec3 pOrigin = offset_ray_origin(ref.p, ref.pErr, ref.n, pCenter - ref.p);
-    if (dist2(pOrigin, pCenter) <= s.radius * s.radius) {
+    return dist2(pOrigin, pCenter) <= s.radius * s.radius;
+}
+// Sphere::Sample(ref, u) (shapes/sphere.cpp:232-292).  INSIDE_POSSIBLE = false is used by
+// callers that have already established sphere_ref_inside() == false.
+template <bool INSIDE_POSSIBLE>
+__device__ __forceinline__ DevIt sphere_sample(const DevSphere &s, bool reverse, const DevIt &ref, float u0, float u1, float *pdf) {
+    vec3 pCenter = xf_point(s.o2w, vec3(0, 0, 0));
+    if (INSIDE_POSSIBLE && sphere_ref_inside(s, ref)) {
         DevIt intr = sphere_sample_area(s, reverse, u0, u1, pdf);
         vec3 wi = intr.p - ref.p;
         if (length2(wi) == 0) *pdf = 0;
@@ -488,6 +485,7 @@ __device__ __forceinline__ rgb area_L(const DevLight &l, vec3 n, vec3 w) {   // 
     return (l.twoSided || dot(n, w) > 0) ? rgb(l.I[0], l.I[1], l.I[2]) : rgb(0.f);
 }
 // Light::Sample_Li (lights/point.cpp:44-53, distant.cpp:49-59, diffuse.cpp:68-81)
+template <bool INSIDE_POSSIBLE>
 __device__ __forceinline__ rgb light_sample(const DevScene &sc, const DevLight &l, const DevIt &ref, float u0, float u1, vec3 *wi,
                                             float *pdf, DevIt *pLight) {
     vec3 lp(l.pos[0], l.pos[1], l.pos[2]);
@@ -502,7 +500,7 @@ __device__ __forceinline__ rgb light_sample(const DevScene &sc, const DevLight &
         pLight->p = ref.p + lp * (2 * sc.worldRadius); pLight->pErr = vec3(); pLight->n = vec3();
         return rgb(l.I[0], l.I[1], l.I[2]);
     }
-    DevIt ps = sphere_sample(sc.spheres[l.sphere], (l.shapeFlags & SHAPE_REVERSE) != 0, ref, u0, u1, pdf);
+    DevIt ps = sphere_sample<INSIDE_POSSIBLE>(sc.spheres[l.sphere], (l.shapeFlags & SHAPE_REVERSE) != 0, ref, u0, u1, pdf);
     if (*pdf == 0 || length2(ps.p - ref.p) == 0) { *pdf = 0; return rgb(0.f); }
     *wi = normalize(ps.p - ref.p);
     *pLight = ps;
@@ -510,12 +508,12 @@ __device__ __forceinline__ rgb light_sample(const DevScene &sc, const DevLight &
 }
 // Light::Pdf_Li for area lights = Sphere::Pdf (shapes/sphere.cpp:294-306; inside case
 // Shape::Pdf, core/shape.cpp:72-88)
-__device__ __noinline__ float light_pdf(const DevScene &sc, const DevLight &l, const DevIt &ref, vec3 wi) {
+template <bool INSIDE_POSSIBLE>
+__device__ __forceinline__ float light_pdf(const DevScene &sc, const DevLight &l, const DevIt &ref, vec3 wi) {
     if (l.type != 2) return 0;
     const DevSphere &s = sc.spheres[l.sphere];
     vec3 pCenter = xf_point(s.o2w, vec3(0, 0, 0));
-    vec3 pOrigin = offset_ray_origin(ref.p, ref.pErr, ref.n, pCenter - ref.p);
-    if (dist2(pOrigin, pCenter) <= s.radius * s.radius) {
+    if (INSIDE_POSSIBLE && sphere_ref_inside(s, ref)) {
         DRay ray; ray.o = offset_ray_origin(ref.p, ref.pErr, ref.n, wi); ray.d = wi; ray.tMax = HPRT_INF;
         DevSI isl; float tHit;
         if (!fill_sphere(sc, l.shape, ray, &isl, &tHit)) return 0;

@@ -26,6 +26,7 @@ struct QueueSet {
     uint32_t *next, *shadow, *mis, *resolve;
     uint32_t *nextCount, *shadowCount, *misCount, *resolveCount;
 };
+struct BinSet { uint32_t *q[3]; uint32_t *count; };   // material bins: 0 matte, 1 plastic, 2 generic (count[3])
 struct RenderParams {
     DevCamera cam;
     DevHalton hal;
@@ -56,8 +57,10 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
                  uint32_t countImm, uint32_t gridItems, const RayPlanes &rays, const HitPlanes &hits, uint8_t *occ,
                  DevCounters *counters, uint32_t *workCounter);
 void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, uint32_t s0, uint32_t nSlots);
-void LaunchShade(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, const uint32_t *queue,
-                 const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, uint32_t s0, const QueueSet &q);
+void LaunchBin(hipStream_t st, const DevScene &sc, const PathPlanes &ps, const uint32_t *queue, const uint32_t *countPtr,
+               uint32_t countImm, uint32_t gridItems, int32_t maxDepth, const BinSet &bins);
+void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, const uint32_t *queue,
+                 const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, uint32_t s0, const QueueSet &q, const BinSet &bins);
 void LaunchResolve(hipStream_t st, const DevScene &sc, const PathPlanes &ps, const uint32_t *queue, const uint32_t *countPtr,
                    uint32_t gridItems);
 void LaunchStoreRadiance(hipStream_t st, const PathPlanes &ps, float *LallR, float *LallG, float *LallB, uint32_t nPix, uint32_t s0,

@@ -19,6 +19,8 @@
 // rounding in the order the reference's scalar code performs it.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include "dev_shading.h"
 #include "kernels.h"
 
@@ -37,6 +39,35 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool pred) {
     if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
     base = __shfl(base, leader);
     return base + prefix;
+}
+
+// Block-level queue append for up to four queues at once.  Global atomics on ONE address
+// retire at only ~90 per microsecond on this chip, so appends are aggregated over the
+// whole workgroup: ballots per wave, a 16-entry scan in LDS, then one atomic per queue and
+// workgroup (1024 lanes) instead of one per wave.  Must be called by every thread of the
+// block in uniform control flow.  pos[k] is valid where pred[k] is set.
+struct BlockAppendLds { uint32_t waveCount[4][16]; uint32_t base[4]; };
+template <int NQ>
+__device__ __forceinline__ void block_append(BlockAppendLds *lds, uint32_t *const counter[NQ], const bool pred[NQ], uint32_t pos[NQ]) {
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63) >> 6;
+    unsigned long long mask[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        mask[k] = __ballot(pred[k]);
+        if (lane == 0) lds->waveCount[k][wave] = (uint32_t)__popcll(mask[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        const int k = threadIdx.x;
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < nWaves; ++w) { const uint32_t c = lds->waveCount[k][w]; lds->waveCount[k][w] = total; total += c; }
+        lds->base[k] = total ? atomicAdd(counter[k], total) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+        pos[k] = lds->base[k] + lds->waveCount[k][wave] +
+                 __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[k], 0u));
 }
 
 __device__ __forceinline__ void wave_count_add(DevCounters *c, bool anyHit, const TraceCount &t) {
@@ -70,12 +101,19 @@ __device__ __forceinline__ void wave_count_add(DevCounters *c, bool anyHit, cons
 // queue == nullptr means "slot = ray index"; tmax == nullptr means Infinity.  Closest hit
 // writes t, prim (ordered index or -1) and b0,b1,b2; any hit writes one byte.
 // ---------------------------------------------------------------------------
-#define HPRT_REFILL_BELOW 44
+// Scheduling knobs of the persistent walk (defaults from a per-ray trace simulation of
+// killeroo-simple bounce rays; overridable through HPRT_TRACE_TUNE="R,P,K").
+struct TraceTune { int refillBelow, parkLimit, stepLimit; };
+static TraceTune DefaultTraceTune() {
+    TraceTune t = {52, 24, 6};
+    if (const char *e = getenv("HPRT_TRACE_TUNE")) { int r, p, k; if (sscanf(e, "%d,%d,%d", &r, &p, &k) == 3) { t.refillBelow = r; t.parkLimit = p; t.stepLimit = k; } }
+    return t;
+}
 
 template <bool ANY_HIT, bool COUNT>
 __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayPlanes rays, HitPlanes hits, uint8_t *occ,
-                                                            DevCounters *counters, uint32_t *workCounter) {
+                                                            DevCounters *counters, uint32_t *workCounter, uint32_t chunk, TraceTune tune) {
     __shared__ int stackMem[HPRT_LDS_STACK * HPRT_TRACE_BLOCK];
     int *const ldsStack = &stackMem[threadIdx.x];
     const uint32_t n = countPtr ? *countPtr : countImm;
@@ -92,8 +130,13 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
     int negX = 0, negY = 0, negZ = 0;
     int sp = 0, cur = -1;
     int32_t prim = -1; float hb0 = 0.f, hb1 = 0.f, hb2 = 0.f;
+    uint32_t leafBegin = 0u, leafEnd = 0u;      // parked leaf: primitives still to test
     int spill[HPRT_SPILL_STACK];
     bool moreWork = n > 0 && sc.nNodes > 0;
+    // The wave draws rays from the global queue head in chunks (one atomic per `chunk` rays:
+    // a single word retires only ~90 atomics per microsecond) and hands them to idle lanes
+    // from its private range [localNext, localEnd).
+    uint32_t localNext = 0u, localEnd = 0u;
     if (sc.nNodes == 0 && n > 0) {
         // empty aggregate: every ray misses (accelerators/bvh.cpp:355)
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -107,15 +150,20 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
         if (moreWork) {
             const unsigned long long idle = __ballot(!active);
             if (idle != 0ull) {
+                if (localNext >= localEnd) {
+                    uint32_t base = 0u;
+                    if (lane == 0) base = atomicAdd(workCounter, chunk);
+                    base = __shfl(base, 0);
+                    localNext = base < n ? base : n;
+                    localEnd = (base + chunk < n) ? base + chunk : n;
+                    if (localNext >= localEnd) moreWork = false;       // queue drained
+                }
                 const uint32_t want = (uint32_t)__popcll(idle);
-                const int leader = __ffsll((long long)idle) - 1;
-                uint32_t base = 0u;
-                if ((int)lane == leader) base = atomicAdd(workCounter, want);
-                base = __shfl(base, leader);
-                if (base + want >= n) moreWork = false;
+                const uint32_t base = localNext;
+                localNext = (localNext + want < localEnd) ? localNext + want : localEnd;
                 if (!active) {
                     const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                    if (idx < n) {
+                    if (idx < localEnd) {
                         slot = queue ? queue[idx] : idx;
                         ro = vec3(rays.ox[slot], rays.oy[slot], rays.oz[slot]);
                         const vec3 rd(rays.dx[slot], rays.dy[slot], rays.dz[slot]);
@@ -124,6 +172,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                         negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
                         shear = ray_shear(rd);
                         sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
+                        leafBegin = leafEnd = 0u;
                         active = true;
                     }
                 }
@@ -132,10 +181,14 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
         if (__ballot(active) == 0ull) break;
         // ---- walk until too few lanes are busy (or, with the queue drained, until all are done) ----
         while (true) {
-            uint32_t leafBegin = 0, leafEnd = 0;
-            if (active) {
-                // phase 1: interior nodes until a leaf is entered or the stack runs dry
-                while (cur >= 0) {
+            // phase 1: wave-uniform loop; a lane takes node steps until it parks a leaf or runs dry.
+            // The phase ends early once `parkLimit` lanes hold a parked leaf (or after `stepLimit`
+            // steps) so that parked lanes do not idle behind the longest interior run.
+            int steps = 0;
+            while (true) {
+                const bool trav = active && leafBegin == leafEnd && cur >= 0;
+                if (__ballot(trav) == 0ull) break;
+                if (trav) {
                     const float4 n0 = nodes4[2 * cur], n1 = nodes4[2 * cur + 1];   // {min.xyz,max.x} {max.yz,offset,countAxis}
                     if (COUNT) ++cnt.fetched;
                     // Bounds3::IntersectP(ray, invDir, dirIsNeg), core/geometry.h:1754-1780
@@ -162,8 +215,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                     const int32_t offset = __float_as_int(n1.z);
                     const uint32_t countAxis = __float_as_uint(n1.w);
                     const uint32_t axis = countAxis & 3u;
+                    if (COUNT && inside) ++cnt.entered;
                     if (inside && axis != 3u) {
-                        if (COUNT) ++cnt.entered;
                         const int isNeg = axis == 0 ? negX : (axis == 1 ? negY : negZ);
                         const int farNode = isNeg ? cur + 1 : offset;
                         const int nearNode = isNeg ? offset : cur + 1;
@@ -171,30 +224,30 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                         else if (sp - HPRT_LDS_STACK < HPRT_SPILL_STACK) spill[sp - HPRT_LDS_STACK] = farNode;
                         ++sp;
                         cur = nearNode;
-                        continue;
-                    }
-                    // leaf entered, or node missed: the next node comes off the stack
-                    if (sp == 0) cur = -1;
-                    else { --sp; cur = (sp < HPRT_LDS_STACK) ? ldsStack[sp * HPRT_TRACE_BLOCK] : spill[sp - HPRT_LDS_STACK]; }
-                    if (inside) {
-                        if (COUNT) ++cnt.entered;
-                        leafBegin = (uint32_t)offset; leafEnd = (uint32_t)offset + (countAxis >> 2);
-                        break;
+                    } else {
+                        // leaf entered, or node missed: the next node comes off the stack
+                        if (sp == 0) cur = -1;
+                        else { --sp; cur = (sp < HPRT_LDS_STACK) ? ldsStack[sp * HPRT_TRACE_BLOCK] : spill[sp - HPRT_LDS_STACK]; }
+                        if (inside) { leafBegin = (uint32_t)offset; leafEnd = (uint32_t)offset + (countAxis >> 2); }
                     }
                 }
+                ++steps;
+                if (steps >= tune.stepLimit || __popcll(__ballot(leafBegin != leafEnd)) >= tune.parkLimit) break;
             }
-            // phase 2: primitives of the parked leaves
-            bool done = false;
-            if (active) {
-                for (uint32_t pi = leafBegin; pi < leafEnd; ++pi) {
+            // phase 2: primitives of the parked leaves (wave-uniform loop over the longest leaf)
+            while (true) {
+                const bool pending = active && leafBegin != leafEnd;
+                if (__ballot(pending) == 0ull) break;
+                if (pending) {
+                    const uint32_t pi = leafBegin++;
                     const float4 v0 = sc.tris[3 * pi], v1 = sc.tris[3 * pi + 1], v2 = sc.tris[3 * pi + 2];
                     const uint32_t tag = __float_as_uint(v0.w);
                     if ((tag & TAG_KIND_MASK) == 0u) {
                         if (COUNT) ++cnt.tri;
                         float b0, b1, b2, t;
                         if (tri_test(vec3(v0.x, v0.y, v0.z), vec3(v1.x, v1.y, v1.z), vec3(v2.x, v2.y, v2.z), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
-                            if (ANY_HIT) { hit = true; break; }
-                            if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = b0; hb1 = b1; hb2 = b2; }
+                            if (ANY_HIT) { hit = true; leafBegin = leafEnd; }
+                            else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = b0; hb1 = b1; hb2 = b2; }
                         }
                     } else {
                         if (COUNT) ++cnt.sphere;
@@ -202,24 +255,24 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                         rr.d = vec3(rays.dx[slot], rays.dy[slot], rays.dz[slot]);
                         DRay robj; vec3 ph; float phi, t;
                         if (sphere_test(sc.spheres[__float_as_uint(v2.w)], rr, &robj, &ph, &phi, &t)) {
-                            if (ANY_HIT) { hit = true; break; }
-                            hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = 0.f; hb1 = 0.f; hb2 = 0.f;
+                            if (ANY_HIT) { hit = true; leafBegin = leafEnd; }
+                            else { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; }
                         }
                     }
                 }
-                done = (cur < 0) || (ANY_HIT && hit);
-                if (done) {
-                    if (ANY_HIT) occ[slot] = hit ? 1 : 0;
-                    else {
-                        hits.t[slot] = rayTMax; hits.prim[slot] = hit ? prim : -1;
-                        if (hits.b0) { hits.b0[slot] = hb0; hits.b1[slot] = hb1; hits.b2[slot] = hb2; }
-                    }
-                    active = false;
+            }
+            // retire finished rays
+            if (active && ((cur < 0 && leafBegin == leafEnd) || (ANY_HIT && hit))) {
+                if (ANY_HIT) occ[slot] = hit ? 1 : 0;
+                else {
+                    hits.t[slot] = rayTMax; hits.prim[slot] = hit ? prim : -1;
+                    if (hits.b0) { hits.b0[slot] = hb0; hits.b1[slot] = hb1; hits.b2[slot] = hb2; }
                 }
+                active = false;
             }
             const int busy = __popcll(__ballot(active));
             if (busy == 0) break;
-            if (moreWork && busy < HPRT_REFILL_BELOW) break;
+            if (moreWork && busy < tune.refillBelow) break;
         }
     }
     if (COUNT) wave_count_add(counters, ANY_HIT, cnt);
@@ -252,15 +305,58 @@ __global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, 
 }
 
 // ---------------------------------------------------------------------------
-// k_shade: one lane per active path.  Consumes the closest hit of the path ray.
+// k_bin: material sorting.  After the closest-hit pass every active path is appended
+// (ballot + mbcnt prefix, one atomic per wave and bin) to the queue of the shading
+// variant it needs, so that a wavefront of k_shade runs one material's code:
+//   bin 0  triangle with a matte material       (Lambertian lobe only)
+//   bin 1  triangle with a plastic material     (Lambertian + Trowbridge-Reitz lobes)
+//   bin 2  anything else that still needs work  (sphere hits: emitter / quadric fill)
+// Paths that escaped the scene, or reached maxDepth (integrators/path.cpp:110), need no
+// shading and are dropped here; emitted radiance is only added at bounce 0 (path.cpp:97).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, RenderParams rp, PathPlanes ps, const uint32_t *queue,
-                                               const uint32_t *countPtr, uint32_t countImm, uint32_t s0, QueueSet q) {
+__global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathPlanes ps, const uint32_t *queue, const uint32_t *countPtr,
+                                              uint32_t countImm, int32_t maxDepth, BinSet bins) {
+    __shared__ BlockAppendLds al;
+    const uint32_t n = countPtr ? *countPtr : countImm;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int bin = -1;
+    uint32_t slot = 0;
+    if (i < n) {
+        slot = queue ? queue[i] : i;
+        const int32_t prim = ps.hit.prim[slot];
+        const int bounces = (int)((ps.state[slot] >> 8) & 0xffu);
+        if (prim >= 0) {
+            const uint32_t tag = __float_as_uint(sc.tris[3 * prim].w);
+            const bool isTri = (tag & TAG_KIND_MASK) == 0u;
+            if (bounces >= maxDepth) { if (bounces == 0 && !isTri) bin = 2; }   // only an emitter hit by a camera ray matters
+            else if (!isTri) bin = 2;
+            else bin = sc.materials[sc.shapes[__float_as_uint(sc.tris[3 * prim + 1].w)].material].type == 1 ? 1 : 0;
+        }
+    }
+    uint32_t *const ctr[3] = {bins.count + 0, bins.count + 1, bins.count + 2};
+    const bool pred[3] = {bin == 0, bin == 1, bin == 2};
+    uint32_t pos[3];
+    block_append<3>(&al, ctr, pred, pos);
+    if (bin == 0) bins.q[0][pos[0]] = slot;
+    else if (bin == 1) bins.q[1][pos[1]] = slot;
+    else if (bin == 2) bins.q[2][pos[2]] = slot;
+}
+
+// ---------------------------------------------------------------------------
+// k_shade<MODE>: one lane per path of bin MODE.  Consumes the closest hit of the path ray.
+// ---------------------------------------------------------------------------
+// Specialised variants (MODE 0/1) run 1024-thread workgroups so that queue appends cost one
+// atomic per queue and workgroup; the rare generic variant keeps 256 threads (it needs more
+// registers than a 1024-thread workgroup can have).
+template <int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 256 : 1024) void k_shade(DevScene sc, RenderParams rp, PathPlanes ps, const uint32_t *queue,
+                                               const uint32_t *countPtr, uint32_t countImm, uint32_t s0, QueueSet q, BinSet bins) {
     __shared__ HaltonLds hl;
+    __shared__ BlockAppendLds al;
     halton_lds_load(sc, &hl);
     const uint32_t n = countPtr ? *countPtr : countImm;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool wantNext = false, wantShadow = false, wantMis = false, wantResolve = false;
+    bool wantNext = false, wantShadow = false, wantMis = false, wantResolve = false, defer = false;
     uint32_t slot = 0;
     if (i < n) {
         slot = queue ? queue[i] : i;
@@ -277,15 +373,16 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RenderParams rp, Pat
         DevSI si;
         if (found) {
             const float4 v0 = sc.tris[3 * prim];
-            if ((__float_as_uint(v0.w) & TAG_KIND_MASK) == 0u)
+            if (MODE != 2 || (__float_as_uint(v0.w) & TAG_KIND_MASK) == 0u)
                 fill_triangle(sc, (uint32_t)prim, ps.hit.b0[slot], ps.hit.b1[slot], ps.hit.b2[slot], rayD, &si);
             else {
                 DRay r0; r0.o = rayO; r0.d = rayD; r0.tMax = ps.ray.tmax[slot];
                 float tt;
                 fill_sphere(sc, (int)__float_as_uint(sc.tris[3 * prim + 1].w), r0, &si, &tt);
             }
-            // emitted radiance at the first vertex (path.cpp:97-107; no specular lobes exist here)
-            if (bounces == 0) {
+            // emitted radiance at the first vertex (path.cpp:97-107; no specular lobes exist here).
+            // Triangle meshes carry no area lights in this build, so only the generic variant looks.
+            if (MODE == 2 && bounces == 0) {
                 const int al = sc.shapes[si.shape].areaLight;
                 if (al >= 0) {
                     rgb Le = area_L(sc.lights[al], si.n, -rayD);
@@ -299,8 +396,9 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RenderParams rp, Pat
         if (found && bounces < rp.maxDepth) {
             DevBsdf bsdf;
             bsdf_init(sc, si, &bsdf);
+            if (MODE == 0) { bsdf.hasS = false; bsdf.Rs = rgb(0.f); bsdf.alpha = 0.f; }   // matte: no microfacet lobe (matte.cpp:45-62)
             // ---- direct lighting (UniformSampleOneLight + EstimateDirect) ----
-            if (bsdf_num(bsdf, BX_ALL & ~BX_SPECULAR) > 0 && sc.nLights > 0) {
+            if (bsdf_num(bsdf) > 0 && sc.nLights > 0) {
                 float pickPdf;
                 const int lightNum = light_pick(sc, halton_dim(sc, rp.hal, index, dim, &hl), &pickPdf);
                 dim += 1;
@@ -309,17 +407,21 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RenderParams rp, Pat
                     const float us0 = halton_dim(sc, rp.hal, index, dim + 2, &hl), us1 = halton_dim(sc, rp.hal, index, dim + 3, &hl);
                     dim += 4;
                     const DevLight light = sc.lights[lightNum];
-                    const int flagsNS = BX_ALL & ~BX_SPECULAR;
                     const bool isDelta = light.type != 2;
                     vec3 wi;
                     float lightPdf = 0, scatteringPdf = 0;
                     DevIt it; it.p = si.p; it.pErr = si.pErr; it.n = si.n;
                     DevIt pl;
-                    rgb Li = light_sample(sc, light, it, ul0, ul1, &wi, &lightPdf, &pl);
+                    // A shading point inside the emitter sphere needs the full quadric code
+                    // (Sphere::Sample(u) + Shape::Pdf); nothing has been written yet, so the
+                    // material-specialised variants hand such a vertex to the generic variant.
+                    if (MODE != 2 && !isDelta && sphere_ref_inside(sc.spheres[light.sphere], it)) defer = true;
+                    if (!defer) {
+                    rgb Li = light_sample<MODE == 2>(sc, light, it, ul0, ul1, &wi, &lightPdf, &pl);
                     rgb pendLight(0.f), pendMis(0.f);
                     if (lightPdf > 0 && !is_black(Li)) {
-                        rgb f = bsdf_f(bsdf, si.wo, wi, flagsNS) * absdot(wi, si.ns);
-                        scatteringPdf = bsdf_pdf(bsdf, si.wo, wi, flagsNS);
+                        rgb f = bsdf_f(bsdf, si.wo, wi) * absdot(wi, si.ns);
+                        scatteringPdf = bsdf_pdf(bsdf, si.wo, wi);
                         if (!is_black(f)) {
                             // shadow ray: Interaction::SpawnRayTo(it) (core/interaction.h:73-78)
                             vec3 origin = offset_ray_origin(it.p, it.pErr, it.n, pl.p - it.p);
@@ -335,10 +437,10 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RenderParams rp, Pat
                     }
                     if (!isDelta) {
                         int sampledType = 0;
-                        rgb f = bsdf_sample(bsdf, si.wo, &wi, us0, us1, &scatteringPdf, flagsNS, &sampledType);
+                        rgb f = bsdf_sample(bsdf, si.wo, &wi, us0, us1, &scatteringPdf, &sampledType);
                         f = f * absdot(wi, si.ns);
                         if (!is_black(f) && scatteringPdf > 0) {
-                            float lp = light_pdf(sc, light, it, wi);
+                            float lp = light_pdf<MODE == 2>(sc, light, it, wi);
                             if (lp != 0) {     // "if (lightPdf == 0) return Ld;" keeps the light-sampling term only
                                 float w = power_heuristic(scatteringPdf, lp);
                                 vec3 o = offset_ray_origin(si.p, si.pErr, si.n, wi);
@@ -360,14 +462,16 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RenderParams rp, Pat
                         wantResolve = true;
                     }
                     // neither ray: Ld == 0, "L += beta * 0 / pdf" leaves L unchanged
+                    }
                 }
             }
             // ---- sample the BSDF for the next path segment (path.cpp:141-164) ----
+            if (!defer) {
             const float ub0 = halton_dim(sc, rp.hal, index, dim, &hl), ub1 = halton_dim(sc, rp.hal, index, dim + 1, &hl);
             dim += 2;
             vec3 wo = -rayD, wi;
             float pdf = 0; int flags = 0;
-            rgb f = bsdf_sample(bsdf, wo, &wi, ub0, ub1, &pdf, BX_ALL, &flags);
+            rgb f = bsdf_sample(bsdf, wo, &wi, ub0, ub1, &pdf, &flags);
             if (!(is_black(f) || pdf == 0.f)) {
                 beta = beta * (f * absdot(wi, si.ns) / pdf);
                 vec3 o = offset_ray_origin(si.p, si.pErr, si.n, wi);
@@ -390,14 +494,19 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, RenderParams rp, Pat
                     wantNext = true;
                 }
             }
+            }
         }
     }
-    // queue appends in wave-uniform control flow
-    uint32_t pos;
-    pos = wave_append(q.nextCount, wantNext); if (wantNext) q.next[pos] = slot;
-    pos = wave_append(q.shadowCount, wantShadow); if (wantShadow) q.shadow[pos] = slot;
-    pos = wave_append(q.misCount, wantMis); if (wantMis) q.mis[pos] = slot;
-    pos = wave_append(q.resolveCount, wantResolve); if (wantResolve) q.resolve[pos] = slot;
+    // queue appends in block-uniform control flow
+    if (MODE != 2) { const uint32_t p2 = wave_append(bins.count + 2, defer); if (defer) bins.q[2][p2] = slot; }   // (almost) never
+    uint32_t *const ctr[4] = {q.nextCount, q.shadowCount, q.misCount, q.resolveCount};
+    const bool pred[4] = {wantNext, wantShadow, wantMis, wantResolve};
+    uint32_t pos[4];
+    block_append<4>(&al, ctr, pred, pos);
+    if (wantNext) q.next[pos[0]] = slot;
+    if (wantShadow) q.shadow[pos[1]] = slot;
+    if (wantMis) q.mis[pos[2]] = slot;
+    if (wantResolve) q.resolve[pos[3]] = slot;
 }
 
 // ---------------------------------------------------------------------------
@@ -566,20 +675,34 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     // persistent waves: enough blocks to fill 256 CUs at this kernel's occupancy, never more than the rays need
     const uint32_t maxBlocks = 256u * 5u;
     dim3 grid(std::min(blocks_for(gridItems, HPRT_TRACE_BLOCK), maxBlocks)), block(HPRT_TRACE_BLOCK);
+    // rays per queue-head atomic: large launches take 512 at a time, small ones keep every wave busy
+    const uint32_t nWaves = grid.x * (HPRT_TRACE_BLOCK / 64);
+    uint32_t chunk = gridItems / (nWaves * 4u);
+    chunk = std::max(64u, std::min(512u, chunk)) & ~63u;
+    static const TraceTune tune = DefaultTraceTune();
     if (anyHit) {
-        if (count) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter);
-        else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter);
+        if (count) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
+        else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
     } else {
-        if (count) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter);
-        else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter);
+        if (count) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
+        else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
     }
 }
 void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, uint32_t s0, uint32_t nSlots) {
     if (nSlots) hipLaunchKernelGGL(k_generate, dim3(blocks_for(nSlots, 256)), dim3(256), 0, st, sc, rp, ps, s0, nSlots);
 }
-void LaunchShade(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, const uint32_t *queue,
-                 const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, uint32_t s0, const QueueSet &q) {
-    if (gridItems) hipLaunchKernelGGL(k_shade, dim3(blocks_for(gridItems, 256)), dim3(256), 0, st, sc, rp, ps, queue, countPtr, countImm, s0, q);
+void LaunchBin(hipStream_t st, const DevScene &sc, const PathPlanes &ps, const uint32_t *queue, const uint32_t *countPtr,
+               uint32_t countImm, uint32_t gridItems, int32_t maxDepth, const BinSet &bins) {
+    if (gridItems) hipLaunchKernelGGL(k_bin, dim3(blocks_for(gridItems, 1024)), dim3(1024), 0, st, sc, ps, queue, countPtr, countImm, maxDepth, bins);
+}
+void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, const uint32_t *queue,
+                 const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, uint32_t s0, const QueueSet &q, const BinSet &bins) {
+    if (!gridItems) return;
+    const uint32_t bs = mode == 2 ? 256u : 1024u;
+    dim3 grid(blocks_for(gridItems, bs)), block(bs);
+    if (mode == 0) hipLaunchKernelGGL((k_shade<0>), grid, block, 0, st, sc, rp, ps, queue, countPtr, countImm, s0, q, bins);
+    else if (mode == 1) hipLaunchKernelGGL((k_shade<1>), grid, block, 0, st, sc, rp, ps, queue, countPtr, countImm, s0, q, bins);
+    else hipLaunchKernelGGL((k_shade<2>), grid, block, 0, st, sc, rp, ps, queue, countPtr, countImm, s0, q, bins);
 }
 void LaunchResolve(hipStream_t st, const DevScene &sc, const PathPlanes &ps, const uint32_t *queue, const uint32_t *countPtr,
                    uint32_t gridItems) {
