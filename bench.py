@@ -72,10 +72,10 @@ def main():
     film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)   # device memory via torch: plumbing only
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def step(count_work=False):
+    def step(count_work=False, gather=True):
         _, st = scene.render(opt, spp_chunk=args.spp_chunk, count_work=count_work, film_ptr=film.data_ptr(), stream=stream,
                              **tiles.shard(rank, max(1, world)))
-        if dist is not None:
+        if dist is not None and gather:
             tiles.gather_film(film, dist, dst=0)             # Film tiles -> rank 0 (RCCL over xGMI); addends are disjoint
         return st
 
@@ -109,10 +109,8 @@ def main():
     roofline = None
     cpu_baseline = None
     if rank == 0:
-        st_c = step(count_work=True)        # untimed counting pass: V (nodes fetched), T (triangle tests)
+        st_c = step(count_work=True, gather=False)   # untimed, rank-local counting pass: V (nodes fetched), T (primitive tests)
         torch.cuda.synchronize(dev)
-        if dist is not None:
-            pass
         ext_rays = sum(s["extend_rays"] for s in stats)
         ext_sec = sum(s["extend_seconds"] for s in stats)
         ext_launches = sum(s["extend_launches"] for s in stats)

@@ -610,7 +610,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     // ---- sizes ----
     const size_t lallBytes = 3ull * spp * nPix * sizeof(float);
     if (lallBytes > (96ull << 30)) return SetError(HPRT_E_UNSUPPORTED, "per-sample radiance store would exceed 96 GiB; render in several tile ranges");
-    uint32_t chunk = desc->spp_chunk > 0 ? (uint32_t)desc->spp_chunk : std::max<uint32_t>(1u, (uint32_t)((8u << 20) / std::max<uint32_t>(nPix, 1u)));
+    uint32_t chunk = desc->spp_chunk > 0 ? (uint32_t)desc->spp_chunk : std::max<uint32_t>(1u, (uint32_t)((64u << 20) / std::max<uint32_t>(nPix, 1u)));   // ~64 M paths per wavefront batch (17 GB of path state)
     chunk = std::min(chunk, spp);
     if ((uint64_t)chunk * nPix > 0x7fffffffull) chunk = (uint32_t)(0x7fffffffull / nPix);
     const size_t maxSlots = (size_t)chunk * nPix;
