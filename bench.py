@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--spp-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=128)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="debug: all ranks share cuda:0 and the film is reduced with gloo (checks the N>1 control flow on a 1-GPU box)")
     args = ap.parse_args()
 
     import numpy as np
@@ -53,8 +55,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -94,11 +101,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         tot = torch.tensor([sum(s["rays"] + s["shadow_rays"] for s in stats), sum(s["camera_rays"] for s in stats)],
-                           dtype=torch.float64, device=dev)
+                           dtype=torch.float64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_rays, total_samples = float(tot[0].item()), float(tot[1].item())
     else:

@@ -113,3 +113,44 @@ def test_render_crop_film_and_counters(hprt, killeroo_model, killeroo_scene, kil
     assert st["nodes_entered"] == c0["nodes_entered"] and st["nodes_entered_p"] == c0["nodes_entered_p"]
     assert st["tri_tests"] == c0["tri_tests"] and st["tri_tests_p"] == c0["tri_tests_p"]
     killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
+
+
+def _two_rank_worker(rank, world, port, out_path, crop, spp):
+    import importlib, os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from conftest import KILLEROO, ROOT
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    hprt = importlib.import_module("thesis-pbrt-v3_amd")
+    tiles = importlib.import_module("thesis-pbrt-v3_amd.tiles")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = hprt.Model.load(KILLEROO); bvh = hprt.Bvh(model); scene = hprt.Scene(model, bvh, device=0)
+    opt = model.options.copy()
+    for i in range(4):
+        opt.crop[i] = crop[i]
+    opt.spp = spp
+    x0, y0, x1, y1 = opt.film_bounds()
+    film = torch.zeros((y1 - y0, x1 - x0, 4), dtype=torch.float32, device="cuda:0")
+    scene.render(opt, film_ptr=film.data_ptr(), **tiles.shard(rank, world))
+    tiles.gather_film(film, dist, dst=0)
+    if rank == 0:
+        np.save(out_path, film.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sharing_the_gpu_reproduce_the_film(tmp_path, killeroo_oracle):
+    """N > 1 path on the 1-GPU box: two processes render alternate tiles on cuda:0, the films are
+    summed (gloo here, RCCL in bench.py) and must equal the oracle's single-process film."""
+    import socket
+    import torch.multiprocessing as mp
+    crop = (0.40, 0.40 + 96 / 700.0, 0.45, 0.45 + 80 / 700.0)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "film2.npy")
+    mp.spawn(_two_rank_worker, args=(2, port, out, crop, 8), nprocs=2, join=True)
+    got = np.load(out)
+    killeroo_oracle.set_film(crop=crop, spp=8)
+    _, film0, _, _, _ = killeroo_oracle.render(spp=8, threads=8)
+    killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
+    assert np.array_equal(got.view(np.uint32), film0.view(np.uint32))

@@ -19,6 +19,15 @@ def shard(rank, world):
 
 
 def gather_film(film, dist, dst=0):
-    """Sum the per-rank film tensors onto `dst` (in place).  `dist` is torch.distributed."""
-    dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
+    """Sum the per-rank film tensors onto `dst` (in place).  `dist` is torch.distributed.
+
+    With the RCCL backend ("nccl") the device tensor is reduced directly over xGMI.  With
+    gloo (CPU rehearsals, or several ranks sharing one GPU in the tests) a device tensor
+    takes a round trip through host memory."""
+    if film.is_cuda and dist.get_backend() == "gloo":
+        host = film.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+        film.copy_(host)
+    else:
+        dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
     return film
