@@ -26,6 +26,8 @@
 
 namespace hprt {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------------------
 // wave-level queue append: returns the position for lanes with pred, one atomic per wave
 // ---------------------------------------------------------------------------
@@ -118,7 +120,12 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
     int *const ldsStack = &stackMem[threadIdx.x];
     const uint32_t n = countPtr ? *countPtr : countImm;
     const uint32_t lane = __lane_id();
-    const float4 *const nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
+    // Nodes and primitives are fetched with buffer loads: a 32-bit per-lane byte offset against a
+    // wave-uniform descriptor (no 64-bit address arithmetic) and — unlike plain loads, which hipcc
+    // splits and sinks into the branches that consume each component — exactly two 16-byte
+    // requests per node and three per primitive, issued together.
+    const auto nodeRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.nodes, 0, (int)((size_t)sc.nNodes * 32u), 0x00020000);
+    const auto triRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.tris, 0, (int)((size_t)sc.nPrims * 48u), 0x00020000);
     const float robust = 1 + 2 * gamma_n(3);
     TraceCount cnt = {0u, 0u, 0u, 0u};
     // per-lane ray state
@@ -189,10 +196,12 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                 const bool trav = active && leafBegin == leafEnd && cur >= 0;
                 if (__ballot(trav) == 0ull) break;
                 if (trav) {
-                    const float4 n0 = nodes4[2 * cur], n1 = nodes4[2 * cur + 1];   // {min.xyz,max.x} {max.yz,offset,countAxis}
+                    const u32x4 n0 = __builtin_amdgcn_raw_buffer_load_b128(nodeRsrc, cur * 32, 0, 0);        // {min.xyz, max.x}
+                    const u32x4 n1 = __builtin_amdgcn_raw_buffer_load_b128(nodeRsrc, cur * 32 + 16, 0, 0);   // {max.yz, offset, countAxis}
                     if (COUNT) ++cnt.fetched;
                     // Bounds3::IntersectP(ray, invDir, dirIsNeg), core/geometry.h:1754-1780
-                    const float bminx = n0.x, bminy = n0.y, bminz = n0.z, bmaxx = n0.w, bmaxy = n1.x, bmaxz = n1.y;
+                    const float bminx = __uint_as_float(n0.x), bminy = __uint_as_float(n0.y), bminz = __uint_as_float(n0.z);
+                    const float bmaxx = __uint_as_float(n0.w), bmaxy = __uint_as_float(n1.x), bmaxz = __uint_as_float(n1.y);
                     float tMin = ((negX ? bmaxx : bminx) - ro.x) * invDir.x;
                     float tMax = ((negX ? bminx : bmaxx) - ro.x) * invDir.x;
                     float tyMin = ((negY ? bmaxy : bminy) - ro.y) * invDir.y;
@@ -212,8 +221,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                             inside = (tMin < rayTMax) && (tMax > 0);
                         }
                     }
-                    const int32_t offset = __float_as_int(n1.z);
-                    const uint32_t countAxis = __float_as_uint(n1.w);
+                    const int32_t offset = (int32_t)n1.z;
+                    const uint32_t countAxis = n1.w;
                     const uint32_t axis = countAxis & 3u;
                     if (COUNT && inside) ++cnt.entered;
                     if (inside && axis != 3u) {
@@ -240,12 +249,16 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                 if (__ballot(pending) == 0ull) break;
                 if (pending) {
                     const uint32_t pi = leafBegin++;
-                    const float4 v0 = sc.tris[3 * pi], v1 = sc.tris[3 * pi + 1], v2 = sc.tris[3 * pi + 2];
-                    const uint32_t tag = __float_as_uint(v0.w);
+                    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48, 0, 0);
+                    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 16, 0, 0);
+                    const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 32, 0, 0);
+                    const uint32_t tag = v0.w;
                     if ((tag & TAG_KIND_MASK) == 0u) {
                         if (COUNT) ++cnt.tri;
                         float b0, b1, b2, t;
-                        if (tri_test(vec3(v0.x, v0.y, v0.z), vec3(v1.x, v1.y, v1.z), vec3(v2.x, v2.y, v2.z), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
+                        if (tri_test(vec3(__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z)),
+                                     vec3(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
+                                     vec3(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z)), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
                             if (ANY_HIT) { hit = true; leafBegin = leafEnd; }
                             else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = b0; hb1 = b1; hb2 = b2; }
                         }
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                         DRay rr; rr.o = ro; rr.tMax = rayTMax;
                         rr.d = vec3(rays.dx[slot], rays.dy[slot], rays.dz[slot]);
                         DRay robj; vec3 ph; float phi, t;
-                        if (sphere_test(sc.spheres[__float_as_uint(v2.w)], rr, &robj, &ph, &phi, &t)) {
+                        if (sphere_test(sc.spheres[v2.w], rr, &robj, &ph, &phi, &t)) {
                             if (ANY_HIT) { hit = true; leafBegin = leafEnd; }
                             else { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; }
                         }
