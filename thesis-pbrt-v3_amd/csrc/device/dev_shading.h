@@ -32,6 +32,25 @@ __device__ __forceinline__ uint64_t reverse_bits64(uint64_t n) {
 // RadicalInverseSpecialized<base> / ScrambledRadicalInverseSpecialized<base>
 // (core/lowdiscrepancy.cpp:389-424); perm == nullptr selects the unscrambled form.
 // PermPtr is `const uint16_t *` (HBM table) or an LDS pointer (staged copy).
+// LDS variant of the scrambled form: invBase = 1/(float)base and the infinite-tail term
+// invBase*perm[0]/(1-invBase) depend on the dimension only, so they are evaluated once per
+// block by halton_lds_load (same float operations, same values) instead of once per sample.
+__device__ __forceinline__ float scrambled_radical_inverse_lds(uint32_t base, uint64_t M, uint64_t a, const uint16_t *perm, float invBase, float tail) {
+    uint64_t reversedDigits = 0;
+    float invBaseN = 1;
+    while (a) {
+        uint64_t next;
+        if (a <= 0xffffffffull) next = div_magic32((uint32_t)a, M);
+        else next = a / base;
+        uint32_t digit = (uint32_t)(a - next * base);
+        reversedDigits = reversedDigits * base + (uint32_t)perm[digit];
+        invBaseN *= invBase;
+        a = next;
+    }
+    // (float)uint64: a value below 2^32 converts identically through the 32-bit instruction
+    const float rd = (reversedDigits >> 32) == 0ull ? (float)(uint32_t)reversedDigits : (float)reversedDigits;
+    return sel_min(invBaseN * (rd + tail), HPRT_ONE_MINUS_EPS);
+}
 template <typename PermPtr>
 __device__ __forceinline__ float radical_inverse_base(uint32_t base, uint64_t M, uint64_t a, PermPtr perm, bool scrambled) {
     const float invBase = 1.0f / (float)base;
@@ -61,11 +80,16 @@ struct HaltonLds {
     uint64_t magic[HPRT_HALTON_LDS_DIMS];
     int32_t prime[HPRT_HALTON_LDS_DIMS];
     int32_t primeSum[HPRT_HALTON_LDS_DIMS];
+    float invBase[HPRT_HALTON_LDS_DIMS];
+    float tail[HPRT_HALTON_LDS_DIMS];
     uint16_t perm[HPRT_HALTON_LDS_PERMS + 3];
 };
 __device__ __forceinline__ void halton_lds_load(const DevScene &sc, HaltonLds *h) {
     for (int i = threadIdx.x; i < HPRT_HALTON_LDS_DIMS; i += blockDim.x) {
         h->magic[i] = sc.primeMagic[i]; h->prime[i] = sc.primes[i]; h->primeSum[i] = sc.primeSums[i];
+        const float invBase = 1.0f / (float)sc.primes[i];
+        h->invBase[i] = invBase;
+        h->tail[i] = invBase * (float)sc.perms[sc.primeSums[i]] / (1 - invBase);   // invBase * perm[0] / (1 - invBase)
     }
     for (int i = threadIdx.x; i < HPRT_HALTON_LDS_PERMS; i += blockDim.x) h->perm[i] = sc.perms[i];
     __syncthreads();
@@ -76,7 +100,7 @@ __device__ __forceinline__ float halton_dim(const DevScene &sc, const DevHalton 
     if (dim == 0) return (float)((double)reverse_bits64(index >> h.baseExp0) * 0x1p-64);
     if (dim == 1) return radical_inverse_base<const uint16_t *>(3u, sc.primeMagic[1], index / (uint64_t)h.baseScale1, nullptr, false);
     if (lds && dim < HPRT_HALTON_LDS_DIMS)
-        return radical_inverse_base<const uint16_t *>((uint32_t)lds->prime[dim], lds->magic[dim], index, lds->perm + lds->primeSum[dim], true);
+        return scrambled_radical_inverse_lds((uint32_t)lds->prime[dim], lds->magic[dim], index, lds->perm + lds->primeSum[dim], lds->invBase[dim], lds->tail[dim]);
     return radical_inverse_base<const uint16_t *>((uint32_t)sc.primes[dim], sc.primeMagic[dim], index, sc.perms + sc.primeSums[dim], true);
 }
 
@@ -92,7 +116,8 @@ __device__ __forceinline__ void concentric_disk(float ux, float uy, float *dx, f
     float theta, r;
     if (fabsf(ox) > fabsf(oy)) { r = ox; theta = HPRT_PI_OVER_4 * (oy / ox); }
     else { r = oy; theta = HPRT_PI_OVER_2 - HPRT_PI_OVER_4 * (ox / oy); }
-    *dx = r * det_cosf(theta); *dy = r * det_sinf(theta);
+    float sn, cs; det_sincosf(theta, &sn, &cs);
+    *dx = r * cs; *dy = r * sn;
 }
 // PerspectiveCamera::GenerateRayDifferential main ray + CameraToWorld(ray) (transform.h:245-259)
 __device__ __forceinline__ void camera_ray(const DevCamera &cam, float fx, float fy, float lu, float lv, DRay *out) {
@@ -281,8 +306,9 @@ __device__ __forceinline__ void tr_sample11(float cosTheta, float U1, float U2, 
     if ((double)cosTheta > .9999) {
         float r = sqrtf(U1 / (1 - U1));
         float phi = (float)(6.28318530718 * (double)U2);
-        *slope_x = (float)((double)r * det_cos((double)phi));   // float * ::cos(double) -> double -> float
-        *slope_y = (float)((double)r * det_sin((double)phi));
+        double sn, cs; det_sincos((double)phi, &sn, &cs);
+        *slope_x = (float)((double)r * cs);   // float * ::cos(double) -> double -> float
+        *slope_y = (float)((double)r * sn);
         return;
     }
     float sinTheta = sqrtf(sel_max(0.f, 1.0f - cosTheta * cosTheta));
@@ -423,14 +449,16 @@ __device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW
 struct DevIt { vec3 p, pErr, n; };   // Interaction subset
 
 __device__ __forceinline__ vec3 spherical_dir(float sinTheta, float cosTheta, float phi, vec3 x, vec3 y, vec3 z) {
-    return sinTheta * det_cosf(phi) * x + sinTheta * det_sinf(phi) * y + cosTheta * z;
+    float sn, cs; det_sincosf(phi, &sn, &cs);
+    return sinTheta * cs * x + sinTheta * sn * y + cosTheta * z;
 }
 // Sphere::Sample(u) (shapes/sphere.cpp:217-230)
 __device__ __forceinline__ DevIt sphere_sample_area(const DevSphere &s, bool reverse, float u0, float u1, float *pdf) {
     float z = 1 - 2 * u0;
     float r = sqrtf(sel_max(0.f, 1.0f - z * z));
     float phi = 2 * HPRT_PI * u1;
-    vec3 pObj = vec3(0, 0, 0) + s.radius * vec3(r * det_cosf(phi), r * det_sinf(phi), z);
+    float sn, cs; det_sincosf(phi, &sn, &cs);
+    vec3 pObj = vec3(0, 0, 0) + s.radius * vec3(r * cs, r * sn, z);
     DevIt it;
     it.n = normalize(xf_normal(s.w2o, pObj));
     if (reverse) it.n = it.n * -1.f;

@@ -366,8 +366,9 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 1024) void k_shade(DevScene sc, R
                                                const uint32_t *countPtr, uint32_t countImm, uint32_t s0, QueueSet q, BinSet bins) {
     __shared__ HaltonLds hl;
     __shared__ BlockAppendLds al;
-    halton_lds_load(sc, &hl);
     const uint32_t n = countPtr ? *countPtr : countImm;
+    if (blockIdx.x * blockDim.x >= n) return;      // whole block beyond the queue (grids are sized for the upper bound)
+    halton_lds_load(sc, &hl);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool wantNext = false, wantShadow = false, wantMis = false, wantResolve = false, defer = false;
     uint32_t slot = 0;

@@ -170,6 +170,15 @@ HPRT_HD double det_cos(double x) {
     double s = k_sin(r), c = k_cos(r);
     return q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
 }
+// sin and cos of one argument with a single reduction and one evaluation of each kernel:
+// the same operations, hence the same two values, as det_sin(x) and det_cos(x).
+HPRT_HD void det_sincos(double x, double *sn, double *cs) {
+    double r; int q = reduce_pio2(x, &r);
+    double s = k_sin(r), c = k_cos(r);
+    *sn = q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c));
+    *cs = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
+}
+HPRT_HD void det_sincosf(float x, float *sn, float *cs) { double s, c; det_sincos((double)x, &s, &c); *sn = (float)s; *cs = (float)c; }
 HPRT_HD double det_atan_pos(double t) {
     double base = 0.0; bool inv = false;
     if (t > 1.0) { t = 1.0 / t; inv = true; }
