@@ -126,9 +126,21 @@ def main():
         t_per_ray = (st_c["tri_tests"] + st_c["sphere_tests"]) / max(1, st_c["rays"])
         bytes_per_ray = 32.0 * v_per_ray + 48.0 * t_per_ray + 28.0 + 20.0
         achieved = ext_rays * bytes_per_ray / max(ext_sec, 1e-12) / 1e9
+        # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 cannot run inside this
+        # process): tools/traffic_passes.sh on this same command, summary committed under profiles/.
+        traffic, traffic_from = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if world == 1 and args.spp == 256 and os.path.exists(tpath):
+            try:
+                tk = json.load(open(tpath))["kernels"].get("k_trace<false, false>")
+                if tk:
+                    traffic, traffic_from = round(tk["hbm_bytes_per_launch"]), "profiles/r01_traffic.json"
+            except Exception:
+                pass
         roofline = {
             "bound": "hbm", "kernel": "k_trace<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_from": traffic_from,
+            "algorithmic_bytes_per_launch": round(ext_rays * bytes_per_ray / max(1, ext_launches)),
             "bytes_per_ray": round(bytes_per_ray, 1), "nodes_fetched_per_ray": round(v_per_ray, 3),
             "prim_tests_per_ray": round(t_per_ray, 3), "launches": int(ext_launches),
             "avg_launch_ms": round(1e3 * ext_sec / max(1, ext_launches), 4),

@@ -118,6 +118,22 @@ __device__ __forceinline__ bool ef_quadratic(efloat A, efloat B, efloat C, efloa
     return true;
 }
 
+// "phi > phiMax" of the clipping test (shapes/sphere.cpp:93-97) without evaluating atan2 when
+// the outcome is already certain.  For a (nearly) full sphere, phiMax > 6.283: with y >= 0 the
+// angle is in [0, pi]; with y < 0 and x <= 0 it is in [pi, 3pi/2]; with y < 0 < x and
+// -y/x > 1e-3 it is below 2pi - 9.9e-4.  None of these can exceed phiMax, so the comparison is
+// false exactly as if phi had been computed.  Everything else takes the full evaluation.
+__device__ __forceinline__ bool sphere_phi_exceeds(const DevSphere &s, vec3 pHit) {
+    if (s.phiMax > 6.283f) {
+        if (pHit.y >= 0.f) return false;
+        if (pHit.x <= 0.f) return false;
+        if (-pHit.y > 1e-3f * pHit.x) return false;
+    }
+    float phi = det_atan2f(pHit.y, pHit.x);
+    if (phi < 0) phi += 2 * HPRT_PI;
+    return phi > s.phiMax;
+}
+
 // Quadric test shared by Sphere::Intersect and IntersectP (shapes/sphere.cpp:49-104 == :159-213).
 __device__ __noinline__ bool sphere_test(const DevSphere &s, const DRay &r, DRay *rayObj, vec3 *pHitOut, float *phiOut,
                                          float *tOut) {
@@ -141,20 +157,16 @@ __device__ __noinline__ bool sphere_test(const DevSphere &s, const DRay &r, DRay
     vec3 pHit = ray.o + ray.d * tHit.v;
     pHit = pHit * (s.radius / dist(pHit, vec3(0, 0, 0)));
     if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * s.radius;
-    float phi = det_atan2f(pHit.y, pHit.x);
-    if (phi < 0) phi += 2 * HPRT_PI;
-    if ((s.zMin > -s.radius && pHit.z < s.zMin) || (s.zMax < s.radius && pHit.z > s.zMax) || phi > s.phiMax) {
+    if ((s.zMin > -s.radius && pHit.z < s.zMin) || (s.zMax < s.radius && pHit.z > s.zMax) || sphere_phi_exceeds(s, pHit)) {
         if (tHit.v == t1.v) return false;
         if (t1.hi > ray.tMax) return false;
         tHit = t1;
         pHit = ray.o + ray.d * tHit.v;
         pHit = pHit * (s.radius / dist(pHit, vec3(0, 0, 0)));
         if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * s.radius;
-        phi = det_atan2f(pHit.y, pHit.x);
-        if (phi < 0) phi += 2 * HPRT_PI;
-        if ((s.zMin > -s.radius && pHit.z < s.zMin) || (s.zMax < s.radius && pHit.z > s.zMax) || phi > s.phiMax) return false;
+        if ((s.zMin > -s.radius && pHit.z < s.zMin) || (s.zMax < s.radius && pHit.z > s.zMax) || sphere_phi_exceeds(s, pHit)) return false;
     }
-    *rayObj = ray; *pHitOut = pHit; *phiOut = phi; *tOut = tHit.v;
+    *rayObj = ray; *pHitOut = pHit; *phiOut = 0.f; *tOut = tHit.v;   // phi itself is not needed downstream (u is unused)
     return true;
 }
 

@@ -105,10 +105,13 @@ __device__ __forceinline__ void wave_count_add(DevCounters *c, bool anyHit, cons
 // ---------------------------------------------------------------------------
 // Scheduling knobs of the persistent walk (defaults from a per-ray trace simulation of
 // killeroo-simple bounce rays; overridable through HPRT_TRACE_TUNE="R,P,K").
-struct TraceTune { int refillBelow, parkLimit, stepLimit; };
+struct TraceTune { int refillBelow, parkLimit, stepLimit, sphereLimit; };
 static TraceTune DefaultTraceTune() {
-    TraceTune t = {52, 24, 6};
-    if (const char *e = getenv("HPRT_TRACE_TUNE")) { int r, p, k; if (sscanf(e, "%d,%d,%d", &r, &p, &k) == 3) { t.refillBelow = r; t.parkLimit = p; t.stepLimit = k; } }
+    TraceTune t = {52, 24, 6, 20};
+    if (const char *e = getenv("HPRT_TRACE_TUNE")) {
+        int r, p, k, q = t.sphereLimit;
+        if (sscanf(e, "%d,%d,%d,%d", &r, &p, &k, &q) >= 3) { t.refillBelow = r; t.parkLimit = p; t.stepLimit = k; t.sphereLimit = q; }
+    }
     return t;
 }
 
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
     int sp = 0, cur = -1;
     int32_t prim = -1; float hb0 = 0.f, hb1 = 0.f, hb2 = 0.f;
     uint32_t leafBegin = 0u, leafEnd = 0u;      // parked leaf: primitives still to test
+    bool sphereWait = false; uint32_t sphereIdx = 0u;   // the primitive at leafBegin is a quadric awaiting its test
     int spill[HPRT_SPILL_STACK];
     bool moreWork = n > 0 && sc.nNodes > 0;
     // The wave draws rays from the global queue head in chunks (one atomic per `chunk` rays:
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                         negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
                         shear = ray_shear(rd);
                         sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
-                        leafBegin = leafEnd = 0u;
+                        leafBegin = leafEnd = 0u; sphereWait = false;
                         active = true;
                     }
                 }
@@ -243,34 +247,47 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                 ++steps;
                 if (steps >= tune.stepLimit || __popcll(__ballot(leafBegin != leafEnd)) >= tune.parkLimit) break;
             }
-            // phase 2: primitives of the parked leaves (wave-uniform loop over the longest leaf)
+            // phase 2: primitives of the parked leaves (wave-uniform loop over the longest leaf).
+            // Quadric primitives are expensive (interval arithmetic) and reached by lanes at
+            // different times, so a lane that meets one waits (sphereWait) until `sphereLimit`
+            // lanes wait or nothing else can run, and the test runs once for all of them.
             while (true) {
-                const bool pending = active && leafBegin != leafEnd;
-                if (__ballot(pending) == 0ull) break;
-                if (pending) {
+                const bool pending = active && leafBegin != leafEnd && !sphereWait;
+                if (__ballot(pending) != 0ull) {
+                    if (pending) {
+                        const uint32_t pi = leafBegin;
+                        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48, 0, 0);
+                        const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 16, 0, 0);
+                        const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 32, 0, 0);
+                        const uint32_t tag = v0.w;
+                        if ((tag & TAG_KIND_MASK) == 0u) {
+                            ++leafBegin;
+                            if (COUNT) ++cnt.tri;
+                            float b0, b1, b2, t;
+                            if (tri_test(vec3(__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z)),
+                                         vec3(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
+                                         vec3(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z)), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
+                                if (ANY_HIT) { hit = true; leafBegin = leafEnd; }
+                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = b0; hb1 = b1; hb2 = b2; }
+                            }
+                        } else { sphereWait = true; sphereIdx = v2.w; }
+                    }
+                    continue;
+                }
+                const int nWait = __popcll(__ballot(sphereWait));
+                if (nWait == 0) break;
+                const bool canWalk = __ballot(active && leafBegin == leafEnd && cur >= 0) != 0ull;
+                if (nWait < tune.sphereLimit && canWalk) break;      // keep waiting, let the others walk
+                if (sphereWait) {
                     const uint32_t pi = leafBegin++;
-                    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48, 0, 0);
-                    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 16, 0, 0);
-                    const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 32, 0, 0);
-                    const uint32_t tag = v0.w;
-                    if ((tag & TAG_KIND_MASK) == 0u) {
-                        if (COUNT) ++cnt.tri;
-                        float b0, b1, b2, t;
-                        if (tri_test(vec3(__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z)),
-                                     vec3(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
-                                     vec3(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z)), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
-                            if (ANY_HIT) { hit = true; leafBegin = leafEnd; }
-                            else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = b0; hb1 = b1; hb2 = b2; }
-                        }
-                    } else {
-                        if (COUNT) ++cnt.sphere;
-                        DRay rr; rr.o = ro; rr.tMax = rayTMax;
-                        rr.d = vec3(rays.dx[slot], rays.dy[slot], rays.dz[slot]);
-                        DRay robj; vec3 ph; float phi, t;
-                        if (sphere_test(sc.spheres[v2.w], rr, &robj, &ph, &phi, &t)) {
-                            if (ANY_HIT) { hit = true; leafBegin = leafEnd; }
-                            else { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; }
-                        }
+                    sphereWait = false;
+                    if (COUNT) ++cnt.sphere;
+                    DRay rr; rr.o = ro; rr.tMax = rayTMax;
+                    rr.d = vec3(rays.dx[slot], rays.dy[slot], rays.dz[slot]);
+                    DRay robj; vec3 ph; float phi, t;
+                    if (sphere_test(sc.spheres[sphereIdx], rr, &robj, &ph, &phi, &t)) {
+                        if (ANY_HIT) { hit = true; leafBegin = leafEnd; }
+                        else { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; }
                     }
                 }
             }
