@@ -232,10 +232,13 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
         const BvhNode *nd = (const BvhNode *)d->nodes;
         for (uint32_t i = 0; i < d->n_nodes; ++i) {
             uint32_t axis = nd[i].countAxis & 3u, cnt = nd[i].countAxis >> 2;
-            if (axis == 3u) { if (nd[i].offset < 0 || (uint64_t)nd[i].offset + cnt > d->n_prims) return SetError(HPRT_E_INVALID, "BVH leaf references primitives out of range"); }
+            if (axis == 3u) { if (nd[i].offset < 0 || cnt == 0 || (uint64_t)nd[i].offset + cnt > d->n_prims) return SetError(HPRT_E_INVALID, "BVH leaf is empty or references primitives out of range"); }
             else if (nd[i].offset <= (int32_t)i || (uint32_t)nd[i].offset >= d->n_nodes || i + 1 >= d->n_nodes) return SetError(HPRT_E_INVALID, "BVH interior node has an invalid child");
         }
         for (uint32_t i = 0; i < d->n_prims; ++i) if (d->prim_order[i] >= d->n_prims) return SetError(HPRT_E_INVALID, "prim_order entry out of range");
+        // the kernels address primitives and node pairs with 32-bit byte offsets
+        if ((uint64_t)d->n_prims * 48ull > 0xffffffffull || (uint64_t)d->n_nodes * 32ull + 64ull > 0xffffffffull)
+            return SetError(HPRT_E_UNSUPPORTED, "more than 89,478,485 primitives in one aggregate");
     }
     for (uint32_t l = 0; l < d->n_lights; ++l) {
         const HprtLightDesc &L = d->lights[l];
@@ -327,12 +330,36 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     }
     // Halton tables + 64-bit division magics
     const std::vector<uint16_t> &perms = HaltonPermutations();
+    // ---- child-pair layout of the BVH (device/dev_scene.h) ----
+    std::vector<DevPair> pairs;
+    if (d->n_nodes) {
+        const BvhNode *nd = (const BvhNode *)d->nodes;
+        std::vector<int32_t> ref(d->n_nodes);
+        int32_t nextPair = 1;
+        for (uint32_t i = 0; i < d->n_nodes; ++i) {
+            if ((nd[i].countAxis & 3u) == 3u) {
+                ref[i] = ~nd[i].offset;
+                const uint32_t last = (uint32_t)nd[i].offset + (nd[i].countAxis >> 2) - 1u;
+                tris[3 * (size_t)last].w = u2f(f2u(tris[3 * (size_t)last].w) | TAG_LAST);
+            } else ref[i] = nextPair++;
+        }
+        pairs.resize((size_t)nextPair);
+        auto fill = [&](DevPair &p, uint32_t c0, uint32_t c1, uint32_t meta) {
+            const BvhNode &a = nd[c0], &b = nd[c1];
+            p.x[0] = a.bmin[0]; p.x[1] = b.bmin[0]; p.x[2] = a.bmax[0]; p.x[3] = b.bmax[0];
+            p.y[0] = a.bmin[1]; p.y[1] = b.bmin[1]; p.y[2] = a.bmax[1]; p.y[3] = b.bmax[1];
+            p.z[0] = a.bmin[2]; p.z[1] = b.bmin[2]; p.z[2] = a.bmax[2]; p.z[3] = b.bmax[2];
+            p.ref0 = ref[c0]; p.ref1 = ref[c1]; p.meta = meta; p.pad = 0u;
+        };
+        fill(pairs[0], 0u, 0u, PAIR_SINGLE);
+        for (uint32_t i = 0; i < d->n_nodes; ++i)
+            if ((nd[i].countAxis & 3u) != 3u) fill(pairs[(size_t)ref[i]], i + 1u, (uint32_t)nd[i].offset, nd[i].countAxis & 3u);
+    }
     std::vector<int32_t> primes(PrimeTable().begin(), PrimeTable().end()), primeSums(PrimeSumTable().begin(), PrimeSumTable().end());
     std::vector<uint64_t> magic(primes.size());
     for (size_t i = 0; i < primes.size(); ++i) magic[i] = 0xffffffffffffffffull / (uint64_t)primes[i] + 1ull;
     // ---- upload ----
-    std::vector<BvhNode> nodeCopy((const BvhNode *)d->nodes, (const BvhNode *)d->nodes + d->n_nodes);
-    HIP_TRY(upload(sc->nodes, nodeCopy)); HIP_TRY(upload(sc->tris, tris)); HIP_TRY(upload(sc->primVtx, primVtx));
+    HIP_TRY(upload(sc->nodes, pairs)); HIP_TRY(upload(sc->tris, tris)); HIP_TRY(upload(sc->primVtx, primVtx));
     HIP_TRY(upload(sc->vN, vN)); HIP_TRY(upload(sc->vUV, vUV)); HIP_TRY(upload(sc->vS, vS));
     HIP_TRY(upload(sc->shapes, shapes)); HIP_TRY(upload(sc->materials, mats)); HIP_TRY(upload(sc->lights, lights));
     HIP_TRY(upload(sc->spheres, spheres)); HIP_TRY(upload(sc->lightFunc, func)); HIP_TRY(upload(sc->lightCdf, cdf));
@@ -342,7 +369,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     HIP_TRY(hipMemset(sc->counters.p, 0, sizeof(DevCounters)));
     HIP_TRY(sc->workCounter.alloc(64));
     DevScene &dv = sc->dev;
-    dv.nodes = sc->nodes.as<DevNode>(); dv.nNodes = d->n_nodes;
+    dv.pairs = sc->nodes.as<DevPair>(); dv.nPairs = (uint32_t)pairs.size();
     dv.tris = sc->tris.as<float4>(); dv.nPrims = d->n_prims;
     dv.primVtx = sc->primVtx.as<uint32_t>();
     dv.vN = sc->vN.as<float>(); dv.vUV = sc->vUV.as<float>(); dv.vS = sc->vS.as<float>();
@@ -356,7 +383,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     // Scene::worldBound + Bounds3::BoundingSphere (core/scene.h:56-66, core/geometry.h:980-983)
     dv.worldRadius = 0.f;
     if (d->n_nodes) {
-        const BvhNode &root = nodeCopy[0];
+        const BvhNode &root = ((const BvhNode *)d->nodes)[0];
         vec3 lo(root.bmin[0], root.bmin[1], root.bmin[2]), hi(root.bmax[0], root.bmax[1], root.bmax[2]);
         vec3 c = div_by(lo + hi, 2.f);
         bool inside = c.x >= lo.x && c.x <= hi.x && c.y >= lo.y && c.y <= hi.y && c.z >= lo.z && c.z <= hi.z;

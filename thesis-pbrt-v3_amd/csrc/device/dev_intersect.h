@@ -14,26 +14,28 @@ struct DRay { vec3 o, d; float tMax; };
 // Ray-only part of the watertight test (shapes/triangle.cpp:207-221): the permutation
 // and the shear coefficients depend on the ray alone, so they are computed once per ray
 // (same operations, same values) instead of once per triangle test.
-struct RayShear { int kx, ky, kz; float Sx, Sy, Sz; };
+struct RayShear { bool k0, k1; float Sx, Sy, Sz; };     // k0: kz == 0, k1: kz == 1
 __device__ __forceinline__ RayShear ray_shear(vec3 rd) {
     RayShear s;
-    s.kz = max_dim(vabs(rd));
-    s.kx = s.kz + 1; if (s.kx == 3) s.kx = 0;
-    s.ky = s.kx + 1; if (s.ky == 3) s.ky = 0;
-    const float dx = rd.get(s.kx), dy = rd.get(s.ky), dz = rd.get(s.kz);
+    const int kz = max_dim(vabs(rd));
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    const float dx = rd.get(kx), dy = rd.get(ky), dz = rd.get(kz);
+    s.k0 = kz == 0; s.k1 = kz == 1;
     s.Sx = -dx / dz; s.Sy = -dy / dz; s.Sz = 1.f / dz;
     return s;
 }
-__device__ __forceinline__ vec3 permute3(vec3 v, int kx, int ky, int kz) {
-    // kz == 0: (y,z,x); kz == 1: (z,x,y); kz == 2: (x,y,z)
-    return kz == 0 ? vec3(v.y, v.z, v.x) : (kz == 1 ? vec3(v.z, v.x, v.y) : v);
+// Permute(v, kx, ky, kz) as plain selects.  kz == 0: (y,z,x); kz == 1: (z,x,y); kz == 2: (x,y,z)
+__device__ __forceinline__ vec3 permute3(vec3 v, bool k0, bool k1) {
+    const float a = k1 ? v.z : v.x, b = k1 ? v.x : v.y, c = k1 ? v.y : v.z;
+    return vec3(k0 ? v.y : a, k0 ? v.z : b, k0 ? v.x : c);
 }
 __device__ __forceinline__ bool tri_test(vec3 p0, vec3 p1, vec3 p2, vec3 rayO, float rayTMax, const RayShear &sh, float *b0o,
                                          float *b1o, float *b2o, float *to) {
     vec3 p0t = p0 - rayO, p1t = p1 - rayO, p2t = p2 - rayO;
-    p0t = permute3(p0t, sh.kx, sh.ky, sh.kz);
-    p1t = permute3(p1t, sh.kx, sh.ky, sh.kz);
-    p2t = permute3(p2t, sh.kx, sh.ky, sh.kz);
+    p0t = permute3(p0t, sh.k0, sh.k1);
+    p1t = permute3(p1t, sh.k0, sh.k1);
+    p2t = permute3(p2t, sh.k0, sh.k1);
     const float Sx = sh.Sx, Sy = sh.Sy, Sz = sh.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
@@ -171,109 +173,18 @@ __device__ __noinline__ bool sphere_test(const DevSphere &s, const DRay &r, DRay
 }
 
 // ---- BVH walk ---------------------------------------------------------------
-// Per-lane traversal stack: the first LDS_STACK entries live in LDS, laid out
-// [entry][thread] so a wave's 64 lanes hit 64 consecutive dwords (no bank conflict);
-// deeper entries spill to a private array (the reference reserves 64 entries,
-// accelerators/bvh.cpp:362; the bundled scenes need <= 26).
-#define HPRT_LDS_STACK 24
-#define HPRT_SPILL_STACK 40
+// Per-lane traversal stack of {node reference, entry distance}: the first LDS_STACK
+// entries live in LDS, laid out [entry][thread] so a wave's 64 lanes hit 64 consecutive
+// 8-byte words; deeper entries spill to a private array (the reference reserves 64 entries,
+// accelerators/bvh.cpp:362).  Only children whose slabs are hit are pushed, so the depth in
+// use stays well below the tree depth.
+#define HPRT_LDS_STACK 16
+#define HPRT_SPILL_STACK 48
 #define HPRT_TRACE_BLOCK 256
 
 struct TraceCount { unsigned int fetched, entered, tri, sphere; };
 
-// "while-while" form of the reference's single loop (accelerators/bvh.cpp:363-394):
-// every lane walks interior nodes until it reaches a leaf that passes the slab test,
-// parks it, and the wave tests the parked leaves' primitives together.  Each lane still
-// performs exactly the reference's sequence of slab tests and primitive tests (the next
-// node is fetched only after the parked leaf has been processed, so a shrunken tMax is
-// seen by every later test) — only the interleaving across lanes changes, which is what
-// keeps the 64 lanes of a wavefront on the same instruction stream.
-template <bool ANY_HIT, bool COUNT>
-__device__ __forceinline__ bool bvh_walk(const DevScene &sc, DRay &ray, int *ldsStack, int32_t *primOut, float *b0o,
-                                         float *b1o, float *b2o, TraceCount &cnt) {
-    bool hit = false;
-    if (sc.nNodes == 0) return false;
-    const vec3 invDir(1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z);
-    const int negX = invDir.x < 0, negY = invDir.y < 0, negZ = invDir.z < 0;
-    const float robust = 1 + 2 * gamma_n(3);
-    const RayShear shear = ray_shear(ray.d);
-    int spill[HPRT_SPILL_STACK];
-    int sp = 0, cur = 0;
-    const float4 *nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
-    while (cur >= 0) {
-        uint32_t leafBegin = 0, leafEnd = 0;
-        // ---- phase 1: interior nodes until a leaf is entered or the stack runs dry ----
-        while (cur >= 0) {
-            const float4 n0 = nodes4[2 * cur], n1 = nodes4[2 * cur + 1];   // {min.xyz,max.x} {max.yz,offset,countAxis}
-            if (COUNT) ++cnt.fetched;
-            // Bounds3::IntersectP(ray, invDir, dirIsNeg), core/geometry.h:1754-1780
-            const float bminx = n0.x, bminy = n0.y, bminz = n0.z, bmaxx = n0.w, bmaxy = n1.x, bmaxz = n1.y;
-            float tMin = ((negX ? bmaxx : bminx) - ray.o.x) * invDir.x;
-            float tMax = ((negX ? bminx : bmaxx) - ray.o.x) * invDir.x;
-            float tyMin = ((negY ? bmaxy : bminy) - ray.o.y) * invDir.y;
-            float tyMax = ((negY ? bminy : bmaxy) - ray.o.y) * invDir.y;
-            tMax *= robust; tyMax *= robust;
-            bool inside = !(tMin > tyMax || tyMin > tMax);
-            if (inside) {
-                if (tyMin > tMin) tMin = tyMin;
-                if (tyMax < tMax) tMax = tyMax;
-                float tzMin = ((negZ ? bmaxz : bminz) - ray.o.z) * invDir.z;
-                float tzMax = ((negZ ? bminz : bmaxz) - ray.o.z) * invDir.z;
-                tzMax *= robust;
-                inside = !(tMin > tzMax || tzMin > tMax);
-                if (inside) {
-                    if (tzMin > tMin) tMin = tzMin;
-                    if (tzMax < tMax) tMax = tzMax;
-                    inside = (tMin < ray.tMax) && (tMax > 0);
-                }
-            }
-            const int32_t offset = __float_as_int(n1.z);
-            const uint32_t countAxis = __float_as_uint(n1.w);
-            const uint32_t axis = countAxis & 3u;
-            if (inside && axis != 3u) {
-                if (COUNT) ++cnt.entered;
-                const int isNeg = axis == 0 ? negX : (axis == 1 ? negY : negZ);
-                const int farNode = isNeg ? cur + 1 : offset;
-                const int nearNode = isNeg ? offset : cur + 1;
-                if (sp < HPRT_LDS_STACK) ldsStack[sp * HPRT_TRACE_BLOCK] = farNode;
-                else if (sp - HPRT_LDS_STACK < HPRT_SPILL_STACK) spill[sp - HPRT_LDS_STACK] = farNode;
-                ++sp;
-                cur = nearNode;
-                continue;
-            }
-            // leaf entered, or node missed: the next node comes off the stack
-            if (sp == 0) cur = -1;
-            else { --sp; cur = (sp < HPRT_LDS_STACK) ? ldsStack[sp * HPRT_TRACE_BLOCK] : spill[sp - HPRT_LDS_STACK]; }
-            if (inside) {
-                if (COUNT) ++cnt.entered;
-                leafBegin = (uint32_t)offset; leafEnd = (uint32_t)offset + (countAxis >> 2);
-                break;
-            }
-        }
-        // ---- phase 2: primitives of the parked leaf ----
-        for (uint32_t pi = leafBegin; pi < leafEnd; ++pi) {
-            const float4 v0 = sc.tris[3 * pi], v1 = sc.tris[3 * pi + 1], v2 = sc.tris[3 * pi + 2];
-            const uint32_t tag = __float_as_uint(v0.w);
-            if ((tag & TAG_KIND_MASK) == 0u) {
-                if (COUNT) ++cnt.tri;
-                float b0, b1, b2, t;
-                if (tri_test(vec3(v0.x, v0.y, v0.z), vec3(v1.x, v1.y, v1.z), vec3(v2.x, v2.y, v2.z), ray.o, ray.tMax, shear, &b0, &b1, &b2, &t)) {
-                    if (ANY_HIT) return true;
-                    if (!(tag & TAG_BOGUS)) {       // zero-area triangles: Triangle::Intersect rejects
-                        hit = true; ray.tMax = t; *primOut = (int32_t)pi; *b0o = b0; *b1o = b1; *b2o = b2;
-                    }
-                }
-            } else {
-                if (COUNT) ++cnt.sphere;
-                DRay ro; vec3 ph; float phi, t;
-                if (sphere_test(sc.spheres[__float_as_uint(v2.w)], ray, &ro, &ph, &phi, &t)) {
-                    if (ANY_HIT) return true;
-                    hit = true; ray.tMax = t; *primOut = (int32_t)pi; *b0o = 0.f; *b1o = 0.f; *b2o = 0.f;
-                }
-            }
-        }
-    }
-    return hit;
-}
+// `cur` of a lane: >= 0 interior pair, REF_NONE finished, otherwise ~(parked primitive index)
+__device__ __forceinline__ bool is_parked(int cur) { return (uint32_t)cur > 0x80000000u; }
 
 }  // namespace hprt

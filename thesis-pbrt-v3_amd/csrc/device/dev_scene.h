@@ -1,11 +1,16 @@
 // hprt device side — plain-data view of the scene in HBM, passed to kernels by value.
 //
 // HBM layout (all arrays 16-byte aligned, allocated once per scene):
-//   nodes      BvhNode[nNodes]      32 B/node; byte-identical to the reference's
-//                                    LinearBVHNode[] (accelerators/bvh.cpp:123-152).  A
-//                                    traversal step reads one node as two float4 (one 32-B
-//                                    sector: whole 64-B cache lines hold 2 nodes, a parent and
-//                                    its first child are adjacent).
+//   pairs      DevPair[nPairs]      64 B per INTERIOR node of the reference's LinearBVHNode[]
+//                                    (accelerators/bvh.cpp:123-152), holding the bounds of both
+//                                    children and references to them, so a traversal step is one
+//                                    64-B read (four 16-B requests, one cache-line half) that
+//                                    decides both children; leaves have no record of their own.
+//                                    Pair 0 is a synthetic parent of the root (PAIR_SINGLE) that
+//                                    carries the root's bounds test.  Pairs follow the depth-first
+//                                    order of the linear array, so a node and its first child
+//                                    stay adjacent.  The LinearBVHNode[] itself stays on the host
+//                                    (hprt_bvh_copy hands it out byte-identical).
 //   tris       float4[3*nPrims]     48 B/primitive in BVH (ordered) order, vertices
 //                                    pre-gathered: {p0,tag} {p1,shape} {p2,aux}.  Replaces the
 //                                    reference's primitive -> shape -> mesh -> index -> vertex
@@ -13,7 +18,9 @@
 //                                    contiguous 48-B read per triangle test.  tag bits: 0-1
 //                                    kind (0 triangle, 1 sphere), bit 2 "bogus" (zero-area
 //                                    triangle: Triangle::Intersect returns false at
-//                                    shapes/triangle.cpp:309-316, IntersectP does not).
+//                                    shapes/triangle.cpp:309-316, IntersectP does not), bit 3
+//                                    "last primitive of its leaf" (ends the leaf loop of
+//                                    accelerators/bvh.cpp:370-373 without a count).
 //                                    For spheres aux = sphere index.
 //   primVtx    uint32[3*nPrims]     global vertex ids of the ordered triangle (shading only)
 //   vN/vUV/vS  float[3|2|3 * nVtx]  shading attributes; a shape's presence bits say which
@@ -23,9 +30,14 @@
 
 namespace hprt {
 
-struct DevNode { float bmin[3], bmax[3]; int32_t offset; uint32_t countAxis; };
+// x/y/z: {lo child0, lo child1, hi child0, hi child1}; child0 = first child (node + 1),
+// child1 = secondChildOffset.  ref: >= 0 pair index of an interior child, ~firstPrimitive of a
+// leaf child.  meta: split axis (bits 0-1) | PAIR_SINGLE.
+struct DevPair { float x[4], y[4], z[4]; int32_t ref0, ref1; uint32_t meta, pad; };
+enum : uint32_t { PAIR_SINGLE = 4u };
+enum : int32_t { REF_NONE = (int32_t)0x80000000 };
 
-enum : uint32_t { TAG_KIND_MASK = 3u, TAG_SPHERE = 1u, TAG_BOGUS = 4u };
+enum : uint32_t { TAG_KIND_MASK = 3u, TAG_SPHERE = 1u, TAG_BOGUS = 4u, TAG_LAST = 8u };
 enum : uint32_t { SHAPE_FLIP = 1u, SHAPE_HAS_N = 2u, SHAPE_HAS_UV = 4u, SHAPE_HAS_S = 8u, SHAPE_REVERSE = 16u };
 
 struct DevShape { int32_t material, areaLight; uint32_t flags; int32_t sphere; };
@@ -34,7 +46,7 @@ struct DevLight { int32_t type; float pos[3]; float I[3]; int32_t shape; int32_t
 struct DevSphere { mat4 o2w, w2o; float radius, zMin, zMax, thetaMin, thetaMax, phiMax; };
 
 struct DevScene {
-    const DevNode *nodes; uint32_t nNodes;
+    const DevPair *pairs; uint32_t nPairs;
     const float4 *tris; uint32_t nPrims;
     const uint32_t *primVtx;
     const float *vN, *vUV, *vS;

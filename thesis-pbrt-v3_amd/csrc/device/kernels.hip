@@ -87,48 +87,96 @@ __device__ __forceinline__ void wave_count_add(DevCounters *c, bool anyHit, cons
 }
 
 // ---------------------------------------------------------------------------
-// k_trace: persistent wavefronts with dynamic ray fetch.
+// k_trace: persistent wavefronts with dynamic ray fetch over the child-pair layout.
 //
 // Incoherent rays have very uneven traversal lengths (killeroo-simple bounce rays: median
 // 7 nodes, mean 25, per-64-ray maximum 78), so a one-ray-per-lane kernel keeps ~1/3 of a
 // wavefront's lanes busy.  Here a wave owns 64 lane slots for its whole life: whenever
-// fewer than HPRT_REFILL_BELOW lanes still have a ray, the idle lanes draw the next rays
-// from the queue with ONE atomic per wave (ballot + mbcnt prefix) and join the walk.
-// Each lane runs the reference's loop (accelerators/bvh.cpp:363-394) unchanged, in the
-// "while-while" arrangement: interior nodes until a leaf is entered, then the wave tests
-// its parked leaves together.  A lane fetches its next node only after its parked leaf
-// has been processed, so every later slab/primitive test sees the shrunken tMax exactly
-// as in the reference.
+// fewer than `refillBelow` lanes still have a ray, the idle lanes draw the next rays
+// from the queue (ballot + mbcnt prefix over a per-wave chunk) and join the walk.
+//
+// A step reads one DevPair — an interior node with the bounds of BOTH children — and runs
+// the reference's slab test (core/geometry.h:1754-1780) on each.  The reference
+// (accelerators/bvh.cpp:363-394) pushes the far child unconditionally and tests its bounds
+// when it is popped, against the tMax of that later moment.  The slab part of that test
+// does not depend on tMax, so here it is evaluated at the parent: a far child whose slabs
+// miss is never pushed, one whose slabs hit is pushed together with its entry distance
+// tMin, and the pop re-applies exactly the one tMax-dependent comparison of the reference
+// (tMin < ray.tMax) with the tMax current at the pop.  The set and order of nodes entered
+// and of primitives tested — hence every hit, t and barycentric — is the reference's;
+// popped-and-culled nodes simply cost no memory access.  With COUNT the far child is always
+// pushed (tMin = +inf when its slabs miss) so that "fetched" counts the reference's pops.
+//
+// Lane state is one word, `cur`: >= 0 an interior pair to step, < 0 a parked primitive
+// (~index; the last primitive of a leaf carries TAG_LAST), REF_NONE when the ray is done.
+// The wave alternates two wave-uniform phases ("while-while"): pair steps until enough
+// lanes are parked, then the parked primitives together.  A lane moves on only after its
+// parked leaf has been processed, so every later test sees the shrunken tMax exactly as in
+// the reference.
 //
 // queue == nullptr means "slot = ray index"; tmax == nullptr means Infinity.  Closest hit
 // writes t, prim (ordered index or -1) and b0,b1,b2; any hit writes one byte.
 // ---------------------------------------------------------------------------
 // Scheduling knobs of the persistent walk (defaults from a per-ray trace simulation of
-// killeroo-simple bounce rays; overridable through HPRT_TRACE_TUNE="R,P,K").
-struct TraceTune { int refillBelow, parkLimit, stepLimit, sphereLimit; };
+// killeroo-simple bounce rays; overridable through HPRT_TRACE_TUNE="R,P,K,S").
+struct TraceTune { int refillBelow, parkLimit, stepLimit, sphereLimit, primMin; };
 static TraceTune DefaultTraceTune() {
-    TraceTune t = {52, 24, 6, 20};
+    TraceTune t = {52, 24, 6, 16, 1};
     if (const char *e = getenv("HPRT_TRACE_TUNE")) {
-        int r, p, k, q = t.sphereLimit;
-        if (sscanf(e, "%d,%d,%d,%d", &r, &p, &k, &q) >= 3) { t.refillBelow = r; t.parkLimit = p; t.stepLimit = k; t.sphereLimit = q; }
+        int r, p, k, q = t.sphereLimit, m = t.primMin;
+        if (sscanf(e, "%d,%d,%d,%d,%d", &r, &p, &k, &q, &m) >= 3) { t.refillBelow = r; t.parkLimit = p; t.stepLimit = k; t.sphereLimit = q; t.primMin = m; }
     }
     return t;
 }
 
-template <bool ANY_HIT, bool COUNT>
+// Bounds3::IntersectP(ray, invDir, dirIsNeg) (core/geometry.h:1754-1780) split into its
+// tMax-independent part (returned) and the entry distance for the `tMin < ray.tMax` part.
+// Branch-free: the reference's early returns only skip work, they do not change the values
+// that the later comparisons see.
+__device__ __forceinline__ bool slab_test(float lox, float hix, float loy, float hiy, float loz, float hiz, vec3 ro, vec3 invDir,
+                                          bool negX, bool negY, bool negZ, float robust, float *tEntry) {
+    float tMin = ((negX ? hix : lox) - ro.x) * invDir.x;
+    float tMax = ((negX ? lox : hix) - ro.x) * invDir.x;
+    const float tyMin = ((negY ? hiy : loy) - ro.y) * invDir.y;
+    float tyMax = ((negY ? loy : hiy) - ro.y) * invDir.y;
+    tMax *= robust; tyMax *= robust;
+    bool ok = !(tMin > tyMax || tyMin > tMax);
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    const float tzMin = ((negZ ? hiz : loz) - ro.z) * invDir.z;
+    float tzMax = ((negZ ? loz : hiz) - ro.z) * invDir.z;
+    tzMax *= robust;
+    ok = ok && !(tMin > tzMax || tzMin > tMax);
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMax) tMax = tzMax;
+    *tEntry = tMin;
+    return ok && (tMax > 0);
+}
+
+// Diagnostics (HPRT_TRACE_PROFILE=1, tools/trace_profile.py): per-phase cycles and lane occupancy,
+// summed over all waves.  [0] total [1] refill [2] pair phase [3] primitive phase [4] quadric
+// batches [5] pair iterations [6] pair lanes [7] primitive iterations [8] primitive lanes
+// [9] refills [10] refilled lanes [11] quadric batches [12] quadric lanes [13] waves.
+__device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31] any hit
+
+// MODE 0: plain; 1: work counters (HprtRenderStats); 2: phase profile (diagnostics only)
+template <bool ANY_HIT, int MODE>
 __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayPlanes rays, HitPlanes hits, uint8_t *occ,
                                                             DevCounters *counters, uint32_t *workCounter, uint32_t chunk, TraceTune tune) {
-    __shared__ int stackMem[HPRT_LDS_STACK * HPRT_TRACE_BLOCK];
-    int *const ldsStack = &stackMem[threadIdx.x];
+    constexpr bool COUNT = MODE == 1, PROF = MODE == 2;
+    unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long pfStart = PROF ? clock64() : 0ull;
+    __shared__ uint2 stackMem[HPRT_LDS_STACK * HPRT_TRACE_BLOCK];     // [entry][thread]: {ref, tMin}
+    uint2 *const ldsStack = &stackMem[threadIdx.x];
     const uint32_t n = countPtr ? *countPtr : countImm;
     const uint32_t lane = __lane_id();
-    // Nodes and primitives are fetched with buffer loads: a 32-bit per-lane byte offset against a
+    // Pairs and primitives are fetched with buffer loads: a 32-bit per-lane byte offset against a
     // wave-uniform descriptor (no 64-bit address arithmetic) and — unlike plain loads, which hipcc
-    // splits and sinks into the branches that consume each component — exactly two 16-byte
-    // requests per node and three per primitive, issued together.
-    const auto nodeRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.nodes, 0, (int)((size_t)sc.nNodes * 32u), 0x00020000);
-    const auto triRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.tris, 0, (int)((size_t)sc.nPrims * 48u), 0x00020000);
+    // splits and sinks into the branches that consume each component — exactly four 16-byte
+    // requests per pair and three per primitive, issued together.
+    const auto pairRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.pairs, 0, (int)(sc.nPairs * 64u), 0x00020000);
+    const auto triRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.tris, 0, (int)(sc.nPrims * 48u), 0x00020000);
     const float robust = 1 + 2 * gamma_n(3);
     TraceCount cnt = {0u, 0u, 0u, 0u};
     // per-lane ray state
@@ -136,19 +184,31 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
     uint32_t slot = 0;
     vec3 ro, invDir;
     float rayTMax = 0.f;
-    RayShear shear; shear.kx = shear.ky = shear.kz = 0; shear.Sx = shear.Sy = shear.Sz = 0.f;
-    int negX = 0, negY = 0, negZ = 0;
-    int sp = 0, cur = -1;
+    RayShear shear; shear.k0 = shear.k1 = false; shear.Sx = shear.Sy = shear.Sz = 0.f;
+    bool negX = false, negY = false, negZ = false;
+    int sp = 0, cur = REF_NONE;
     int32_t prim = -1; float hb0 = 0.f, hb1 = 0.f, hb2 = 0.f;
-    uint32_t leafBegin = 0u, leafEnd = 0u;      // parked leaf: primitives still to test
-    bool sphereWait = false; uint32_t sphereIdx = 0u;   // the primitive at leafBegin is a quadric awaiting its test
-    int spill[HPRT_SPILL_STACK];
-    bool moreWork = n > 0 && sc.nNodes > 0;
+    bool sphereWait = false; uint32_t sphereInfo = 0u;   // the parked primitive is a quadric awaiting its (batched) test
+    volatile uint32_t spillRef[HPRT_SPILL_STACK], spillT[HPRT_SPILL_STACK];   // volatile: keeps the rare scratch path out of the LDS one
+    bool moreWork = n > 0 && sc.nPairs > 0;
+
+    // nodesToVisit[--toVisitOffset] + the tMax-dependent part of the bounds test (see above)
+    auto pop = [&]() -> int {
+        while (sp > 0) {
+            --sp;
+            uint2 e;
+            if (sp < HPRT_LDS_STACK) e = ldsStack[sp * HPRT_TRACE_BLOCK]; else e = make_uint2(spillRef[sp - HPRT_LDS_STACK], spillT[sp - HPRT_LDS_STACK]);
+            if (COUNT) ++cnt.fetched;
+            if (__uint_as_float(e.y) < rayTMax) { if (COUNT) ++cnt.entered; return (int)e.x; }
+        }
+        return REF_NONE;
+    };
+
     // The wave draws rays from the global queue head in chunks (one atomic per `chunk` rays:
     // a single word retires only ~90 atomics per microsecond) and hands them to idle lanes
     // from its private range [localNext, localEnd).
     uint32_t localNext = 0u, localEnd = 0u;
-    if (sc.nNodes == 0 && n > 0) {
+    if (sc.nPairs == 0 && n > 0) {
         // empty aggregate: every ray misses (accelerators/bvh.cpp:355)
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
             const uint32_t s = queue ? queue[i] : i;
@@ -161,6 +221,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
         if (moreWork) {
             const unsigned long long idle = __ballot(!active);
             if (idle != 0ull) {
+                const unsigned long long pfT = PROF ? clock64() : 0ull;
                 if (localNext >= localEnd) {
                     uint32_t base = 0u;
                     if (lane == 0) base = atomicAdd(workCounter, chunk);
@@ -183,116 +244,128 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                         negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
                         shear = ray_shear(rd);
                         sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
-                        leafBegin = leafEnd = 0u; sphereWait = false;
+                        sphereWait = false;
                         active = true;
                     }
                 }
+                if (PROF) { pf[1] += clock64() - pfT; pf[9] += 1; pf[10] += __popcll(idle); }
             }
         }
         if (__ballot(active) == 0ull) break;
         // ---- walk until too few lanes are busy (or, with the queue drained, until all are done) ----
         while (true) {
-            // phase 1: wave-uniform loop; a lane takes node steps until it parks a leaf or runs dry.
-            // The phase ends early once `parkLimit` lanes hold a parked leaf (or after `stepLimit`
-            // steps) so that parked lanes do not idle behind the longest interior run.
+            // phase 1: wave-uniform loop of pair steps.  It ends early once `parkLimit` lanes hold a
+            // parked primitive (or after `stepLimit` steps) so that parked lanes do not idle behind
+            // the longest interior run.
             int steps = 0;
+            const unsigned long long pfT1 = PROF ? clock64() : 0ull;
             while (true) {
-                const bool trav = active && leafBegin == leafEnd && cur >= 0;
+                const bool trav = active && cur >= 0;
                 if (__ballot(trav) == 0ull) break;
+                if (PROF) { pf[5] += 1; pf[6] += __popcll(__ballot(trav)); }
                 if (trav) {
-                    const u32x4 n0 = __builtin_amdgcn_raw_buffer_load_b128(nodeRsrc, cur * 32, 0, 0);        // {min.xyz, max.x}
-                    const u32x4 n1 = __builtin_amdgcn_raw_buffer_load_b128(nodeRsrc, cur * 32 + 16, 0, 0);   // {max.yz, offset, countAxis}
-                    if (COUNT) ++cnt.fetched;
-                    // Bounds3::IntersectP(ray, invDir, dirIsNeg), core/geometry.h:1754-1780
-                    const float bminx = __uint_as_float(n0.x), bminy = __uint_as_float(n0.y), bminz = __uint_as_float(n0.z);
-                    const float bmaxx = __uint_as_float(n0.w), bmaxy = __uint_as_float(n1.x), bmaxz = __uint_as_float(n1.y);
-                    float tMin = ((negX ? bmaxx : bminx) - ro.x) * invDir.x;
-                    float tMax = ((negX ? bminx : bmaxx) - ro.x) * invDir.x;
-                    float tyMin = ((negY ? bmaxy : bminy) - ro.y) * invDir.y;
-                    float tyMax = ((negY ? bminy : bmaxy) - ro.y) * invDir.y;
-                    tMax *= robust; tyMax *= robust;
-                    bool inside = !(tMin > tyMax || tyMin > tMax);
-                    if (inside) {
-                        if (tyMin > tMin) tMin = tyMin;
-                        if (tyMax < tMax) tMax = tyMax;
-                        float tzMin = ((negZ ? bmaxz : bminz) - ro.z) * invDir.z;
-                        float tzMax = ((negZ ? bminz : bmaxz) - ro.z) * invDir.z;
-                        tzMax *= robust;
-                        inside = !(tMin > tzMax || tzMin > tMax);
-                        if (inside) {
-                            if (tzMin > tMin) tMin = tzMin;
-                            if (tzMax < tMax) tMax = tzMax;
-                            inside = (tMin < rayTMax) && (tMax > 0);
+                    const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(pairRsrc, cur * 64, 0, 0);        // x: {lo0, lo1, hi0, hi1}
+                    const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(pairRsrc, cur * 64 + 16, 0, 0);   // y
+                    const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(pairRsrc, cur * 64 + 32, 0, 0);   // z
+                    const u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(pairRsrc, cur * 64 + 48, 0, 0);   // {ref0, ref1, meta, -}
+                    float t0, t1;
+                    const bool s0 = slab_test(__uint_as_float(q0.x), __uint_as_float(q0.z), __uint_as_float(q1.x), __uint_as_float(q1.z),
+                                              __uint_as_float(q2.x), __uint_as_float(q2.z), ro, invDir, negX, negY, negZ, robust, &t0);
+                    const bool s1 = slab_test(__uint_as_float(q0.y), __uint_as_float(q0.w), __uint_as_float(q1.y), __uint_as_float(q1.w),
+                                              __uint_as_float(q2.y), __uint_as_float(q2.w), ro, invDir, negX, negY, negZ, robust, &t1);
+                    const uint32_t meta = q3.z;
+                    const uint32_t axis = meta & 3u;
+                    const bool single = (meta & PAIR_SINGLE) != 0u;
+                    // second child first when the ray is negative along the split axis (bvh.cpp:381-388)
+                    const bool isNeg = axis == 0 ? negX : (axis == 1 ? negY : negZ);
+                    const int refN = (int)(isNeg ? q3.y : q3.x), refF = (int)(isNeg ? q3.x : q3.y);
+                    const float tN = isNeg ? t1 : t0, tF = isNeg ? t0 : t1;
+                    const bool hitN = (isNeg ? s1 : s0) && tN < rayTMax;
+                    const bool slabF = (isNeg ? s0 : s1) && !single;
+                    if (COUNT) { ++cnt.fetched; if (hitN) ++cnt.entered; }
+                    if (hitN) {
+                        cur = refN;
+                        if (COUNT ? !single : (slabF && tF < rayTMax)) {
+                            const uint2 e = make_uint2((uint32_t)refF, __float_as_uint(slabF ? tF : HPRT_INF));
+                            if (sp < HPRT_LDS_STACK) { ldsStack[sp * HPRT_TRACE_BLOCK] = e; ++sp; }
+                            else if (sp < HPRT_LDS_STACK + HPRT_SPILL_STACK) { spillRef[sp - HPRT_LDS_STACK] = e.x; spillT[sp - HPRT_LDS_STACK] = e.y; ++sp; }
                         }
-                    }
-                    const int32_t offset = (int32_t)n1.z;
-                    const uint32_t countAxis = n1.w;
-                    const uint32_t axis = countAxis & 3u;
-                    if (COUNT && inside) ++cnt.entered;
-                    if (inside && axis != 3u) {
-                        const int isNeg = axis == 0 ? negX : (axis == 1 ? negY : negZ);
-                        const int farNode = isNeg ? cur + 1 : offset;
-                        const int nearNode = isNeg ? offset : cur + 1;
-                        if (sp < HPRT_LDS_STACK) ldsStack[sp * HPRT_TRACE_BLOCK] = farNode;
-                        else if (sp - HPRT_LDS_STACK < HPRT_SPILL_STACK) spill[sp - HPRT_LDS_STACK] = farNode;
-                        ++sp;
-                        cur = nearNode;
                     } else {
-                        // leaf entered, or node missed: the next node comes off the stack
-                        if (sp == 0) cur = -1;
-                        else { --sp; cur = (sp < HPRT_LDS_STACK) ? ldsStack[sp * HPRT_TRACE_BLOCK] : spill[sp - HPRT_LDS_STACK]; }
-                        if (inside) { leafBegin = (uint32_t)offset; leafEnd = (uint32_t)offset + (countAxis >> 2); }
+                        const bool hitF = slabF && tF < rayTMax;
+                        if (COUNT && !single) { ++cnt.fetched; if (hitF) ++cnt.entered; }
+                        cur = hitF ? refF : pop();
                     }
                 }
                 ++steps;
-                if (steps >= tune.stepLimit || __popcll(__ballot(leafBegin != leafEnd)) >= tune.parkLimit) break;
+                if (steps >= tune.stepLimit || __popcll(__ballot(active && is_parked(cur) && !sphereWait)) >= tune.parkLimit) break;
             }
-            // phase 2: primitives of the parked leaves (wave-uniform loop over the longest leaf).
+            const unsigned long long pfT2 = PROF ? clock64() : 0ull;
+            if (PROF) pf[2] += pfT2 - pfT1;
+            unsigned long long pfSphere = 0ull;
+            // phase 2: the parked primitives (wave-uniform loop over the longest leaf run).
             // Quadric primitives are expensive (interval arithmetic) and reached by lanes at
             // different times, so a lane that meets one waits (sphereWait) until `sphereLimit`
             // lanes wait or nothing else can run, and the test runs once for all of them.
             while (true) {
-                const bool pending = active && leafBegin != leafEnd && !sphereWait;
-                if (__ballot(pending) != 0ull) {
+                const bool pending = active && is_parked(cur) && !sphereWait;
+                const int nPending = __popcll(__ballot(pending));
+                // too few parked lanes for a primitive test to pay: let the others walk first
+                if (nPending != 0 && nPending < tune.primMin && __ballot(active && cur >= 0) != 0ull) break;
+                if (nPending != 0) {
+                    if (PROF) { pf[7] += 1; pf[8] += __popcll(__ballot(pending)); }
                     if (pending) {
-                        const uint32_t pi = leafBegin;
-                        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48, 0, 0);
-                        const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 16, 0, 0);
-                        const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 32, 0, 0);
+                        const uint32_t pi = (uint32_t)~cur;
+                        u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48, 0, 0);
+                        u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 16, 0, 0);
+                        u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 32, 0, 0);
+                        // keep the three requests whole and in flight together (hipcc otherwise narrows the
+                        // second one and sinks it behind the tag test: a second, dependent memory round trip)
+                        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2));
                         const uint32_t tag = v0.w;
                         if ((tag & TAG_KIND_MASK) == 0u) {
-                            ++leafBegin;
                             if (COUNT) ++cnt.tri;
                             float b0, b1, b2, t;
+                            bool done = false;
                             if (tri_test(vec3(__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z)),
                                          vec3(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
                                          vec3(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z)), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
-                                if (ANY_HIT) { hit = true; leafBegin = leafEnd; }
+                                if (ANY_HIT) { hit = true; done = true; }
                                 else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = b0; hb1 = b1; hb2 = b2; }
                             }
-                        } else { sphereWait = true; sphereIdx = v2.w; }
+                            if (done) cur = REF_NONE;
+                            else if (tag & TAG_LAST) cur = pop();
+                            else --cur;                                  // ~(pi + 1)
+                        } else { sphereWait = true; sphereInfo = v2.w | ((tag & TAG_LAST) ? 0x80000000u : 0u); }
                     }
                     continue;
                 }
                 const int nWait = __popcll(__ballot(sphereWait));
                 if (nWait == 0) break;
-                const bool canWalk = __ballot(active && leafBegin == leafEnd && cur >= 0) != 0ull;
+                const bool canWalk = __ballot(active && cur >= 0) != 0ull;
                 if (nWait < tune.sphereLimit && canWalk) break;      // keep waiting, let the others walk
+                const unsigned long long pfT3 = PROF ? clock64() : 0ull;
+                if (PROF) { pf[11] += 1; pf[12] += nWait; }
                 if (sphereWait) {
-                    const uint32_t pi = leafBegin++;
+                    const uint32_t pi = (uint32_t)~cur;
                     sphereWait = false;
                     if (COUNT) ++cnt.sphere;
                     DRay rr; rr.o = ro; rr.tMax = rayTMax;
                     rr.d = vec3(rays.dx[slot], rays.dy[slot], rays.dz[slot]);
                     DRay robj; vec3 ph; float phi, t;
-                    if (sphere_test(sc.spheres[sphereIdx], rr, &robj, &ph, &phi, &t)) {
-                        if (ANY_HIT) { hit = true; leafBegin = leafEnd; }
+                    bool done = false;
+                    if (sphere_test(sc.spheres[sphereInfo & 0x7fffffffu], rr, &robj, &ph, &phi, &t)) {
+                        if (ANY_HIT) { hit = true; done = true; }
                         else { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; }
                     }
+                    if (done) cur = REF_NONE;
+                    else if (sphereInfo & 0x80000000u) cur = pop();
+                    else --cur;
                 }
+                if (PROF) pfSphere += clock64() - pfT3;
             }
+            if (PROF) { pf[3] += clock64() - pfT2 - pfSphere; pf[4] += pfSphere; }
             // retire finished rays
-            if (active && ((cur < 0 && leafBegin == leafEnd) || (ANY_HIT && hit))) {
+            if (active && cur == REF_NONE) {
                 if (ANY_HIT) occ[slot] = hit ? 1 : 0;
                 else {
                     hits.t[slot] = rayTMax; hits.prim[slot] = hit ? prim : -1;
@@ -306,6 +379,11 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
         }
     }
     if (COUNT) wave_count_add(counters, ANY_HIT, cnt);
+    if (PROF && lane == 0) {
+        pf[0] = clock64() - pfStart;
+        for (int k = 0; k < 13; ++k) atomicAdd(&g_traceProf[(ANY_HIT ? 16 : 0) + k], pf[k]);
+        atomicAdd(&g_traceProf[(ANY_HIT ? 16 : 0) + 13], 1ull);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -711,13 +789,22 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     uint32_t chunk = gridItems / (nWaves * 4u);
     chunk = std::max(64u, std::min(512u, chunk)) & ~63u;
     static const TraceTune tune = DefaultTraceTune();
+    static const bool profile = getenv("HPRT_TRACE_PROFILE") != nullptr;
     if (anyHit) {
-        if (count) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
-        else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
+        if (count) hipLaunchKernelGGL((k_trace<true, 1>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
+        else if (profile) hipLaunchKernelGGL((k_trace<true, 2>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
+        else hipLaunchKernelGGL((k_trace<true, 0>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
     } else {
-        if (count) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
-        else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
+        if (count) hipLaunchKernelGGL((k_trace<false, 1>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
+        else if (profile) hipLaunchKernelGGL((k_trace<false, 2>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
+        else hipLaunchKernelGGL((k_trace<false, 0>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
     }
+}
+// diagnostics hook (not part of include/hprt.h): read and optionally clear the phase profile
+extern "C" __attribute__((visibility("default"))) int hprt_debug_trace_profile(unsigned long long out[32], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_traceProf), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_traceProf), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
 }
 void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, uint32_t s0, uint32_t nSlots) {
     if (nSlots) hipLaunchKernelGGL(k_generate, dim3(blocks_for(nSlots, 256)), dim3(256), 0, st, sc, rp, ps, s0, nSlots);
