@@ -121,7 +121,7 @@ __device__ __forceinline__ void wave_count_add(DevCounters *c, bool anyHit, cons
 // killeroo-simple bounce rays; overridable through HPRT_TRACE_TUNE="R,P,K,S").
 struct TraceTune { int refillBelow, parkLimit, stepLimit, sphereLimit, primMin; };
 static TraceTune DefaultTraceTune() {
-    TraceTune t = {52, 24, 6, 16, 1};
+    TraceTune t = {52, 24, 6, 16, 8};
     if (const char *e = getenv("HPRT_TRACE_TUNE")) {
         int r, p, k, q = t.sphereLimit, m = t.primMin;
         if (sscanf(e, "%d,%d,%d,%d,%d", &r, &p, &k, &q, &m) >= 3) { t.refillBelow = r; t.parkLimit = p; t.stepLimit = k; t.sphereLimit = q; t.primMin = m; }
