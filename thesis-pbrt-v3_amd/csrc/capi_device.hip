@@ -56,7 +56,8 @@ struct HprtScene {
     DevBuf nodes, tris, primVtx, vN, vUV, vS, shapes, materials, lights, spheres, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
     DevBuf counters, workCounter;
     // render-time state
-    DevBuf planes; size_t planeCapacity = 0;         // PathPlanes backing store
+    DevBuf planes;                                    // backing store of the path streams (Workspace)
+    DevBuf apiRays, apiHits;                          // stream copies of the plane-layout arguments of the *_device calls
     DevBuf queues, queueCounts;
     DevBuf pixelXY, pixelOffset, Lall, film, irregular, irregularCount;
     DevBuf exOwnBegin, exOwnSrc, exOwnSample, exOwnPre, exFDest, exFDestBegin, exFGroupBegin, exFSrc, exFSample;
@@ -113,33 +114,30 @@ struct PlaneAllocator {
     char *base; size_t off = 0, cap;
     template <typename T> T *take(size_t n) { off = (off + 255) & ~(size_t)255; T *p = (T *)(base + off); off += n * sizeof(T); return p; }
 };
-const size_t kPlaneBytesPerSlot = 4 * (7 + 5 + 6 + 1 + 7 + 6 + 5 + 10 + 1) + 1 + 64;   // generous upper bound incl. alignment slack
+// Device view of one batch's path data (device/kernels.h): two path streams used alternately
+// (a bounce reads one and writes the other), the hits of the stream being read, the per-vertex
+// streams and the finished paths' radiance by path id.
+struct Workspace {
+    PathStream path[2];
+    HitStream hit;
+    VertexStreams vs;
+    float4 *Lfinal;
+};
+// 16-byte words per stream index: 2 x (ray a,b + beta + L) + hit a + shadow a,b + mis a,b + misHit a
+// + pendLight/Mis/Beta + Lfinal; plus b2 (4 B), occluded (1 B) and alignment slack
+const size_t kPlaneBytesPerSlot = 16 * (2 * 4 + 1 + 2 + 2 + 1 + 3 + 1) + 4 + 1;
+size_t PlaneBytes(size_t n) { return n * kPlaneBytesPerSlot + 32 * 256; }
 
-void CarvePlanes(char *base, size_t n, PathPlanes *ps) {
+void CarvePlanes(char *base, size_t n, Workspace *w) {
     PlaneAllocator a{base, 0, 0};
-    auto rays = [&](RayPlanes &r, bool withT) {
-        r.ox = a.take<float>(n); r.oy = a.take<float>(n); r.oz = a.take<float>(n);
-        r.dx = a.take<float>(n); r.dy = a.take<float>(n); r.dz = a.take<float>(n);
-        r.tmax = withT ? a.take<float>(n) : nullptr;
-    };
-    rays(ps->ray, true);
-    ps->hit.t = a.take<float>(n); ps->hit.prim = a.take<int32_t>(n);
-    ps->hit.b0 = a.take<float>(n); ps->hit.b1 = a.take<float>(n); ps->hit.b2 = a.take<float>(n);
-    ps->betaR = a.take<float>(n); ps->betaG = a.take<float>(n); ps->betaB = a.take<float>(n);
-    ps->LR = a.take<float>(n); ps->LG = a.take<float>(n); ps->LB = a.take<float>(n);
-    ps->state = a.take<uint32_t>(n);
-    rays(ps->sh, true);
-    rays(ps->mis, false);
-    ps->misHit.t = a.take<float>(n); ps->misHit.prim = a.take<int32_t>(n);
-    ps->misHit.b0 = ps->misHit.b1 = ps->misHit.b2 = nullptr;
-    ps->occluded = a.take<uint8_t>(n);
-    ps->pendLightR = a.take<float>(n); ps->pendLightG = a.take<float>(n); ps->pendLightB = a.take<float>(n);
-    ps->pendMisR = a.take<float>(n); ps->pendMisG = a.take<float>(n); ps->pendMisB = a.take<float>(n);
-    ps->pendBetaR = a.take<float>(n); ps->pendBetaG = a.take<float>(n); ps->pendBetaB = a.take<float>(n);
-    ps->pendPdf = a.take<float>(n);
-    ps->pendInfo = a.take<uint32_t>(n);
+    auto rays = [&](RayStream &r) { r.a = a.take<float4>(n); r.b = a.take<float4>(n); };
+    for (int k = 0; k < 2; ++k) { rays(w->path[k].ray); w->path[k].beta = a.take<float4>(n); w->path[k].L = a.take<float4>(n); }
+    w->hit.a = a.take<float4>(n); w->hit.b2 = a.take<float>(n);
+    rays(w->vs.shadow); w->vs.occluded = a.take<uint8_t>(n);
+    rays(w->vs.mis); w->vs.misHit.a = a.take<float4>(n); w->vs.misHit.b2 = nullptr;
+    w->vs.pendLight = a.take<float4>(n); w->vs.pendMis = a.take<float4>(n); w->vs.pendBeta = a.take<float4>(n);
+    w->Lfinal = a.take<float4>(n);
 }
-size_t PlaneBytes(size_t n) { return n * kPlaneBytesPerSlot + 64 * 256; }
 
 struct EventTimer {
     std::vector<hipEvent_t> pool; size_t used = 0;
@@ -453,28 +451,42 @@ static void ReadCounters(HprtScene *s, bool anyHit, uint64_t out[4]) {
     if (!anyHit) { out[0] = c.nodesFetched; out[1] = c.nodesEntered; out[2] = c.triTests; out[3] = c.sphereTests; }
     else { out[0] = c.nodesFetchedP; out[1] = c.nodesEnteredP; out[2] = c.triTestsP; out[3] = c.sphereTestsP; }
 }
-static RayPlanes RaysFrom7(const float *d7, size_t n) {
-    RayPlanes r; float *p = const_cast<float *>(d7);
-    r.ox = p; r.oy = p + n; r.oz = p + 2 * n; r.dx = p + 3 * n; r.dy = p + 4 * n; r.dz = p + 5 * n; r.tmax = p + 6 * n;
-    return r;
+// Stream copies for the plane-layout entry points ([7][n] rays in; t, prim, [3][n] barycentrics out)
+static int ApiStreams(HprtScene *s, size_t n, RayStream *rays, HitStream *hits) {
+    HIP_TRY(s->apiRays.alloc(32 * n + 256));
+    HIP_TRY(s->apiHits.alloc(20 * n + 256));
+    rays->a = s->apiRays.as<float4>(); rays->b = rays->a + n;
+    hits->a = s->apiHits.as<float4>(); hits->b2 = (float *)(hits->a + n);
+    return HPRT_OK;
 }
 
 int hprt_intersect_device(HprtScene *s, size_t n, const float *d_rays7, float *d_t, int32_t *d_prim, float *d_bary3, void *stream) {
     if (!s || (n && (!d_rays7 || !d_t || !d_prim))) return SetError(HPRT_E_INVALID, "hprt_intersect_device: null argument");
-    if (n > 0xfffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
+    if (n > 0x7ffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
+    if (n == 0) return HPRT_OK;
     HIP_TRY(hipSetDevice(s->device));
-    HitPlanes h; h.t = d_t; h.prim = d_prim;
-    h.b0 = d_bary3; h.b1 = d_bary3 ? d_bary3 + n : nullptr; h.b2 = d_bary3 ? d_bary3 + 2 * n : nullptr;
-    LaunchTrace((hipStream_t)stream, s->dev, false, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(d_rays7, n), h, nullptr, nullptr, s->workCounter.as<uint32_t>());
+    RayStream rays; HitStream hits;
+    int rc = ApiStreams(s, n, &rays, &hits);
+    if (rc != HPRT_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    LaunchPackRays(st, d_rays7, (uint32_t)n, rays);
+    LaunchTrace(st, s->dev, false, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, rays, hits, nullptr, nullptr, s->workCounter.as<uint32_t>());
+    LaunchUnpackHits(st, hits, (uint32_t)n, d_t, d_prim, d_bary3);
     HIP_TRY(hipGetLastError());
     return HPRT_OK;
 }
 int hprt_occluded_device(HprtScene *s, size_t n, const float *d_rays7, uint8_t *d_occ, void *stream) {
     if (!s || (n && (!d_rays7 || !d_occ))) return SetError(HPRT_E_INVALID, "hprt_occluded_device: null argument");
-    if (n > 0xfffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
+    if (n > 0x7ffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
+    if (n == 0) return HPRT_OK;
     HIP_TRY(hipSetDevice(s->device));
-    HitPlanes h; h.t = nullptr; h.prim = nullptr; h.b0 = h.b1 = h.b2 = nullptr;
-    LaunchTrace((hipStream_t)stream, s->dev, true, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(d_rays7, n), h, d_occ, nullptr, s->workCounter.as<uint32_t>());
+    RayStream rays; HitStream hits;
+    int rc = ApiStreams(s, n, &rays, &hits);
+    if (rc != HPRT_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    LaunchPackRays(st, d_rays7, (uint32_t)n, rays);
+    HitStream none; none.a = nullptr; none.b2 = nullptr;
+    LaunchTrace(st, s->dev, true, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, rays, none, d_occ, nullptr, s->workCounter.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     return HPRT_OK;
 }
@@ -482,36 +494,37 @@ int hprt_occluded_device(HprtScene *s, size_t n, const float *d_rays7, uint8_t *
 static int TraceHost(HprtScene *s, bool anyHit, size_t n, const float *o, const float *d, const float *tmax, float *t_out,
                      int32_t *prim_out, float *bary_out, uint8_t *occ_out, uint64_t counters[4]) {
     if (!s || (n && (!o || !d || !tmax))) return SetError(HPRT_E_INVALID, "trace: null argument");
-    if (n > 0xfffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
+    if (n > 0x7ffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
     if (n == 0) { if (counters) memset(counters, 0, 32); return HPRT_OK; }
     HIP_TRY(hipSetDevice(s->device));
-    std::vector<float> soa(7 * n);
+    std::vector<float4> ra(n), rb(n);
     for (size_t i = 0; i < n; ++i) {
-        soa[i] = o[3 * i]; soa[n + i] = o[3 * i + 1]; soa[2 * n + i] = o[3 * i + 2];
-        soa[3 * n + i] = d[3 * i]; soa[4 * n + i] = d[3 * i + 1]; soa[5 * n + i] = d[3 * i + 2];
-        soa[6 * n + i] = tmax[i];
+        ra[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], tmax[i]);
+        rb[i] = make_float4(d[3 * i], d[3 * i + 1], d[3 * i + 2], 0.f);
     }
-    DevBuf rays, outT, outPrim, outB, outOcc;
-    HIP_TRY(rays.alloc(28 * n)); HIP_TRY(hipMemcpy(rays.p, soa.data(), 28 * n, hipMemcpyHostToDevice));
+    RayStream rays; HitStream hits;
+    int rc = ApiStreams(s, n, &rays, &hits);
+    if (rc != HPRT_OK) return rc;
+    HIP_TRY(hipMemcpy(rays.a, ra.data(), 16 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(rays.b, rb.data(), 16 * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(s->counters.p, 0, sizeof(DevCounters)));
     const bool count = counters != nullptr;
     if (!anyHit) {
-        HIP_TRY(outT.alloc(4 * n)); HIP_TRY(outPrim.alloc(4 * n)); HIP_TRY(outB.alloc(12 * n));
-        HitPlanes h; h.t = outT.as<float>(); h.prim = outPrim.as<int32_t>();
-        h.b0 = outB.as<float>(); h.b1 = h.b0 + n; h.b2 = h.b0 + 2 * n;
-        LaunchTrace(nullptr, s->dev, false, count, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(rays.as<float>(), n), h, nullptr, s->counters.as<DevCounters>(), s->workCounter.as<uint32_t>());
+        LaunchTrace(nullptr, s->dev, false, count, nullptr, nullptr, (uint32_t)n, (uint32_t)n, rays, hits, nullptr, s->counters.as<DevCounters>(), s->workCounter.as<uint32_t>());
         HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
-        if (t_out) HIP_TRY(hipMemcpy(t_out, outT.p, 4 * n, hipMemcpyDeviceToHost));
-        if (prim_out) HIP_TRY(hipMemcpy(prim_out, outPrim.p, 4 * n, hipMemcpyDeviceToHost));
-        if (bary_out) {
-            std::vector<float> b(3 * n);
-            HIP_TRY(hipMemcpy(b.data(), outB.p, 12 * n, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < n; ++i) { bary_out[3 * i] = b[i]; bary_out[3 * i + 1] = b[n + i]; bary_out[3 * i + 2] = b[2 * n + i]; }
+        std::vector<float4> ha(n); std::vector<float> hb2(n);
+        HIP_TRY(hipMemcpy(ha.data(), hits.a, 16 * n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hb2.data(), hits.b2, 4 * n, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+            if (t_out) t_out[i] = ha[i].x;
+            if (prim_out) memcpy(&prim_out[i], &ha[i].y, 4);
+            if (bary_out) { bary_out[3 * i] = ha[i].z; bary_out[3 * i + 1] = ha[i].w; bary_out[3 * i + 2] = hb2[i]; }
         }
     } else {
+        DevBuf outOcc;
         HIP_TRY(outOcc.alloc(n));
-        HitPlanes h; h.t = nullptr; h.prim = nullptr; h.b0 = h.b1 = h.b2 = nullptr;
-        LaunchTrace(nullptr, s->dev, true, count, nullptr, nullptr, (uint32_t)n, (uint32_t)n, RaysFrom7(rays.as<float>(), n), h, outOcc.as<uint8_t>(), s->counters.as<DevCounters>(), s->workCounter.as<uint32_t>());
+        HitStream none; none.a = nullptr; none.b2 = nullptr;
+        LaunchTrace(nullptr, s->dev, true, count, nullptr, nullptr, (uint32_t)n, (uint32_t)n, rays, none, outOcc.as<uint8_t>(), s->counters.as<DevCounters>(), s->workCounter.as<uint32_t>());
         HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
         if (occ_out) HIP_TRY(hipMemcpy(occ_out, outOcc.p, n, hipMemcpyDeviceToHost));
     }
@@ -534,35 +547,37 @@ namespace {
 struct BatchTimers { double extendMs = 0, occludedMs = 0; uint64_t extendLaunches = 0, occludedLaunches = 0, extendRays = 0, occludedRays = 0; };
 
 // Runs the bounce loop for one batch of nSlots freshly generated paths.
-int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const PathPlanes &ps, const QueueSet &qa, const QueueSet &qb,
+int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspace &w, const QueueSet &qa, const QueueSet &qb,
              const BinSet &bins, uint32_t s0, uint32_t nSlots, bool count, EventTimer &ev, BatchTimers *bt, HprtRenderStats *stats) {
-    LaunchGenerate(st, s->dev, rp, ps, s0, nSlots);
+    LaunchGenerate(st, s->dev, rp, w.path[0], s0, nSlots);
     const uint32_t *activeQ = nullptr; uint32_t active = nSlots;
     QueueSet q[2] = {qa, qb};
     DevCounters *ctr = s->counters.as<DevCounters>();
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evExt, evOcc;
     for (int bounce = 0; active > 0; ++bounce) {
         const QueueSet &cur = q[bounce & 1];
+        const PathStream &in = w.path[bounce & 1], &out = w.path[(bounce + 1) & 1];
         hipEvent_t e0 = ev.get(), e1 = ev.get();
         HIP_TRY(hipEventRecord(e0, st));
-        LaunchTrace(st, s->dev, false, count, activeQ, nullptr, active, active, ps.ray, ps.hit, nullptr, ctr, s->workCounter.as<uint32_t>());
+        LaunchTrace(st, s->dev, false, count, activeQ, nullptr, active, active, in.ray, w.hit, nullptr, ctr, s->workCounter.as<uint32_t>());
         HIP_TRY(hipEventRecord(e1, st));
         evExt.push_back({e0, e1}); bt->extendRays += active; ++bt->extendLaunches;
         stats->rays += active;
         HIP_TRY(hipMemsetAsync(cur.nextCount, 0, 4 * sizeof(uint32_t), st));   // the four counters are contiguous
         HIP_TRY(hipMemsetAsync(bins.count, 0, 4 * sizeof(uint32_t), st));
-        LaunchBin(st, s->dev, ps, activeQ, nullptr, active, active, rp.maxDepth, bins);
-        // one launch per material bin; grids are sized for the upper bound, surplus blocks exit on *count
+        LaunchBin(st, s->dev, in, w.hit, activeQ, nullptr, active, active, rp.maxDepth, bins, w.Lfinal);
+        HIP_TRY(hipMemcpyAsync(bins.count + 3, bins.count + 2, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));   // bin 2 before deferrals
+        // one launch per material bin; grids are sized for the upper bound, surplus blocks exit on the bin's count
         for (int mode = 0; mode < 3; ++mode)
-            LaunchShade(st, mode, s->dev, rp, ps, bins.q[mode], bins.count + mode, 0, active, s0, cur, bins);
+            LaunchShade(st, mode, s->dev, rp, in, w.hit, active, s0, out, w.vs, cur, bins, w.Lfinal);
         HIP_TRY(hipMemcpyAsync(s->hostCounts, cur.nextCount, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const uint32_t nNext = s->hostCounts[0], nShadow = s->hostCounts[1], nMis = s->hostCounts[2], nResolve = s->hostCounts[3];
         if (nShadow) {
             hipEvent_t a = ev.get(), b = ev.get();
             HIP_TRY(hipEventRecord(a, st));
-            HitPlanes none; none.t = nullptr; none.prim = nullptr; none.b0 = none.b1 = none.b2 = nullptr;
-            LaunchTrace(st, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, ps.sh, none, ps.occluded, ctr, s->workCounter.as<uint32_t>());
+            HitStream none; none.a = nullptr; none.b2 = nullptr;
+            LaunchTrace(st, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, w.vs.shadow, none, w.vs.occluded, ctr, s->workCounter.as<uint32_t>());
             HIP_TRY(hipEventRecord(b, st));
             evOcc.push_back({a, b}); bt->occludedRays += nShadow; ++bt->occludedLaunches;
             stats->shadow_rays += nShadow;
@@ -570,12 +585,12 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const PathPla
         if (nMis) {
             hipEvent_t a = ev.get(), b = ev.get();
             HIP_TRY(hipEventRecord(a, st));
-            LaunchTrace(st, s->dev, false, count, cur.mis, nullptr, nMis, nMis, ps.mis, ps.misHit, nullptr, ctr, s->workCounter.as<uint32_t>());
+            LaunchTrace(st, s->dev, false, count, cur.mis, nullptr, nMis, nMis, w.vs.mis, w.vs.misHit, nullptr, ctr, s->workCounter.as<uint32_t>());
             HIP_TRY(hipEventRecord(b, st));
             evExt.push_back({a, b}); bt->extendRays += nMis; ++bt->extendLaunches;
             stats->rays += nMis;
         }
-        if (nResolve) LaunchResolve(st, s->dev, ps, cur.resolve, cur.resolveCount, nResolve);
+        if (nResolve) LaunchResolve(st, s->dev, w.vs, out.L, w.Lfinal, cur.resolve, cur.resolveCount, nResolve);
         activeQ = cur.next; active = nNext;
         if (bounce > 250) break;
     }
@@ -587,10 +602,10 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const PathPla
     return HPRT_OK;
 }
 
-int EnsureWorkspace(HprtScene *s, size_t nSlots, PathPlanes *ps, QueueSet *qa, QueueSet *qb, BinSet *bins) {
+int EnsureWorkspace(HprtScene *s, size_t nSlots, Workspace *ps, QueueSet *qa, QueueSet *qb, BinSet *bins) {
     HIP_TRY(s->planes.alloc(PlaneBytes(nSlots)));
     CarvePlanes(s->planes.as<char>(), nSlots, ps);
-    HIP_TRY(s->queues.alloc(11 * nSlots * sizeof(uint32_t) + 4096));
+    HIP_TRY(s->queues.alloc(12 * nSlots * sizeof(uint32_t) + 4096));
     HIP_TRY(s->queueCounts.alloc(64 * sizeof(uint32_t)));
     uint32_t *qbase = s->queues.as<uint32_t>(), *cbase = s->queueCounts.as<uint32_t>();
     QueueSet *qs[2] = {qa, qb};
@@ -600,6 +615,7 @@ int EnsureWorkspace(HprtScene *s, size_t nSlots, PathPlanes *ps, QueueSet *qa, Q
         qs[k]->nextCount = cbase + 16 * k; qs[k]->shadowCount = cbase + 16 * k + 1; qs[k]->misCount = cbase + 16 * k + 2; qs[k]->resolveCount = cbase + 16 * k + 3;
     }
     for (int k = 0; k < 3; ++k) bins->q[k] = qbase + (8 + k) * nSlots;
+    bins->aux = qbase + 11 * nSlots;
     bins->count = cbase + 32;
     return HPRT_OK;
 }
@@ -637,11 +653,11 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     // ---- sizes ----
     const size_t lallBytes = 3ull * spp * nPix * sizeof(float);
     if (lallBytes > (96ull << 30)) return SetError(HPRT_E_UNSUPPORTED, "per-sample radiance store would exceed 96 GiB; render in several tile ranges");
-    uint32_t chunk = desc->spp_chunk > 0 ? (uint32_t)desc->spp_chunk : std::max<uint32_t>(1u, (uint32_t)((64u << 20) / std::max<uint32_t>(nPix, 1u)));   // ~64 M paths per wavefront batch (17 GB of path state)
+    uint32_t chunk = desc->spp_chunk > 0 ? (uint32_t)desc->spp_chunk : std::max<uint32_t>(1u, (uint32_t)((64u << 20) / std::max<uint32_t>(nPix, 1u)));   // ~64 M paths per wavefront batch (22 GB of path streams and queues)
     chunk = std::min(chunk, spp);
     if ((uint64_t)chunk * nPix > 0x7fffffffull) chunk = (uint32_t)(0x7fffffffull / nPix);
     const size_t maxSlots = (size_t)chunk * nPix;
-    PathPlanes ps; QueueSet qa, qb; BinSet bins;
+    Workspace ps; QueueSet qa, qb; BinSet bins;
     rc = EnsureWorkspace(s, maxSlots, &ps, &qa, &qb, &bins);
     if (rc != HPRT_OK) return rc;
     HIP_TRY(s->Lall.alloc(lallBytes));
@@ -729,7 +745,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
         const uint32_t c = std::min(chunk, spp - s0), nSlots = c * nPix;
         rc = RunBatch(s, st, rp, ps, qa, qb, bins, s0, nSlots, count, ev, &bt, stats);
         if (rc != HPRT_OK) return rc;
-        LaunchStoreRadiance(st, ps, LallR, LallG, LallB, nPix, s0, nSlots);
+        LaunchStoreRadiance(st, ps.Lfinal, LallR, LallG, LallB, nPix, s0, nSlots);
     }
     LaunchFilmOwn(st, rp, f.fg, LallR, LallG, LallB, spp, ex, film);
     LaunchFilmForeign(st, rp, f.fg, LallR, LallG, LallB, ex, film);
@@ -773,7 +789,7 @@ int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, c
         xy[i] = (uint32_t)px[i] | ((uint32_t)py[i] << 16);
         off[i] = (uint64_t)HaltonPixelOffset(f.hal, px[i], py[i]) + (uint64_t)sample[i] * (uint64_t)f.hal.sampleStride;
     }
-    PathPlanes ps; QueueSet qa, qb; BinSet bins;
+    Workspace ps; QueueSet qa, qb; BinSet bins;
     rc = EnsureWorkspace(s, n, &ps, &qa, &qb, &bins);
     if (rc != HPRT_OK) return rc;
     HIP_TRY(upload(s->pixelXY, xy)); HIP_TRY(upload(s->pixelOffset, off));
@@ -788,7 +804,7 @@ int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, c
     rc = RunBatch(s, nullptr, rp, ps, qa, qb, bins, 0, (uint32_t)n, false, ev, &bt, &stats);
     if (rc != HPRT_OK) return rc;
     float *LR = s->Lall.as<float>();
-    LaunchStoreRadiance(nullptr, ps, LR, LR + n, LR + 2 * n, (uint32_t)n, 0, (uint32_t)n);
+    LaunchStoreRadiance(nullptr, ps.Lfinal, LR, LR + n, LR + 2 * n, (uint32_t)n, 0, (uint32_t)n);
     HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
     std::vector<float> planes(3 * n);
     HIP_TRY(hipMemcpy(planes.data(), LR, 12 * n, hipMemcpyDeviceToHost));

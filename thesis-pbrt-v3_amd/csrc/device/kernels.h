@@ -5,28 +5,36 @@
 
 namespace hprt {
 
-struct RayPlanes { float *ox, *oy, *oz, *dx, *dy, *dz, *tmax; };      // SoA, indexed by slot
-struct HitPlanes { float *t; int32_t *prim; float *b0, *b1, *b2; };
-
-// Per-path state in HBM, one float/uint plane per field (coalesced when consecutive
-// lanes hold consecutive slots).
-struct PathPlanes {
-    RayPlanes ray;          // current path segment
-    HitPlanes hit;          // its closest hit
-    float *betaR, *betaG, *betaB, *LR, *LG, *LB;
-    uint32_t *state;        // sampler dimension (bits 0-7) | bounces (bits 8-15)
-    RayPlanes sh;           // shadow ray of the light sample
-    RayPlanes mis;          // BSDF-sampled MIS ray (tmax plane unused: Infinity)
-    HitPlanes misHit;
-    uint8_t *occluded;
-    float *pendLightR, *pendLightG, *pendLightB, *pendMisR, *pendMisG, *pendMisB, *pendBetaR, *pendBetaG, *pendBetaB, *pendPdf;
-    uint32_t *pendInfo;     // light number | bit30 shadow ray issued | bit31 MIS ray issued
+// Path data lives in HBM as STREAMS of 16-byte words: a lane reads or writes a whole word with
+// one request, and a shading pass writes its results at its own thread index, so consecutive
+// lanes touch consecutive words.  Index spaces are re-made every bounce: the paths that a bounce
+// shades are numbered 0..n-1 in shading order (matte bin, plastic bin, generic bin) and
+// everything that bounce produces — the next path segment, the shadow and MIS rays, the pending
+// light terms — is stored under that number; queues list the numbers that need a given pass
+// (in ascending runs, one per workgroup), so gathers stay almost sequential however thin the
+// paths become.
+struct RayStream { float4 *a, *b; };                 // a = {o.xyz, tMax}   b = {d.xyz, aux}
+struct HitStream { float4 *a; float *b2; };          // a = {t, prim, b0, b1}; b2 may be null
+struct PathStream {
+    RayStream ray;          // current path segment; ray.b.w = sampler dimension (bits 0-7) | bounces (bits 8-15)
+    float4 *beta;           // {beta.rgb, path id}   path id = sampleInBatch * nPix + pixel
+    float4 *L;              // {L.rgb, 1 if the path continues after this vertex else 0}
+};
+// What a shading pass leaves for the rest of its bounce, indexed like its output PathStream
+struct VertexStreams {
+    RayStream shadow; uint8_t *occluded;             // shadow ray of the light sample, its any-hit result
+    RayStream mis; HitStream misHit;                 // BSDF-sampled MIS ray, its closest hit (b2 unused)
+    float4 *pendLight;      // {light-sampling term rgb, info}   info: light number | bit30 shadow ray issued | bit31 MIS ray issued
+    float4 *pendMis;        // {BSDF-sampling term rgb, light pick pdf}
+    float4 *pendBeta;       // {beta before this vertex rgb, path id}
 };
 struct QueueSet {
     uint32_t *next, *shadow, *mis, *resolve;
     uint32_t *nextCount, *shadowCount, *misCount, *resolveCount;
 };
-struct BinSet { uint32_t *q[3]; uint32_t *count; };   // material bins: 0 matte, 1 plastic, 2 generic (count[3])
+// material bins: 0 matte, 1 plastic, 2 generic.  count[0..2] sizes, count[3] = size of bin 2 before
+// the specialised variants deferred vertices to it; aux[k] = output index of a deferred entry k.
+struct BinSet { uint32_t *q[3]; uint32_t *aux; uint32_t *count; };
 struct RenderParams {
     DevCamera cam;
     DevHalton hal;
@@ -54,17 +62,21 @@ struct FilmExtras {
 };
 
 void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
-                 uint32_t countImm, uint32_t gridItems, const RayPlanes &rays, const HitPlanes &hits, uint8_t *occ,
+                 uint32_t countImm, uint32_t gridItems, const RayStream &rays, const HitStream &hits, uint8_t *occ,
                  DevCounters *counters, uint32_t *workCounter);
-void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, uint32_t s0, uint32_t nSlots);
-void LaunchBin(hipStream_t st, const DevScene &sc, const PathPlanes &ps, const uint32_t *queue, const uint32_t *countPtr,
-               uint32_t countImm, uint32_t gridItems, int32_t maxDepth, const BinSet &bins);
-void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, const uint32_t *queue,
-                 const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, uint32_t s0, const QueueSet &q, const BinSet &bins);
-void LaunchResolve(hipStream_t st, const DevScene &sc, const PathPlanes &ps, const uint32_t *queue, const uint32_t *countPtr,
-                   uint32_t gridItems);
-void LaunchStoreRadiance(hipStream_t st, const PathPlanes &ps, float *LallR, float *LallG, float *LallB, uint32_t nPix, uint32_t s0,
+void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathStream &out, uint32_t s0, uint32_t nSlots);
+void LaunchBin(hipStream_t st, const DevScene &sc, const PathStream &in, const HitStream &hit, const uint32_t *queue,
+               const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, int32_t maxDepth, const BinSet &bins, float4 *Lfinal);
+void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathStream &in, const HitStream &hit,
+                 uint32_t gridItems, uint32_t s0, const PathStream &out, const VertexStreams &vs, const QueueSet &q,
+                 const BinSet &bins, float4 *Lfinal);
+void LaunchResolve(hipStream_t st, const DevScene &sc, const VertexStreams &vs, float4 *L, float4 *Lfinal, const uint32_t *queue,
+                   const uint32_t *countPtr, uint32_t gridItems);
+void LaunchStoreRadiance(hipStream_t st, const float4 *Lfinal, float *LallR, float *LallG, float *LallB, uint32_t nPix, uint32_t s0,
                          uint32_t nSlots);
+// the *_device entry points of include/hprt.h keep their plane layouts: [7][n] rays in, t / prim / [3][n] barycentrics out
+void LaunchPackRays(hipStream_t st, const float *rays7, uint32_t n, const RayStream &out);
+void LaunchUnpackHits(hipStream_t st, const HitStream &hits, uint32_t n, float *t, int32_t *prim, float *bary3);
 void LaunchFindIrregular(hipStream_t st, const DevScene &sc, const RenderParams &rp, const FilmGeom &fg, uint32_t spp, uint32_t *count,
                          uint32_t capacity, IrregularSample *out);
 void LaunchFilmOwn(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, const float *LallR, const float *LallG, const float *LallB,

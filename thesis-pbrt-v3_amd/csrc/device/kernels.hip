@@ -1,8 +1,8 @@
 // hprt device side — the wavefront path-tracing kernels (gfx950, wave64).
 //
-// One camera sample ("path") owns one SLOT in a set of SoA planes in HBM; kernels
-// communicate through queues of slot numbers built with wave-level ballot/prefix
-// compaction (one atomic per wave).  Per bounce:
+// Path data lives in streams of 16-byte words (kernels.h); kernels communicate through
+// queues of stream indices built with workgroup-level ballot/prefix compaction (one atomic
+// per queue and workgroup).  Per bounce:
 //     k_trace<closest>  path rays            BVHAccel::Intersect + Triangle::Intersect
 //     k_shade           Li loop body         PathIntegrator::Li (integrators/path.cpp:64-204),
 //                                            UniformSampleOneLight/EstimateDirect set-up
@@ -114,8 +114,8 @@ __device__ __forceinline__ void wave_count_add(DevCounters *c, bool anyHit, cons
 // parked leaf has been processed, so every later test sees the shrunken tMax exactly as in
 // the reference.
 //
-// queue == nullptr means "slot = ray index"; tmax == nullptr means Infinity.  Closest hit
-// writes t, prim (ordered index or -1) and b0,b1,b2; any hit writes one byte.
+// queue == nullptr means "slot = ray index".  Closest hit writes {t, prim (ordered index or
+// -1), b0, b1} and b2; any hit writes one byte.
 // ---------------------------------------------------------------------------
 // Scheduling knobs of the persistent walk (defaults from a per-ray trace simulation of
 // killeroo-simple bounce rays; overridable through HPRT_TRACE_TUNE="R,P,K,S").
@@ -162,7 +162,7 @@ __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31
 // MODE 0: plain; 1: work counters (HprtRenderStats); 2: phase profile (diagnostics only)
 template <bool ANY_HIT, int MODE>
 __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
-                                                            uint32_t countImm, RayPlanes rays, HitPlanes hits, uint8_t *occ,
+                                                            uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ,
                                                             DevCounters *counters, uint32_t *workCounter, uint32_t chunk, TraceTune tune) {
     constexpr bool COUNT = MODE == 1, PROF = MODE == 2;
     unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
             const uint32_t s = queue ? queue[i] : i;
             if (ANY_HIT) occ[s] = 0;
-            else { hits.t[s] = rays.tmax ? rays.tmax[s] : HPRT_INF; hits.prim[s] = -1; if (hits.b0) { hits.b0[s] = 0.f; hits.b1[s] = 0.f; hits.b2[s] = 0.f; } }
+            else { hits.a[s] = make_float4(rays.a[s].w, __int_as_float(-1), 0.f, 0.f); if (hits.b2) hits.b2[s] = 0.f; }
         }
     }
     while (true) {
@@ -237,9 +237,10 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                     const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                     if (idx < localEnd) {
                         slot = queue ? queue[idx] : idx;
-                        ro = vec3(rays.ox[slot], rays.oy[slot], rays.oz[slot]);
-                        const vec3 rd(rays.dx[slot], rays.dy[slot], rays.dz[slot]);
-                        rayTMax = rays.tmax ? rays.tmax[slot] : HPRT_INF;
+                        const float4 ra = rays.a[slot], rb = rays.b[slot];
+                        ro = vec3(ra.x, ra.y, ra.z);
+                        const vec3 rd(rb.x, rb.y, rb.z);
+                        rayTMax = ra.w;
                         invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
                         negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
                         shear = ray_shear(rd);
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                     sphereWait = false;
                     if (COUNT) ++cnt.sphere;
                     DRay rr; rr.o = ro; rr.tMax = rayTMax;
-                    rr.d = vec3(rays.dx[slot], rays.dy[slot], rays.dz[slot]);
+                    { const float4 rb = rays.b[slot]; rr.d = vec3(rb.x, rb.y, rb.z); }
                     DRay robj; vec3 ph; float phi, t;
                     bool done = false;
                     if (sphere_test(sc.spheres[sphereInfo & 0x7fffffffu], rr, &robj, &ph, &phi, &t)) {
@@ -368,8 +369,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
             if (active && cur == REF_NONE) {
                 if (ANY_HIT) occ[slot] = hit ? 1 : 0;
                 else {
-                    hits.t[slot] = rayTMax; hits.prim[slot] = hit ? prim : -1;
-                    if (hits.b0) { hits.b0[slot] = hb0; hits.b1[slot] = hb1; hits.b2[slot] = hb2; }
+                    hits.a[slot] = make_float4(rayTMax, __int_as_float(hit ? prim : -1), hb0, hb1);
+                    if (hits.b2) hits.b2[slot] = hb2;
                 }
                 active = false;
             }
@@ -388,10 +389,10 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
 
 // ---------------------------------------------------------------------------
 // k_generate: Sampler::GetCameraSample (core/sampler.cpp:46-52) + GenerateRayDifferential.
-// slot = sampleInChunk * nPix + pixelIndex, so consecutive lanes are consecutive pixels
-// of a 16x16 tile (coherent primary rays).
+// path id = sampleInChunk * nPix + pixelIndex, so consecutive lanes are consecutive pixels
+// of a 16x16 tile (coherent primary rays).  Bounce 0 uses the path id as stream index.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, PathPlanes ps, uint32_t s0, uint32_t nSlots) {
+__global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, PathStream out, uint32_t s0, uint32_t nSlots) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= nSlots) return;
     const uint32_t pix = slot % rp.nPix, sIdx = slot / rp.nPix;
@@ -404,12 +405,10 @@ __global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, 
     if (rp.cam.lensRadius > 0) { lu = halton_dim(sc, rp.hal, index, 3); lv = halton_dim(sc, rp.hal, index, 4); }
     DRay ray;
     camera_ray(rp.cam, fx, fy, lu, lv, &ray);
-    ps.ray.ox[slot] = ray.o.x; ps.ray.oy[slot] = ray.o.y; ps.ray.oz[slot] = ray.o.z;
-    ps.ray.dx[slot] = ray.d.x; ps.ray.dy[slot] = ray.d.y; ps.ray.dz[slot] = ray.d.z;
-    ps.ray.tmax[slot] = ray.tMax;
-    ps.betaR[slot] = 1.f; ps.betaG[slot] = 1.f; ps.betaB[slot] = 1.f;
-    ps.LR[slot] = 0.f; ps.LG[slot] = 0.f; ps.LB[slot] = 0.f;
-    ps.state[slot] = 5u;          // sampler dimension 5 (after pFilm, time, pLens), bounce 0
+    out.ray.a[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tMax);
+    out.ray.b[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(5u));   // sampler dimension 5 (after pFilm, time, pLens), bounce 0
+    out.beta[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(slot));
+    out.L[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
 }
 
 // ---------------------------------------------------------------------------
@@ -420,10 +419,11 @@ __global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, 
 //   bin 1  triangle with a plastic material     (Lambertian + Trowbridge-Reitz lobes)
 //   bin 2  anything else that still needs work  (sphere hits: emitter / quadric fill)
 // Paths that escaped the scene, or reached maxDepth (integrators/path.cpp:110), need no
-// shading and are dropped here; emitted radiance is only added at bounce 0 (path.cpp:97).
+// shading: they end here and hand their radiance to Lfinal[path id]; emitted radiance is
+// only added at bounce 0 (path.cpp:97).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathPlanes ps, const uint32_t *queue, const uint32_t *countPtr,
-                                              uint32_t countImm, int32_t maxDepth, BinSet bins) {
+__global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStream hit, const uint32_t *queue, const uint32_t *countPtr,
+                                              uint32_t countImm, int32_t maxDepth, BinSet bins, float4 *Lfinal) {
     __shared__ BlockAppendLds al;
     const uint32_t n = countPtr ? *countPtr : countImm;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -431,8 +431,8 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathPlanes ps, const 
     uint32_t slot = 0;
     if (i < n) {
         slot = queue ? queue[i] : i;
-        const int32_t prim = ps.hit.prim[slot];
-        const int bounces = (int)((ps.state[slot] >> 8) & 0xffu);
+        const int32_t prim = __float_as_int(hit.a[slot].y);
+        const int bounces = (int)((__float_as_uint(in.ray.b[slot].w) >> 8) & 0xffu);
         if (prim >= 0) {
             const uint32_t tag = __float_as_uint(sc.tris[3 * prim].w);
             const bool isTri = (tag & TAG_KIND_MASK) == 0u;
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathPlanes ps, const 
             else if (!isTri) bin = 2;
             else bin = sc.materials[sc.shapes[__float_as_uint(sc.tris[3 * prim + 1].w)].material].type == 1 ? 1 : 0;
         }
+        if (bin < 0) Lfinal[__float_as_uint(in.beta[slot].w)] = in.L[slot];      // the path ends here
     }
     uint32_t *const ctr[3] = {bins.count + 0, bins.count + 1, bins.count + 2};
     const bool pred[3] = {bin == 0, bin == 1, bin == 2};
@@ -451,41 +452,49 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathPlanes ps, const 
 }
 
 // ---------------------------------------------------------------------------
-// k_shade<MODE>: one lane per path of bin MODE.  Consumes the closest hit of the path ray.
+// k_shade<MODE>: one lane per path of bin MODE.  Consumes the closest hit of the path ray
+// (input streams, gathered through the bin's ascending index list) and writes everything it
+// produces at its own output index: bin 0 occupies [0, n0), bin 1 [n0, n0+n1), bin 2 follows.
 // ---------------------------------------------------------------------------
 // Specialised variants (MODE 0/1) run 1024-thread workgroups so that queue appends cost one
 // atomic per queue and workgroup; the rare generic variant keeps 256 threads (it needs more
 // registers than a 1024-thread workgroup can have).
 template <int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 256 : 1024) void k_shade(DevScene sc, RenderParams rp, PathPlanes ps, const uint32_t *queue,
-                                               const uint32_t *countPtr, uint32_t countImm, uint32_t s0, QueueSet q, BinSet bins) {
+__global__ __launch_bounds__(MODE == 2 ? 256 : 1024) void k_shade(DevScene sc, RenderParams rp, PathStream in, HitStream hit, uint32_t s0,
+                                               PathStream out, VertexStreams vs, QueueSet q, BinSet bins, float4 *Lfinal) {
     __shared__ HaltonLds hl;
     __shared__ BlockAppendLds al;
-    const uint32_t n = countPtr ? *countPtr : countImm;
-    if (blockIdx.x * blockDim.x >= n) return;      // whole block beyond the queue (grids are sized for the upper bound)
+    const uint32_t n = bins.count[MODE];
+    if (blockIdx.x * blockDim.x >= n) return;      // whole block beyond the bin (grids are sized for the upper bound)
     halton_lds_load(sc, &hl);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool wantNext = false, wantShadow = false, wantMis = false, wantResolve = false, defer = false;
-    uint32_t slot = 0;
+    uint32_t slot = 0;          // index in the input streams
+    uint32_t j = 0;             // index in the output streams
     if (i < n) {
-        slot = queue ? queue[i] : i;
-        const uint32_t st = ps.state[slot];
+        slot = bins.q[MODE][i];
+        j = (MODE == 0 ? 0u : MODE == 1 ? bins.count[0] : bins.count[0] + bins.count[1]) + i;
+        if (MODE == 2 && i >= bins.count[3]) j = bins.aux[i];       // deferred by a specialised variant: keeps that variant's index
+        const float4 rayA = in.ray.a[slot], rayB = in.ray.b[slot], beta4 = in.beta[slot], L4 = in.L[slot], hitA = hit.a[slot];
+        const uint32_t st = __float_as_uint(rayB.w);
         int dim = (int)(st & 0xffu);
         const int bounces = (int)((st >> 8) & 0xffu);
-        const uint32_t pix = slot % rp.nPix, sIdx = slot / rp.nPix;
+        const uint32_t pathId = __float_as_uint(beta4.w);
+        const uint32_t pix = pathId % rp.nPix, sIdx = pathId / rp.nPix;
         const uint64_t index = (uint64_t)rp.pixelOffset[pix] + (uint64_t)(s0 + sIdx) * (uint64_t)rp.hal.sampleStride;
-        const int32_t prim = ps.hit.prim[slot];
-        const vec3 rayO(ps.ray.ox[slot], ps.ray.oy[slot], ps.ray.oz[slot]);
-        const vec3 rayD(ps.ray.dx[slot], ps.ray.dy[slot], ps.ray.dz[slot]);
-        rgb beta(ps.betaR[slot], ps.betaG[slot], ps.betaB[slot]);
+        const int32_t prim = __float_as_int(hitA.y);
+        const vec3 rayO(rayA.x, rayA.y, rayA.z);
+        const vec3 rayD(rayB.x, rayB.y, rayB.z);
+        rgb beta(beta4.x, beta4.y, beta4.z);
+        rgb L(L4.x, L4.y, L4.z);
         const bool found = prim >= 0;
         DevSI si;
         if (found) {
             const float4 v0 = sc.tris[3 * prim];
             if (MODE != 2 || (__float_as_uint(v0.w) & TAG_KIND_MASK) == 0u)
-                fill_triangle(sc, (uint32_t)prim, ps.hit.b0[slot], ps.hit.b1[slot], ps.hit.b2[slot], rayD, &si);
+                fill_triangle(sc, (uint32_t)prim, hitA.z, hitA.w, hit.b2[slot], rayD, &si);
             else {
-                DRay r0; r0.o = rayO; r0.d = rayD; r0.tMax = ps.ray.tmax[slot];
+                DRay r0; r0.o = rayO; r0.d = rayD; r0.tMax = rayA.w;
                 float tt;
                 fill_sphere(sc, (int)__float_as_uint(sc.tris[3 * prim + 1].w), r0, &si, &tt);
             }
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 1024) void k_shade(DevScene sc, R
                 if (al >= 0) {
                     rgb Le = area_L(sc.lights[al], si.n, -rayD);
                     rgb add = beta * Le;
-                    ps.LR[slot] = ps.LR[slot] + add.r; ps.LG[slot] = ps.LG[slot] + add.g; ps.LB[slot] = ps.LB[slot] + add.b;
+                    L = rgb(L.r + add.r, L.g + add.g, L.b + add.b);
                 } else {
                     // L += beta * Spectrum(0): adds +0 (or -0) and leaves L's value unchanged
                 }
@@ -536,9 +545,8 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 1024) void k_shade(DevScene sc, R
                             vec3 origin = offset_ray_origin(it.p, it.pErr, it.n, pl.p - it.p);
                             vec3 target = offset_ray_origin(pl.p, pl.pErr, pl.n, origin - pl.p);
                             vec3 d = target - origin;
-                            ps.sh.ox[slot] = origin.x; ps.sh.oy[slot] = origin.y; ps.sh.oz[slot] = origin.z;
-                            ps.sh.dx[slot] = d.x; ps.sh.dy[slot] = d.y; ps.sh.dz[slot] = d.z;
-                            ps.sh.tmax[slot] = 1 - HPRT_SHADOW_EPS;
+                            vs.shadow.a[j] = make_float4(origin.x, origin.y, origin.z, 1 - HPRT_SHADOW_EPS);
+                            vs.shadow.b[j] = make_float4(d.x, d.y, d.z, 0.f);
                             if (isDelta) pendLight = f * Li / lightPdf;
                             else { float w = power_heuristic(lightPdf, scatteringPdf); pendLight = f * Li * w / lightPdf; }
                             wantShadow = true;
@@ -553,8 +561,8 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 1024) void k_shade(DevScene sc, R
                             if (lp != 0) {     // "if (lightPdf == 0) return Ld;" keeps the light-sampling term only
                                 float w = power_heuristic(scatteringPdf, lp);
                                 vec3 o = offset_ray_origin(si.p, si.pErr, si.n, wi);
-                                ps.mis.ox[slot] = o.x; ps.mis.oy[slot] = o.y; ps.mis.oz[slot] = o.z;
-                                ps.mis.dx[slot] = wi.x; ps.mis.dy[slot] = wi.y; ps.mis.dz[slot] = wi.z;
+                                vs.mis.a[j] = make_float4(o.x, o.y, o.z, HPRT_INF);
+                                vs.mis.b[j] = make_float4(wi.x, wi.y, wi.z, 0.f);
                                 // contribution if the ray reaches the light's emitting side: f * Li * Tr * weight / pdf
                                 rgb Lemit(light.I[0], light.I[1], light.I[2]);
                                 pendMis = f * Lemit * rgb(1.f) * w / scatteringPdf;
@@ -563,11 +571,10 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 1024) void k_shade(DevScene sc, R
                         }
                     }
                     if (wantShadow || wantMis) {
-                        ps.pendLightR[slot] = pendLight.r; ps.pendLightG[slot] = pendLight.g; ps.pendLightB[slot] = pendLight.b;
-                        ps.pendMisR[slot] = pendMis.r; ps.pendMisG[slot] = pendMis.g; ps.pendMisB[slot] = pendMis.b;
-                        ps.pendBetaR[slot] = beta.r; ps.pendBetaG[slot] = beta.g; ps.pendBetaB[slot] = beta.b;
-                        ps.pendPdf[slot] = pickPdf;
-                        ps.pendInfo[slot] = (uint32_t)lightNum | (wantShadow ? 0x40000000u : 0u) | (wantMis ? 0x80000000u : 0u);
+                        vs.pendLight[j] = make_float4(pendLight.r, pendLight.g, pendLight.b,
+                                                      __uint_as_float((uint32_t)lightNum | (wantShadow ? 0x40000000u : 0u) | (wantMis ? 0x80000000u : 0u)));
+                        vs.pendMis[j] = make_float4(pendMis.r, pendMis.g, pendMis.b, pickPdf);
+                        vs.pendBeta[j] = make_float4(beta.r, beta.g, beta.b, beta4.w);
                         wantResolve = true;
                     }
                     // neither ray: Ld == 0, "L += beta * 0 / pdf" leaves L unchanged
@@ -595,71 +602,83 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 1024) void k_shade(DevScene sc, R
                     else beta = beta / (1 - qv);
                 }
                 if (alive) {
-                    ps.ray.ox[slot] = o.x; ps.ray.oy[slot] = o.y; ps.ray.oz[slot] = o.z;
-                    ps.ray.dx[slot] = wi.x; ps.ray.dy[slot] = wi.y; ps.ray.dz[slot] = wi.z;
-                    ps.ray.tmax[slot] = HPRT_INF;
-                    ps.betaR[slot] = beta.r; ps.betaG[slot] = beta.g; ps.betaB[slot] = beta.b;
-                    ps.state[slot] = (uint32_t)dim | ((uint32_t)(bounces + 1) << 8);
+                    out.ray.a[j] = make_float4(o.x, o.y, o.z, HPRT_INF);
+                    out.ray.b[j] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((uint32_t)dim | ((uint32_t)(bounces + 1) << 8)));
+                    out.beta[j] = make_float4(beta.r, beta.g, beta.b, beta4.w);
                     wantNext = true;
                 }
             }
             }
         }
+        // Radiance so far: k_resolve adds this vertex's direct lighting to out.L[j] and, if the path
+        // stops here (w == 0), passes the sum on to Lfinal; without a pending term this lane does it.
+        if (!defer) {
+            if (wantNext || wantResolve) out.L[j] = make_float4(L.r, L.g, L.b, wantNext ? 1.f : 0.f);
+            else Lfinal[pathId] = make_float4(L.r, L.g, L.b, 0.f);
+        }
     }
     // queue appends in block-uniform control flow
-    if (MODE != 2) { const uint32_t p2 = wave_append(bins.count + 2, defer); if (defer) bins.q[2][p2] = slot; }   // (almost) never
+    if (MODE != 2) {   // (almost) never
+        const uint32_t p2 = wave_append(bins.count + 2, defer);
+        if (defer) { bins.q[2][p2] = slot; bins.aux[p2] = j; }
+    }
     uint32_t *const ctr[4] = {q.nextCount, q.shadowCount, q.misCount, q.resolveCount};
     const bool pred[4] = {wantNext, wantShadow, wantMis, wantResolve};
     uint32_t pos[4];
     block_append<4>(&al, ctr, pred, pos);
-    if (wantNext) q.next[pos[0]] = slot;
-    if (wantShadow) q.shadow[pos[1]] = slot;
-    if (wantMis) q.mis[pos[2]] = slot;
-    if (wantResolve) q.resolve[pos[3]] = slot;
+    if (wantNext) q.next[pos[0]] = j;
+    if (wantShadow) q.shadow[pos[1]] = j;
+    if (wantMis) q.mis[pos[2]] = j;
+    if (wantResolve) q.resolve[pos[3]] = j;
 }
 
 // ---------------------------------------------------------------------------
 // k_resolve: Ld = [unoccluded ? light term] + [MIS ray reached the light ? bsdf term];
 // L += beta * (Ld / lightPickPdf)   (core/integrator.cpp:106, integrators/path.cpp:132-137)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_resolve(DevScene sc, PathPlanes ps, const uint32_t *queue, const uint32_t *countPtr) {
+__global__ __launch_bounds__(256) void k_resolve(DevScene sc, VertexStreams vs, float4 *Lio, float4 *Lfinal, const uint32_t *queue,
+                                                 const uint32_t *countPtr) {
     const uint32_t n = *countPtr;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t slot = queue[i];
-    const uint32_t info = ps.pendInfo[slot];
+    const uint32_t j = queue[i];
+    const float4 pl = vs.pendLight[j], pm = vs.pendMis[j], pb = vs.pendBeta[j], L4 = Lio[j];
+    const uint32_t info = __float_as_uint(pl.w);
     const int lightNum = (int)(info & 0x3fffffffu);
     rgb Ld(0.f);
-    if ((info & 0x40000000u) && !ps.occluded[slot]) Ld = Ld + rgb(ps.pendLightR[slot], ps.pendLightG[slot], ps.pendLightB[slot]);
+    if ((info & 0x40000000u) && !vs.occluded[j]) Ld = Ld + rgb(pl.x, pl.y, pl.z);
     if (info & 0x80000000u) {
-        const int32_t prim = ps.misHit.prim[slot];
+        const int32_t prim = __float_as_int(vs.misHit.a[j].y);
         if (prim >= 0) {
             const int shapeId = (int)__float_as_uint(sc.tris[3 * prim + 1].w);
             if (sc.shapes[shapeId].areaLight == lightNum) {
                 // lightIsect.Le(-wi): the normal of the emitter at the hit (sphere emitters)
-                DRay r; r.o = vec3(ps.mis.ox[slot], ps.mis.oy[slot], ps.mis.oz[slot]);
-                r.d = vec3(ps.mis.dx[slot], ps.mis.dy[slot], ps.mis.dz[slot]); r.tMax = HPRT_INF;
+                const float4 ma = vs.mis.a[j], mb = vs.mis.b[j];
+                DRay r; r.o = vec3(ma.x, ma.y, ma.z); r.d = vec3(mb.x, mb.y, mb.z); r.tMax = HPRT_INF;
                 DevSI li; float tt;
                 if (fill_sphere(sc, shapeId, r, &li, &tt)) {
                     const DevLight light = sc.lights[lightNum];
-                    if (light.twoSided || dot(li.n, -r.d) > 0) Ld = Ld + rgb(ps.pendMisR[slot], ps.pendMisG[slot], ps.pendMisB[slot]);
+                    if (light.twoSided || dot(li.n, -r.d) > 0) Ld = Ld + rgb(pm.x, pm.y, pm.z);
                 }
             }
         }
     }
-    rgb add = rgb(ps.pendBetaR[slot], ps.pendBetaG[slot], ps.pendBetaB[slot]) * (Ld / ps.pendPdf[slot]);
-    ps.LR[slot] = ps.LR[slot] + add.r; ps.LG[slot] = ps.LG[slot] + add.g; ps.LB[slot] = ps.LB[slot] + add.b;
+    rgb add = rgb(pb.x, pb.y, pb.z) * (Ld / pm.w);
+    const float4 Lnew = make_float4(L4.x + add.r, L4.y + add.g, L4.z + add.b, L4.w);
+    if (L4.w != 0.f) Lio[j] = Lnew;                                   // the path goes on: radiance travels with it
+    else Lfinal[__float_as_uint(pb.w)] = Lnew;                        // last vertex of the path
 }
 
 // ---------------------------------------------------------------------------
 // k_store_radiance: radiance guards (core/integrator.cpp:300-321) and transfer of the
 // finished batch into the per-sample radiance store Lall[channel][sample][pixel].
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_store_radiance(PathPlanes ps, float *LallR, float *LallG, float *LallB, uint32_t nPix,
+__global__ __launch_bounds__(256) void k_store_radiance(const float4 *Lfinal, float *LallR, float *LallG, float *LallB, uint32_t nPix,
                                                          uint32_t s0, uint32_t nSlots) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= nSlots) return;
-    rgb L(ps.LR[slot], ps.LG[slot], ps.LB[slot]);
+    const float4 L4 = Lfinal[slot];
+    rgb L(L4.x, L4.y, L4.z);
     const float y = luminance(L);
     if (is_nan(L.r) || is_nan(L.g) || is_nan(L.b)) L = rgb(0.f);
     else if ((double)y < -1e-5) L = rgb(0.f);
@@ -777,7 +796,7 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
 static inline uint32_t blocks_for(size_t n, uint32_t bs) { return (uint32_t)((n + bs - 1) / bs); }
 
 void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
-                 uint32_t countImm, uint32_t gridItems, const RayPlanes &rays, const HitPlanes &hits, uint8_t *occ,
+                 uint32_t countImm, uint32_t gridItems, const RayStream &rays, const HitStream &hits, uint8_t *occ,
                  DevCounters *counters, uint32_t *workCounter) {
     if (gridItems == 0) return;
     (void)hipMemsetAsync(workCounter, 0, sizeof(uint32_t), st);
@@ -806,29 +825,50 @@ extern "C" __attribute__((visibility("default"))) int hprt_debug_trace_profile(u
     if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_traceProf), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
-void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, uint32_t s0, uint32_t nSlots) {
-    if (nSlots) hipLaunchKernelGGL(k_generate, dim3(blocks_for(nSlots, 256)), dim3(256), 0, st, sc, rp, ps, s0, nSlots);
+void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathStream &out, uint32_t s0, uint32_t nSlots) {
+    if (nSlots) hipLaunchKernelGGL(k_generate, dim3(blocks_for(nSlots, 256)), dim3(256), 0, st, sc, rp, out, s0, nSlots);
 }
-void LaunchBin(hipStream_t st, const DevScene &sc, const PathPlanes &ps, const uint32_t *queue, const uint32_t *countPtr,
-               uint32_t countImm, uint32_t gridItems, int32_t maxDepth, const BinSet &bins) {
-    if (gridItems) hipLaunchKernelGGL(k_bin, dim3(blocks_for(gridItems, 1024)), dim3(1024), 0, st, sc, ps, queue, countPtr, countImm, maxDepth, bins);
+void LaunchBin(hipStream_t st, const DevScene &sc, const PathStream &in, const HitStream &hit, const uint32_t *queue,
+               const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, int32_t maxDepth, const BinSet &bins, float4 *Lfinal) {
+    if (gridItems) hipLaunchKernelGGL(k_bin, dim3(blocks_for(gridItems, 1024)), dim3(1024), 0, st, sc, in, hit, queue, countPtr, countImm, maxDepth, bins, Lfinal);
 }
-void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathPlanes &ps, const uint32_t *queue,
-                 const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, uint32_t s0, const QueueSet &q, const BinSet &bins) {
-    if (!gridItems) return;
+void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathStream &in, const HitStream &hit,
+                 uint32_t gridItems, uint32_t s0, const PathStream &out, const VertexStreams &vs, const QueueSet &q,
+                 const BinSet &bins, float4 *Lfinal) {
+    if (gridItems == 0) return;
     const uint32_t bs = mode == 2 ? 256u : 1024u;
     dim3 grid(blocks_for(gridItems, bs)), block(bs);
-    if (mode == 0) hipLaunchKernelGGL((k_shade<0>), grid, block, 0, st, sc, rp, ps, queue, countPtr, countImm, s0, q, bins);
-    else if (mode == 1) hipLaunchKernelGGL((k_shade<1>), grid, block, 0, st, sc, rp, ps, queue, countPtr, countImm, s0, q, bins);
-    else hipLaunchKernelGGL((k_shade<2>), grid, block, 0, st, sc, rp, ps, queue, countPtr, countImm, s0, q, bins);
+    if (mode == 0) hipLaunchKernelGGL((k_shade<0>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal);
+    else if (mode == 1) hipLaunchKernelGGL((k_shade<1>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal);
+    else hipLaunchKernelGGL((k_shade<2>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal);
 }
-void LaunchResolve(hipStream_t st, const DevScene &sc, const PathPlanes &ps, const uint32_t *queue, const uint32_t *countPtr,
-                   uint32_t gridItems) {
-    if (gridItems) hipLaunchKernelGGL(k_resolve, dim3(blocks_for(gridItems, 256)), dim3(256), 0, st, sc, ps, queue, countPtr);
+void LaunchResolve(hipStream_t st, const DevScene &sc, const VertexStreams &vs, float4 *L, float4 *Lfinal, const uint32_t *queue,
+                   const uint32_t *countPtr, uint32_t gridItems) {
+    if (gridItems) hipLaunchKernelGGL(k_resolve, dim3(blocks_for(gridItems, 256)), dim3(256), 0, st, sc, vs, L, Lfinal, queue, countPtr);
 }
-void LaunchStoreRadiance(hipStream_t st, const PathPlanes &ps, float *LallR, float *LallG, float *LallB, uint32_t nPix, uint32_t s0,
+void LaunchStoreRadiance(hipStream_t st, const float4 *Lfinal, float *LallR, float *LallG, float *LallB, uint32_t nPix, uint32_t s0,
                          uint32_t nSlots) {
-    if (nSlots) hipLaunchKernelGGL(k_store_radiance, dim3(blocks_for(nSlots, 256)), dim3(256), 0, st, ps, LallR, LallG, LallB, nPix, s0, nSlots);
+    if (nSlots) hipLaunchKernelGGL(k_store_radiance, dim3(blocks_for(nSlots, 256)), dim3(256), 0, st, Lfinal, LallR, LallG, LallB, nPix, s0, nSlots);
+}
+__global__ __launch_bounds__(256) void k_pack_rays(const float *r7, uint32_t n, RayStream out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = n;
+    out.a[i] = make_float4(r7[i], r7[N + i], r7[2 * N + i], r7[6 * N + i]);
+    out.b[i] = make_float4(r7[3 * N + i], r7[4 * N + i], r7[5 * N + i], 0.f);
+}
+__global__ __launch_bounds__(256) void k_unpack_hits(HitStream h, uint32_t n, float *t, int32_t *prim, float *bary3) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = h.a[i];
+    t[i] = a.x; prim[i] = __float_as_int(a.y);
+    if (bary3) { const size_t N = n; bary3[i] = a.z; bary3[N + i] = a.w; bary3[2 * N + i] = h.b2[i]; }
+}
+void LaunchPackRays(hipStream_t st, const float *rays7, uint32_t n, const RayStream &out) {
+    if (n) hipLaunchKernelGGL(k_pack_rays, dim3(blocks_for(n, 256)), dim3(256), 0, st, rays7, n, out);
+}
+void LaunchUnpackHits(hipStream_t st, const HitStream &hits, uint32_t n, float *t, int32_t *prim, float *bary3) {
+    if (n) hipLaunchKernelGGL(k_unpack_hits, dim3(blocks_for(n, 256)), dim3(256), 0, st, hits, n, t, prim, bary3);
 }
 void LaunchFindIrregular(hipStream_t st, const DevScene &sc, const RenderParams &rp, const FilmGeom &fg, uint32_t spp, uint32_t *count,
                          uint32_t capacity, IrregularSample *out) {
