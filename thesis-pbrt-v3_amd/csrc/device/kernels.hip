@@ -426,6 +426,7 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
                                               uint32_t countImm, int32_t maxDepth, BinSet bins, float4 *Lfinal) {
     __shared__ BlockAppendLds al;
     const uint32_t n = countPtr ? *countPtr : countImm;
+    if (blockIdx.x * blockDim.x >= n) return;      // whole block beyond the queue (grids are sized for the batch)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     int bin = -1;
     uint32_t slot = 0;

@@ -3,7 +3,7 @@
 Units and gfx950 correction per MI355X_MICROARCH.md (HBM): both counters are in KiB;
 FETCH_SIZE reports half of the bytes of 16-B-per-lane reads on gfx950 and is doubled;
 WRITE_SIZE is taken as is.  The timed step's kernels are the non-counting template
-instantiations (k_trace<..., false>)."""
+instantiations (k_trace<..., 0>; <..., 1> is bench.py's untimed counting pass)."""
 import collections, csv, glob, json, sys
 root = sys.argv[1]
 agg = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "launches": 0})
