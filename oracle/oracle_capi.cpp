@@ -78,6 +78,31 @@ void orc_intersect(void *h, size_t n, const float *o, const float *d, const floa
     }
     if (counters13) export_counters(ctr, counters13);
 }
+// Same with the instance each hit went through (-1: none).  prim numbers the ordered primitives of
+// all aggregates: top level first, then object 0, 1, ...
+void orc_intersect_inst(void *h, size_t n, const float *o, const float *d, const float *tmax, float *t, int32_t *prim,
+                        int32_t *inst, float *bary, uint64_t *counters13) {
+    Renderer *r = (Renderer *)h;
+    Counters ctr;
+    for (size_t i = 0; i < n; ++i) {
+        Ray ray(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]);
+        SurfaceInteraction si; int ordered = -1;
+        bool hit = r->bvh.Intersect(ray, &si, ctr, &ordered);
+        t[i] = ray.tMax; prim[i] = hit ? ordered : -1; inst[i] = hit ? si.inst : -1;
+        bary[3 * i] = hit ? si.b0 : 0; bary[3 * i + 1] = hit ? si.b1 : 0; bary[3 * i + 2] = hit ? si.b2 : 0;
+    }
+    if (counters13) export_counters(ctr, counters13);
+}
+int orc_object_count(void *h) { return (int)((Renderer *)h)->objectBvh.size(); }
+void orc_object_bvh_info(void *h, int object, int *nNodes, int *nPrims) {
+    Renderer *r = (Renderer *)h;
+    *nNodes = (int)r->objectBvh[object].nodes.size(); *nPrims = (int)r->objectBvh[object].primOrder.size();
+}
+void orc_object_bvh_copy(void *h, int object, void *nodes, uint32_t *primOrder) {
+    Renderer *r = (Renderer *)h;
+    memcpy(nodes, r->objectBvh[object].nodes.data(), r->objectBvh[object].nodes.size() * sizeof(LinearBVHNode));
+    memcpy(primOrder, r->objectBvh[object].primOrder.data(), r->objectBvh[object].primOrder.size() * 4);
+}
 // Per-ray work of the closest-hit walk: nodes fetched and primitive tests (for SIMT-efficiency studies)
 void orc_intersect_work(void *h, size_t n, const float *o, const float *d, const float *tmax, uint32_t *nodes, uint32_t *prims) {
     Renderer *r = (Renderer *)h;

@@ -33,8 +33,10 @@ struct SurfaceInteraction {
     P2 uv;
     V3 dpdu, dpdv;
     struct { V3 n, dpdu, dpdv; } shading;
-    int prim = -1;        // creation-order primitive number
+    int prim = -1;        // creation-order primitive number (within its aggregate)
     int shape = -1;
+    int ordered = -1;     // ordered index of the hit primitive over all aggregates: top level first, then object 0, 1, ...
+    int inst = -1;        // instance the hit went through (Scene::instances), -1: none
     // barycentrics (triangles) kept for the per-ray golden vectors
     Float b0 = 0, b1 = 0, b2 = 0;
 };
@@ -345,12 +347,35 @@ static_assert(sizeof(LinearBVHNode) == 32, "LinearBVHNode must be 32 bytes");
 
 struct BVH {
     const Scene *scene = nullptr;
+    const std::vector<PrimRef> *plist = nullptr;      // the aggregate's primitives in creation order
+    const std::vector<BVH> *objects = nullptr;        // the object aggregates (for TransformedPrimitive entries)
+    uint32_t orderedBase = 0;                         // position of this aggregate in the all-aggregates ordered numbering
     std::vector<LinearBVHNode> nodes;
     std::vector<uint32_t> primOrder;      // ordered index -> creation-order prim number (primNumMapping)
     int maxDepth = 0, nLeaves = 0;
 
+    // Transform::operator()(const Bounds3f &), core/transform.cpp:238-249
+    static B3 XfBounds(const M44 &M, const V3 &lo, const V3 &hi) {
+        B3 ret; ret.pMin = ret.pMax = XfPoint(M, V3(lo.x, lo.y, lo.z));
+        ret = Union(ret, XfPoint(M, V3(hi.x, lo.y, lo.z)));
+        ret = Union(ret, XfPoint(M, V3(lo.x, hi.y, lo.z)));
+        ret = Union(ret, XfPoint(M, V3(lo.x, lo.y, hi.z)));
+        ret = Union(ret, XfPoint(M, V3(lo.x, hi.y, hi.z)));
+        ret = Union(ret, XfPoint(M, V3(hi.x, hi.y, lo.z)));
+        ret = Union(ret, XfPoint(M, V3(hi.x, lo.y, hi.z)));
+        ret = Union(ret, XfPoint(M, V3(hi.x, hi.y, hi.z)));
+        return ret;
+    }
     B3 PrimWorldBound(uint32_t primNum) const {
-        const PrimRef &pr = scene->prims[primNum];
+        const PrimRef &pr = (*plist)[primNum];
+        if (pr.shape < 0) {
+            // TransformedPrimitive::WorldBound (core/primitive.h:116-118): MotionBounds of a static transform
+            // is that transform applied to the wrapped primitive's bounds (BVHAccel::WorldBound, or the lone
+            // primitive's own bound — the same box, a one-leaf tree's root)
+            const Instance &in = scene->instances[pr.local];
+            const B3 ob = (*objects)[in.object].WorldBound();
+            return XfBounds(in.i2w, ob.pMin, ob.pMax);
+        }
         const ShapeRec &sh = scene->shapes[pr.shape];
         if (sh.kind == SHAPE_MESH) {   // shapes/triangle.cpp:180-186
             const Mesh &m = scene->meshes[sh.meshIndex];
@@ -358,17 +383,7 @@ struct BVH {
             return Union(B3(m.p[v[0]], m.p[v[1]]), m.p[v[2]]);
         } else {                       // core/shape.cpp:53 + transform.cpp:237-249, sphere.cpp:43-46
             const Sphere &s = scene->spheres[sh.sphereIndex];
-            V3 lo(-s.radius, -s.radius, s.zMin), hi(s.radius, s.radius, s.zMax);
-            const M44 &M = s.o2w;
-            B3 ret; ret.pMin = ret.pMax = XfPoint(M, V3(lo.x, lo.y, lo.z));
-            ret = Union(ret, XfPoint(M, V3(hi.x, lo.y, lo.z)));
-            ret = Union(ret, XfPoint(M, V3(lo.x, hi.y, lo.z)));
-            ret = Union(ret, XfPoint(M, V3(lo.x, lo.y, hi.z)));
-            ret = Union(ret, XfPoint(M, V3(lo.x, hi.y, hi.z)));
-            ret = Union(ret, XfPoint(M, V3(hi.x, hi.y, lo.z)));
-            ret = Union(ret, XfPoint(M, V3(hi.x, lo.y, hi.z)));
-            ret = Union(ret, XfPoint(M, V3(hi.x, hi.y, hi.z)));
-            return ret;
+            return XfBounds(s.o2w, V3(-s.radius, -s.radius, s.zMin), V3(s.radius, s.radius, s.zMax));
         }
     }
 
@@ -380,11 +395,11 @@ struct BVH {
     struct ToDo { BuildNode *node; int start, end; };
 
     // accelerators/bvh.cpp:155-185 + iterativeBuild :196-333 + flatten :335-350
-    void Build(const Scene *sc) {
-        scene = sc;
+    void Build(const Scene *sc, const std::vector<PrimRef> *prims, const std::vector<BVH> *objs, uint32_t base) {
+        scene = sc; plist = prims; objects = objs; orderedBase = base;
         const int maxPrimsInNode = smin(255, sc->prm.maxNodePrims);
         const int isectCost = sc->prm.isectCost, traversalCost = sc->prm.travCost;
-        size_t n = sc->prims.size();
+        size_t n = prims->size();
         nodes.clear(); primOrder.clear();
         if (n == 0) return;
         std::vector<PrimInfo> primitiveInfo(n);
@@ -543,10 +558,44 @@ struct BVH {
         return (tMin < ray.tMax) && (tMax > 0);
     }
 
+    // TransformedPrimitive::Intersect / IntersectP, core/primitive.cpp:77-102 (static transform:
+    // AnimatedTransform::Interpolate returns the start transform)
+    bool InstanceIntersect(int instIndex, const Ray &r, SurfaceInteraction *isect, Counters &ctr) const {
+        const Instance &in = scene->instances[instIndex];
+        Ray ray = XfRay(in.w2i, r);
+        const BVH &ob = (*objects)[in.object];
+        // ObjectInstance wraps an accelerator only around more than one primitive (core/api.cpp:1798-1806)
+        const bool intersects = ob.plist->size() > 1 ? ob.Intersect(ray, isect, ctr) : ob.PrimIntersect(0, ray, isect, ctr);
+        if (!intersects) return false;
+        r.tMax = ray.tMax;
+        if (!IsIdentity(in.i2w)) {
+            // Transform::operator()(const SurfaceInteraction &), core/transform.cpp:262-297
+            SurfaceInteraction si = *isect;
+            isect->p = XfPointErr2(in.i2w, si.p, si.pError, &isect->pError);
+            isect->n = Normalize(XfNormal(in.w2i, si.n));
+            isect->wo = Normalize(XfVector(in.i2w, si.wo));
+            isect->dpdu = XfVector(in.i2w, si.dpdu);
+            isect->dpdv = XfVector(in.i2w, si.dpdv);
+            isect->shading.n = Normalize(XfNormal(in.w2i, si.shading.n));
+            isect->shading.dpdu = XfVector(in.i2w, si.shading.dpdu);
+            isect->shading.dpdv = XfVector(in.i2w, si.shading.dpdv);
+            isect->shading.n = Faceforward(isect->shading.n, isect->n);
+        }
+        isect->inst = instIndex;
+        return true;
+    }
+    bool InstanceIntersectP(int instIndex, const Ray &r, Counters &ctr) const {
+        const Instance &in = scene->instances[instIndex];
+        Ray ray = XfRay(in.w2i, r);
+        const BVH &ob = (*objects)[in.object];
+        return ob.plist->size() > 1 ? ob.IntersectP(ray, ctr) : ob.PrimIntersectP(0, ray, ctr);
+    }
+
     // GeometricPrimitive::Intersect, core/primitive.cpp:123-138
     bool PrimIntersect(uint32_t ordered, const Ray &r, SurfaceInteraction *isect, Counters &ctr) const {
         uint32_t primNum = primOrder[ordered];
-        const PrimRef &pr = scene->prims[primNum];
+        const PrimRef &pr = (*plist)[primNum];
+        if (pr.shape < 0) return InstanceIntersect(pr.local, r, isect, ctr);
         const ShapeRec &sh = scene->shapes[pr.shape];
         bool flip = (sh.reverseOrientation != 0) ^ (sh.swapsHandedness != 0);
         Float tHit;
@@ -560,11 +609,14 @@ struct BVH {
         r.tMax = tHit;
         isect->prim = (int)primNum;
         isect->shape = pr.shape;
+        isect->ordered = (int)(orderedBase + ordered);
+        isect->inst = -1;
         return true;
     }
     bool PrimIntersectP(uint32_t ordered, const Ray &r, Counters &ctr) const {
         uint32_t primNum = primOrder[ordered];
-        const PrimRef &pr = scene->prims[primNum];
+        const PrimRef &pr = (*plist)[primNum];
+        if (pr.shape < 0) return InstanceIntersectP(pr.local, r, ctr);
         const ShapeRec &sh = scene->shapes[pr.shape];
         if (sh.kind == SHAPE_MESH) {
             const Mesh &m = scene->meshes[sh.meshIndex];
@@ -594,7 +646,7 @@ struct BVH {
                     for (uint32_t i = 0; i < node->nPrimitives(); ++i)
                         if (PrimIntersect(node->offset + i, ray, isect, ctr)) {
                             hit = true;
-                            if (orderedHit) *orderedHit = node->offset + i;
+                            if (orderedHit) *orderedHit = isect->ordered;
                         }
                     if (toVisitOffset == 0) break;
                     currentNodeIndex = nodesToVisit[--toVisitOffset];

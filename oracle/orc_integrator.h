@@ -259,7 +259,8 @@ struct Distribution1D {
 
 struct Renderer {
     Scene scene;
-    BVH bvh;
+    BVH bvh;                       // top-level aggregate
+    std::vector<BVH> objectBvh;    // one per object definition (core/api.cpp:1798-1806)
     Camera camera;
     Film film;
     Distribution1D lightDistrib;
@@ -274,7 +275,13 @@ struct Renderer {
             if (l.type == LIGHT_AREA && scene.shapes[l.shape].kind != SHAPE_SPHERE) {
                 *err = "area lights are supported on spheres only"; return false;
             }
-        bvh.Build(&scene);
+        objectBvh.resize(scene.objectPrims.size());
+        uint32_t base = (uint32_t)scene.prims.size();
+        for (size_t o = 0; o < objectBvh.size(); ++o) {
+            objectBvh[o].Build(&scene, &scene.objectPrims[o], &objectBvh, base);
+            base += (uint32_t)scene.objectPrims[o].size();
+        }
+        bvh.Build(&scene, &scene.prims, &objectBvh, 0);
         camera.Init(scene.prm);
         film.Init(scene.prm);
         if (scene.lights.size() > 1 && scene.prm.lightStrategy == 2) {

@@ -400,4 +400,25 @@ struct Ray {
     V3 operator()(Float t) const { return o + d * t; }
 };
 
+// Transform::IsIdentity, core/transform.h:148-155
+inline bool IsIdentity(const M44 &M) {
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) if (M.m[i][j] != (i == j ? 1.f : 0.f)) return false;
+    return true;
+}
+// Transform::operator()(const Ray &), core/transform.h:251-264: the origin moves to the edge of its
+// error bound and tMax shrinks by the same step
+inline Ray XfRay(const M44 &M, const Ray &r) {
+    V3 oError;
+    V3 o = XfPointErr(M, r.o, &oError);
+    V3 d = XfVector(M, r.d);
+    Float lengthSquared = d.LengthSquared();
+    Float tMax = r.tMax;
+    if (lengthSquared > 0) {
+        Float dt = Dot(Abs(d), oError) / lengthSquared;
+        o += d * dt;
+        tMax -= dt;
+    }
+    return Ray(o, d, tMax);
+}
+
 }  // namespace orc

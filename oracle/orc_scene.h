@@ -34,7 +34,8 @@ struct Sphere {
 struct ShapeRec {
     int kind, material, areaLight, reverseOrientation, swapsHandedness;
     int meshIndex, sphereIndex;   // into Scene::meshes / spheres
-    uint32_t firstPrim, nPrims;   // range in creation-order primitive numbering
+    uint32_t nPrims;
+    int object = -1;              // >= 0: defined inside ObjectBegin/ObjectEnd (core/api.cpp:1752-1774)
 };
 struct Light {
     int type;
@@ -54,9 +55,12 @@ struct SceneParams {
     int maxDepth; Float rrThreshold; int lightStrategy;
     int maxNodePrims, isectCost, travCost;
 };
-// One entry per primitive in creation order (what the reference's
-// renderOptions->primitives holds, core/api.cpp:1641-1649)
+// One entry per primitive of an aggregate in creation order (what the reference's
+// renderOptions->primitives / renderOptions->instances[name] hold, core/api.cpp:1638-1649):
+// shape >= 0: GeometricPrimitive over that shape's primitive `local`;
+// shape == -1: TransformedPrimitive, `local` indexes Scene::instances (core/api.cpp:1817-1819)
 struct PrimRef { int shape; int local; };
+struct Instance { int object; M44 i2w, w2i; };
 
 struct Scene {
     SceneParams prm;
@@ -65,7 +69,9 @@ struct Scene {
     std::vector<Mesh> meshes;
     std::vector<Sphere> spheres;
     std::vector<Light> lights;
-    std::vector<PrimRef> prims;
+    std::vector<PrimRef> prims;                          // top level
+    std::vector<std::vector<PrimRef>> objectPrims;       // per object definition
+    std::vector<Instance> instances;
 };
 
 struct Reader {
@@ -84,7 +90,7 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
     char magic[8]; r.raw(magic, 8);
     if (!r.ok || memcmp(magic, "HPRTSCN1", 8) != 0) { *err = "bad magic"; return false; }
     uint32_t version = r.u32();
-    if (version != 1) { *err = "bad version"; return false; }
+    if (version != 1 && version != 2) { *err = "bad version"; return false; }
     SceneParams &p = sc->prm;
     p.xres = r.i32(); p.yres = r.i32();
     for (int i = 0; i < 4; ++i) p.crop[i] = r.f32();
@@ -105,13 +111,11 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
         m.roughness = r.f32(); m.remap = r.i32();
     }
     sc->shapes.resize(nShapes);
-    uint32_t primCount = 0;
     for (uint32_t si = 0; si < nShapes; ++si) {
         ShapeRec &s = sc->shapes[si];
         s.kind = r.i32(); s.material = r.i32(); s.areaLight = r.i32();
         s.reverseOrientation = r.i32(); s.swapsHandedness = r.i32();
         s.meshIndex = s.sphereIndex = -1;
-        s.firstPrim = primCount;
         if (s.kind == SHAPE_MESH) {
             Mesh m;
             m.nTris = r.u32(); m.nVerts = r.u32();
@@ -135,8 +139,6 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
             s.nPrims = 1;
             sc->spheres.push_back(sp);
         } else { *err = "bad shape kind"; return false; }
-        for (uint32_t k = 0; k < s.nPrims; ++k) sc->prims.push_back(PrimRef{(int)si, (int)k});
-        primCount += s.nPrims;
     }
     sc->lights.resize(nLights);
     for (auto &l : sc->lights) {
@@ -144,6 +146,37 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
         float a[3]; r.raw(a, 12); l.pos = V3(a[0], a[1], a[2]);
         float b[3]; r.raw(b, 12); l.I = Spec(b[0], b[1], b[2]);
         l.shape = r.i32(); l.twoSided = r.i32();
+    }
+    // instancing section (version 2): objects, instances, creation order of the top level
+    auto addShapePrims = [&](std::vector<PrimRef> &dst, uint32_t si) {
+        for (uint32_t k = 0; k < sc->shapes[si].nPrims; ++k) dst.push_back(PrimRef{(int)si, (int)k});
+    };
+    if (version == 2) {
+        uint32_t nObjects = r.u32();
+        if (!r.ok || nObjects > (1u << 24)) { *err = "bad object count"; return false; }
+        sc->objectPrims.resize(nObjects);
+        for (uint32_t si = 0; si < nShapes; ++si) {
+            int o = r.i32();
+            if (o < -1 || o >= (int)nObjects) { *err = "bad object index"; return false; }
+            sc->shapes[si].object = o;
+            if (o >= 0) addShapePrims(sc->objectPrims[o], si);
+        }
+        uint32_t nInst = r.u32();
+        if (!r.ok || nInst > (1u << 28)) { *err = "bad instance count"; return false; }
+        sc->instances.resize(nInst);
+        for (auto &in : sc->instances) {
+            in.object = r.i32(); r.raw(in.i2w.m, 64); r.raw(in.w2i.m, 64);
+            if (in.object < 0 || in.object >= (int)nObjects) { *err = "bad instance object"; return false; }
+        }
+        uint32_t nTop = r.u32();
+        if (!r.ok || nTop > (1u << 28)) { *err = "bad top-level list"; return false; }
+        for (uint32_t t = 0; t < nTop; ++t) {
+            int kind = r.i32(); uint32_t index = r.u32();
+            if (kind == 0) { if (index >= nShapes) { *err = "bad top-level item"; return false; } addShapePrims(sc->prims, index); }
+            else { if (kind != 1 || index >= nInst) { *err = "bad top-level item"; return false; } sc->prims.push_back(PrimRef{-1, (int)index}); }
+        }
+    } else {
+        for (uint32_t si = 0; si < nShapes; ++si) addShapePrims(sc->prims, si);
     }
     if (!r.ok) { *err = "truncated file"; return false; }
     return true;

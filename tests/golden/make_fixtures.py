@@ -10,6 +10,14 @@ gets the resulting files with the repository snapshot.
                          (scenes/killeroo-simple.png, 8 spp, 8-bit sRGB) as a uint8 array —
                          a data file the reference ships as its regression image
                          (scripts/render.sh:4).
+  simple_instanced.hprt  baked scene of scenes/simple (eight spheres in one object definition,
+                         one ObjectInstance, distant light) — the reference's object-instancing
+                         scene — with the camera and light of the version its checked-in render
+                         shows: eye (-5,0,0) and light from (-1,0,0), the values the previous
+                         revision of that scene carries (scenes/old/simple-bvh-all.pbrt:1,22).
+  simple_8spp_srgb8.npz  scenes/simple.png (8 spp, 8-bit sRGB) as a uint8 array.  With the two
+                         values above the oracle reproduces it bit for bit; with the current
+                         scenes/simple text (eye (-5,-5,0)) it shows a different view.
 """
 import importlib
 import os
@@ -32,6 +40,17 @@ def main():
     from PIL import Image
     png = np.asarray(Image.open(os.path.join(REF, "killeroo-simple.png")).convert("RGB"))
     np.savez_compressed(os.path.join(HERE, "killeroo_simple_8spp_srgb8.npz"), srgb8=png)
+    import tempfile
+    text = open(os.path.join(REF, "simple")).read()
+    text = text.replace("LookAt -5 -5 0", "LookAt -5 0 0").replace('"point from" [-1 -1 0]', '"point from" [-1 0 0]')
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "simple.pbrt")
+        open(p, "w").write(text)
+        m = hprt.Model.parse(p, {"$acc": '"bvh"'})
+    print("simple:", m.counts(), m.warnings())
+    m.save(os.path.join(HERE, "simple_instanced.hprt"))
+    png = np.asarray(Image.open(os.path.join(REF, "simple.png")).convert("RGB"))
+    np.savez_compressed(os.path.join(HERE, "simple_8spp_srgb8.npz"), srgb8=png)
 
 
 if __name__ == "__main__":

@@ -37,6 +37,10 @@ def _load():
     lib.orc_bvh_info.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.orc_bvh_copy.argtypes = [vp, vp, vp]
     lib.orc_intersect.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]
+    lib.orc_intersect_inst.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.orc_object_count.argtypes = [vp]
+    lib.orc_object_bvh_info.argtypes = [vp, C.c_int, vp, vp]
+    lib.orc_object_bvh_copy.argtypes = [vp, C.c_int, vp, vp]
     lib.orc_intersect_full.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp]
     lib.orc_occluded.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp]
     lib.orc_pcg32.argtypes = [C.c_int, vp]
@@ -106,6 +110,25 @@ class OracleScene:
         ctr = np.zeros(13, np.uint64)
         lib.orc_intersect(self._h, n, _p(o), _p(d), _p(tmax), _p(t), _p(prim), _p(bary), _p(ctr))
         return t, prim, bary, dict(zip(COUNTER_NAMES, [int(x) for x in ctr]))
+
+    def intersect_inst(self, o, d, tmax):
+        """closest hit with the instance it went through: (t, prim over all aggregates, inst, bary, counters)"""
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32); tmax = np.ascontiguousarray(tmax, np.float32)
+        n = tmax.shape[0]
+        t = np.zeros(n, np.float32); prim = np.zeros(n, np.int32); inst = np.zeros(n, np.int32); bary = np.zeros((n, 3), np.float32)
+        ctr = np.zeros(13, np.uint64)
+        lib.orc_intersect_inst(self._h, n, _p(o), _p(d), _p(tmax), _p(t), _p(prim), _p(inst), _p(bary), _p(ctr))
+        return t, prim, inst, bary, dict(zip(COUNTER_NAMES, [int(x) for x in ctr]))
+
+    def object_bvh_arrays(self):
+        out = []
+        for k in range(lib.orc_object_count(self._h)):
+            nn, npr = C.c_int(), C.c_int()
+            lib.orc_object_bvh_info(self._h, k, C.byref(nn), C.byref(npr))
+            nodes = np.zeros((nn.value, 8), np.uint32); order = np.zeros(npr.value, np.uint32)
+            lib.orc_object_bvh_copy(self._h, k, _p(nodes), _p(order))
+            out.append((nodes, order))
+        return out
 
     def occluded(self, o, d, tmax):
         o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32); tmax = np.ascontiguousarray(tmax, np.float32)

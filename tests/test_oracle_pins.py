@@ -98,6 +98,24 @@ def test_render_8spp_counters_and_regression_image(killeroo_oracle):
     assert abs(float(rgb.mean()) - 2.28) < 0.01 and abs(float(rgb.max()) - 2000.0) < 0.01
 
 
+def test_instancing_regression_image(orc):
+    """Object instancing (core/api.cpp:1752-1820, TransformedPrimitive core/primitive.cpp:77-102): the
+    reference's own instancing scene and its checked-in render (scenes/simple, scenes/simple.png;
+    tests/golden/make_fixtures.py says which camera/light revision the image shows).  Eight spheres
+    in one object definition, one instance: the oracle reproduces the 700x700 image bit for bit."""
+    o = orc.OracleScene(os.path.join(GOLDEN, "simple_instanced.hprt"))
+    assert o.bvh_info()["nodes"] == 1 and o.bvh_info()["prims"] == 1          # the top level holds the instance only
+    (nodes, order), = o.object_bvh_arrays()
+    assert sorted(order.tolist()) == list(range(8)) and nodes.shape[0] >= 3    # the object aggregate: eight spheres
+    rgb, _, c, _, _ = o.render(spp=8, threads=8)
+    ref = np.load(os.path.join(GOLDEN, "simple_8spp_srgb8.npz"))["srgb8"].astype(np.int32)
+    v = rgb.astype(np.float64)
+    g = np.where(v <= 0.0031308, 12.92 * v, 1.055 * np.power(np.maximum(v, 1e-30), 1 / 2.4) - 0.055)
+    q = np.clip(255.0 * g + 0.5, 0, 255).astype(np.int32)
+    assert np.array_equal(q, ref)
+    assert c["camera_rays"] == 700 * 700 * 8 and c["sphere_tests"] > 0 and c["tri_tests"] == 0
+
+
 def test_libm_mode_is_statistically_indistinguishable(killeroo_oracle, orc):
     """The reference calls glibc sinf/cosf; the parity path uses deterministic versions.
     Measured here: how many of 20,000 camera samples change when the oracle switches."""

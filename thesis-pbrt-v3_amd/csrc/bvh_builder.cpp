@@ -36,35 +36,55 @@ struct Work { int node, start, end; };
 
 }  // namespace
 
-void ComputePrimBounds(const SceneModel &sc, std::vector<float> *bmin, std::vector<float> *bmax) {
-    size_t n = sc.totalPrims();
-    bmin->resize(3 * n); bmax->resize(3 * n);
-    size_t k = 0;
-    for (const ShapeDesc &sh : sc.shapes) {
-        if (sh.kind == kTriangleMesh) {
-            const MeshData &m = sh.mesh;
-            for (uint32_t t = 0; t < m.nTris(); ++t, ++k) {
-                const float *a = &m.P[3 * (size_t)m.indices[3 * t]], *b = &m.P[3 * (size_t)m.indices[3 * t + 1]],
-                            *c = &m.P[3 * (size_t)m.indices[3 * t + 2]];
-                for (int d = 0; d < 3; ++d) {
-                    float lo = sel_min(a[d], b[d]), hi = sel_max(a[d], b[d]);   // Bounds3f(p0, p1)
-                    (*bmin)[3 * k + d] = sel_min(lo, c[d]);                     // Union(b, p2)
-                    (*bmax)[3 * k + d] = sel_max(hi, c[d]);
-                }
+// Transform::operator()(const Bounds3f &), core/transform.cpp:238-249: corners in that order
+static void TransformBounds(const mat4 &M, vec3 lo, vec3 hi, float *outLo, float *outHi) {
+    const vec3 corner[8] = {vec3(lo.x, lo.y, lo.z), vec3(hi.x, lo.y, lo.z), vec3(lo.x, hi.y, lo.z), vec3(lo.x, lo.y, hi.z),
+                            vec3(lo.x, hi.y, hi.z), vec3(hi.x, hi.y, lo.z), vec3(hi.x, lo.y, hi.z), vec3(hi.x, hi.y, hi.z)};
+    vec3 p0 = xf_point(M, corner[0]);
+    vec3 mn = p0, mx = p0;
+    for (int c = 1; c < 8; ++c) { vec3 p = xf_point(M, corner[c]); mn = vmin(mn, p); mx = vmax(mx, p); }
+    outLo[0] = mn.x; outLo[1] = mn.y; outLo[2] = mn.z; outHi[0] = mx.x; outHi[1] = mx.y; outHi[2] = mx.z;
+}
+static void ShapePrimBounds(const ShapeDesc &sh, std::vector<float> *bmin, std::vector<float> *bmax) {
+    const size_t base = bmin->size() / 3;
+    const size_t n = sh.nPrims();
+    bmin->resize(3 * (base + n)); bmax->resize(3 * (base + n));
+    float *lo = bmin->data() + 3 * base, *hi = bmax->data() + 3 * base;
+    if (sh.kind == kTriangleMesh) {
+        const MeshData &m = sh.mesh;
+        for (uint32_t t = 0; t < m.nTris(); ++t, lo += 3, hi += 3) {
+            const float *a = &m.P[3 * (size_t)m.indices[3 * t]], *b = &m.P[3 * (size_t)m.indices[3 * t + 1]],
+                        *c = &m.P[3 * (size_t)m.indices[3 * t + 2]];
+            for (int d = 0; d < 3; ++d) {
+                float l = sel_min(a[d], b[d]), h = sel_max(a[d], b[d]);   // Bounds3f(p0, p1)
+                lo[d] = sel_min(l, c[d]);                                 // Union(b, p2)
+                hi[d] = sel_max(h, c[d]);
             }
-        } else {
-            // Transform::operator()(Bounds3f), core/transform.cpp:237-249, on Sphere::ObjectBound
-            const SphereData &s = sh.sphere;
-            vec3 lo(-s.radius, -s.radius, s.zMin), hi(s.radius, s.radius, s.zMax);
-            const vec3 corner[8] = {vec3(lo.x, lo.y, lo.z), vec3(hi.x, lo.y, lo.z), vec3(lo.x, hi.y, lo.z), vec3(lo.x, lo.y, hi.z),
-                                    vec3(lo.x, hi.y, hi.z), vec3(hi.x, hi.y, lo.z), vec3(hi.x, lo.y, hi.z), vec3(hi.x, hi.y, hi.z)};
-            vec3 p0 = xf_point(s.objectToWorld, corner[0]);
-            vec3 mn = p0, mx = p0;
-            for (int c = 1; c < 8; ++c) { vec3 p = xf_point(s.objectToWorld, corner[c]); mn = vmin(mn, p); mx = vmax(mx, p); }
-            (*bmin)[3 * k] = mn.x; (*bmin)[3 * k + 1] = mn.y; (*bmin)[3 * k + 2] = mn.z;
-            (*bmax)[3 * k] = mx.x; (*bmax)[3 * k + 1] = mx.y; (*bmax)[3 * k + 2] = mx.z;
-            ++k;
         }
+    } else {
+        // Transform::operator()(Bounds3f) on Sphere::ObjectBound (shapes/sphere.cpp:43-46)
+        const SphereData &s = sh.sphere;
+        TransformBounds(s.objectToWorld, vec3(-s.radius, -s.radius, s.zMin), vec3(s.radius, s.radius, s.zMax), lo, hi);
+    }
+}
+void ComputeObjectPrimBounds(const SceneModel &sc, int object, std::vector<float> *bmin, std::vector<float> *bmax) {
+    bmin->clear(); bmax->clear();
+    for (const ShapeDesc &sh : sc.shapes) if (sh.object == object) ShapePrimBounds(sh, bmin, bmax);
+}
+void ComputePrimBounds(const SceneModel &sc, const std::vector<BvhTree> &objectTrees, std::vector<float> *bmin,
+                       std::vector<float> *bmax) {
+    bmin->clear(); bmax->clear();
+    for (const TopItem &t : sc.top) {
+        if (t.kind == 0) { ShapePrimBounds(sc.shapes[t.index], bmin, bmax); continue; }
+        // TransformedPrimitive::WorldBound = PrimitiveToWorld.MotionBounds(primitive->WorldBound()) (core/primitive.h:116-118);
+        // without animation: the instance transform applied to the bounds of the object's aggregate (or lone primitive)
+        const InstanceDesc &in = sc.instances[t.index];
+        const BvhTree &tree = objectTrees[(size_t)in.object];
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        if (!tree.nodes.empty())
+            TransformBounds(in.instanceToWorld, vec3(tree.nodes[0].bmin[0], tree.nodes[0].bmin[1], tree.nodes[0].bmin[2]),
+                            vec3(tree.nodes[0].bmax[0], tree.nodes[0].bmax[1], tree.nodes[0].bmax[2]), lo, hi);
+        bmin->insert(bmin->end(), lo, lo + 3); bmax->insert(bmax->end(), hi, hi + 3);
     }
 }
 

@@ -23,9 +23,12 @@ struct BvhTree {
     int maxDepth = 0, nLeaves = 0;
 };
 
-// World bounds of every primitive in creation order (Triangle::WorldBound,
-// shapes/triangle.cpp:180-186; Shape::WorldBound for spheres, core/shape.cpp:53).
-void ComputePrimBounds(const SceneModel &sc, std::vector<float> *bmin, std::vector<float> *bmax);
+// World bounds of every primitive of an aggregate in creation order (Triangle::WorldBound,
+// shapes/triangle.cpp:180-186; Shape::WorldBound for spheres, core/shape.cpp:53;
+// TransformedPrimitive::WorldBound for instances, which needs the objects' trees).
+void ComputeObjectPrimBounds(const SceneModel &sc, int object, std::vector<float> *bmin, std::vector<float> *bmax);
+void ComputePrimBounds(const SceneModel &sc, const std::vector<BvhTree> &objectTrees, std::vector<float> *bmin,
+                       std::vector<float> *bmax);
 
 // Full-sweep SAH build.  bmin/bmax: 3 floats per primitive.
 void BuildBvh(size_t nPrims, const float *bmin, const float *bmax, int maxPrimsInNode, int isectCost, int travCost,

@@ -102,8 +102,13 @@ const char *hprt_model_warnings(const HprtModel *m) {
 int hprt_bvh_build(const HprtModel *m, HprtBvh **out) {
     if (!m || !out) return SetError(HPRT_E_INVALID, "hprt_bvh_build: null argument");
     std::vector<float> lo, hi;
-    ComputePrimBounds(m->sc, &lo, &hi);
     HprtBvh *b = new HprtBvh();
+    b->objects.resize(m->sc.nObjects);
+    for (uint32_t o = 0; o < m->sc.nObjects; ++o) {
+        ComputeObjectPrimBounds(m->sc, (int)o, &lo, &hi);
+        BuildBvh(lo.size() / 3, lo.data(), hi.data(), m->sc.opt.maxNodePrims, m->sc.opt.isectCost, m->sc.opt.travCost, &b->objects[o]);
+    }
+    ComputePrimBounds(m->sc, b->objects, &lo, &hi);
     BuildBvh(lo.size() / 3, lo.data(), hi.data(), m->sc.opt.maxNodePrims, m->sc.opt.isectCost, m->sc.opt.travCost, &b->tree);
     *out = b;
     return HPRT_OK;
@@ -132,6 +137,24 @@ int hprt_bvh_copy(const HprtBvh *b, void *nodes32, uint32_t *prim_order) {
     if (!b) return SetError(HPRT_E_INVALID, "hprt_bvh_copy: null argument");
     if (nodes32) memcpy(nodes32, b->tree.nodes.data(), b->tree.nodes.size() * sizeof(BvhNode));
     if (prim_order) memcpy(prim_order, b->tree.primOrder.data(), b->tree.primOrder.size() * 4);
+    return HPRT_OK;
+}
+
+int hprt_bvh_object_info(const HprtBvh *b, uint32_t object, uint32_t info[4], float bounds6[6]) {
+    if (!b || !info || object >= b->objects.size()) return SetError(HPRT_E_INVALID, "hprt_bvh_object_info: bad argument");
+    const BvhTree &t = b->objects[object];
+    info[0] = (uint32_t)t.nodes.size(); info[1] = (uint32_t)t.primOrder.size(); info[2] = (uint32_t)t.nLeaves; info[3] = (uint32_t)t.maxDepth;
+    if (bounds6) {
+        if (t.nodes.empty()) for (int i = 0; i < 6; ++i) bounds6[i] = 0;
+        else { memcpy(bounds6, t.nodes[0].bmin, 12); memcpy(bounds6 + 3, t.nodes[0].bmax, 12); }
+    }
+    return HPRT_OK;
+}
+int hprt_bvh_object_copy(const HprtBvh *b, uint32_t object, void *nodes32, uint32_t *prim_order) {
+    if (!b || object >= b->objects.size()) return SetError(HPRT_E_INVALID, "hprt_bvh_object_copy: bad argument");
+    const BvhTree &t = b->objects[object];
+    if (nodes32) memcpy(nodes32, t.nodes.data(), t.nodes.size() * sizeof(BvhNode));
+    if (prim_order) memcpy(prim_order, t.primOrder.data(), t.primOrder.size() * 4);
     return HPRT_OK;
 }
 

@@ -101,6 +101,8 @@ struct Frontend {
     std::map<std::string, Xform> namedCS;
     std::vector<GraphicsState> gsStack; GraphicsState gs;
     std::vector<Xform> xfStack;
+    int currentObject = -1;                        // renderOptions->currentInstance
+    std::map<std::string, int> objectByName;       // renderOptions->instances
     std::map<std::string, std::pair<std::string, ParamList>> namedMaterials;
     std::map<std::string, int> materialCache;
     bool inWorld = false;
@@ -304,8 +306,14 @@ struct Frontend {
         if (UV.size() >= 2 * nv) sh.mesh.UV.assign(UV.begin(), UV.begin() + 2 * nv);
         if (!gs.areaLight.empty())
             warn("area lights on triangle meshes are outside the hot-path scope (one DiffuseAreaLight per triangle); ignored");
-        sc->shapes.push_back(std::move(sh));
+        pushShape(std::move(sh));
         return true;
+    }
+    // "Add prims to scene or current instance", core/api.cpp:1638-1650
+    void pushShape(ShapeDesc &&sh) {
+        sh.object = currentObject;
+        if (currentObject < 0) sc->top.push_back(TopItem{0, (uint32_t)sc->shapes.size()});
+        sc->shapes.push_back(std::move(sh));
     }
     bool doShape(const std::string &name, const ParamList &params) {
         if (name == "trianglemesh" || name == "loopsubdiv" || name == "plymesh") {
@@ -357,7 +365,9 @@ struct Frontend {
             s.thetaMax = std::acos(clampf(sel_max(zmin, zmax) / radius, -1, 1));
             s.phiMax = radians(clampf(phimax, 0, 360));
             sh.areaLight = -1;
-            if (!gs.areaLight.empty()) {        // MakeAreaLight, core/api.cpp:782-788 + lights/diffuse.cpp:113-125
+            if (!gs.areaLight.empty() && currentObject >= 0)
+                warn("Area lights not supported with object instancing (core/api.cpp:1640); the shape is kept without emission");
+            else if (!gs.areaLight.empty()) {   // MakeAreaLight, core/api.cpp:782-788 + lights/diffuse.cpp:113-125
                 if (gs.areaLight != "area" && gs.areaLight != "diffuse") warn("area light \"" + gs.areaLight + "\" unknown; treated as diffuse");
                 LightDesc l; memset(&l, 0, sizeof(l));
                 l.type = kDiffuseAreaLight;
@@ -370,7 +380,7 @@ struct Frontend {
                 sh.areaLight = (int)sc->lights.size();
                 sc->lights.push_back(l);
             }
-            sc->shapes.push_back(std::move(sh));
+            pushShape(std::move(sh));
             return true;
         }
         warn("shape \"" + name + "\" is outside the hot-path scope; skipped");
@@ -540,8 +550,28 @@ struct Frontend {
             else if (tok == "Include") {
                 if (!readQuoted(&name)) return false;
                 if (!pushFile(resolve(name))) return false;
-            } else if (tok == "ObjectBegin" || tok == "ObjectEnd" || tok == "ObjectInstance")
-                return fail(tok + ": object instancing is a 'next' item (SURVEY.md §8(f)-1), not built yet");
+            } else if (tok == "ObjectBegin") {               // core/api.cpp:1752-1761
+                if (!readQuoted(&name)) return false;
+                gsStack.push_back(gs); xfStack.push_back(ctm);
+                if (currentObject >= 0) return fail("ObjectBegin called inside of instance definition");
+                currentObject = (int)sc->nObjects++;
+                objectByName[name] = currentObject;          // a later definition replaces an earlier one of the same name
+            } else if (tok == "ObjectEnd") {                 // core/api.cpp:1765-1774
+                if (currentObject < 0) return fail("ObjectEnd called outside of instance definition");
+                currentObject = -1;
+                if (!gsStack.empty()) { gs = gsStack.back(); gsStack.pop_back(); ctm = xfStack.back(); xfStack.pop_back(); }
+            } else if (tok == "ObjectInstance") {            // core/api.cpp:1778-1820
+                if (!readQuoted(&name)) return false;
+                if (currentObject >= 0) return fail("ObjectInstance can't be called inside instance definition");
+                if (!objectByName.count(name)) return fail("Unable to find instance named \"" + name + "\"");
+                const int obj = objectByName[name];
+                bool any = false;
+                for (const ShapeDesc &sh : sc->shapes) if (sh.object == obj && sh.nPrims() > 0) { any = true; break; }
+                if (!any) continue;                          // "if (in.empty()) return;"
+                InstanceDesc in; in.object = obj; in.instanceToWorld = ctm.m; in.worldToInstance = ctm.inv;
+                sc->top.push_back(TopItem{1, (uint32_t)sc->instances.size()});
+                sc->instances.push_back(in);
+            }
             else if (tok == "MediumInterface" || tok == "MakeNamedMedium") {
                 warn(tok + " ignored (media are outside the hot-path scope)");
                 std::string t2; while (nextToken(&t2)) { if (!quoted(t2) && t2 != "[" && t2 != "]") { float d; if (!parseNumber(t2, &d)) { unget(t2); break; } } }

@@ -33,7 +33,10 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
     if (!fp) { *err = "cannot create " + path; return false; }
     Out o{fp};
     const RenderOptions &p = sc.opt;
-    o.raw("HPRTSCN1", 8); o.u32(1);
+    // version 1: every shape is a top-level primitive source.  Version 2 appends the instancing
+    // section (objects, instances, top-level creation order) and is written only when needed.
+    const bool instancing = sc.nObjects > 0 || !sc.instances.empty();
+    o.raw("HPRTSCN1", 8); o.u32(instancing ? 2u : 1u);
     o.i32(p.xres); o.i32(p.yres);
     o.raw(p.crop, 16);
     o.raw(p.filterRadius, 8); o.i32(p.filterType);
@@ -67,6 +70,14 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
         }
     }
     for (const LightDesc &l : sc.lights) { o.i32(l.type); o.raw(l.pos, 12); o.raw(l.I, 12); o.i32(l.shape); o.i32(l.twoSided); }
+    if (instancing) {
+        o.u32(sc.nObjects);
+        for (const ShapeDesc &s : sc.shapes) o.i32(s.object);
+        o.u32((uint32_t)sc.instances.size());
+        for (const InstanceDesc &in : sc.instances) { o.i32(in.object); o.raw(in.instanceToWorld.m, 64); o.raw(in.worldToInstance.m, 64); }
+        o.u32((uint32_t)sc.top.size());
+        for (const TopItem &t : sc.top) { o.i32(t.kind); o.u32(t.index); }
+    }
     bool ok = o.ok;
     if (fclose(fp) != 0) ok = false;
     if (!ok) *err = "write error on " + path;
@@ -80,7 +91,8 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
     auto fail = [&](const char *m) { *err = path + ": " + m; fclose(fp); return false; };
     char magic[8]; in.raw(magic, 8);
     if (!in.ok || memcmp(magic, "HPRTSCN1", 8) != 0) return fail("not a baked hprt scene");
-    if (in.u32() != 1) return fail("unsupported version");
+    const uint32_t version = in.u32();
+    if (version != 1 && version != 2) return fail("unsupported version");
     RenderOptions &p = sc->opt;
     p.xres = in.i32(); p.yres = in.i32();
     in.raw(p.crop, 16);
@@ -123,6 +135,27 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
     for (LightDesc &l : sc->lights) {
         l.type = in.i32(); in.raw(l.pos, 12); in.raw(l.I, 12); l.shape = in.i32(); l.twoSided = in.i32();
         if (l.type == kDiffuseAreaLight && (l.shape < 0 || (uint32_t)l.shape >= nShapes)) return fail("area light shape out of range");
+    }
+    sc->nObjects = 0; sc->instances.clear(); sc->top.clear();
+    if (version == 2) {
+        sc->nObjects = in.u32();
+        for (ShapeDesc &s : sc->shapes) { s.object = in.i32(); if (s.object < -1 || s.object >= (int32_t)sc->nObjects) return fail("object index out of range"); }
+        const uint32_t nInst = in.u32();
+        if (!in.ok || nInst > (1u << 28)) return fail("corrupt instance count");
+        sc->instances.resize(nInst);
+        for (InstanceDesc &i : sc->instances) {
+            i.object = in.i32(); in.raw(i.instanceToWorld.m, 64); in.raw(i.worldToInstance.m, 64);
+            if (i.object < 0 || i.object >= (int32_t)sc->nObjects) return fail("instance object out of range");
+        }
+        const uint32_t nTop = in.u32();
+        if (!in.ok || nTop > (1u << 28)) return fail("corrupt top-level list");
+        sc->top.resize(nTop);
+        for (TopItem &t : sc->top) {
+            t.kind = in.i32(); t.index = in.u32();
+            if (t.kind == 0 ? (t.index >= nShapes || sc->shapes[t.index].object >= 0) : (t.kind != 1 || t.index >= nInst)) return fail("corrupt top-level item");
+        }
+    } else {
+        for (uint32_t i = 0; i < nShapes; ++i) { sc->shapes[i].object = -1; sc->top.push_back(TopItem{0, i}); }
     }
     if (!in.ok) return fail("truncated file");
     fclose(fp);

@@ -33,6 +33,7 @@ struct SphereData {
 };
 struct ShapeDesc {
     int32_t kind, material, areaLight, reverseOrientation, transformSwapsHandedness;
+    int32_t object = -1;  // >= 0: defined between ObjectBegin/ObjectEnd (core/api.cpp:1752-1774), reachable through instances only
     MeshData mesh;        // kind == kTriangleMesh
     SphereData sphere;    // kind == kSphere
     uint32_t nPrims() const { return kind == kTriangleMesh ? mesh.nTris() : 1u; }
@@ -44,6 +45,10 @@ struct LightDesc {
     int32_t shape;    // area: index into shapes
     int32_t twoSided;
 };
+// ObjectInstance (core/api.cpp:1778-1820): a TransformedPrimitive over the object's primitives
+struct InstanceDesc { int32_t object; mat4 instanceToWorld, worldToInstance; };
+// renderOptions->primitives in creation order: a shape's primitives (kind 0) or one instance (kind 1)
+struct TopItem { int32_t kind; uint32_t index; };
 struct RenderOptions {
     int32_t xres = 1280, yres = 720;
     float crop[4] = {0, 1, 0, 1};                 // x0 x1 y0 y1
@@ -63,8 +68,12 @@ struct SceneModel {
     std::vector<MaterialDesc> materials;
     std::vector<ShapeDesc> shapes;
     std::vector<LightDesc> lights;
+    uint32_t nObjects = 0;                // object ids are 0..nObjects-1 (ShapeDesc::object)
+    std::vector<InstanceDesc> instances;
+    std::vector<TopItem> top;             // what the top-level aggregate holds, in creation order
     std::vector<std::string> warnings;
-    uint64_t totalPrims() const { uint64_t n = 0; for (auto &s : shapes) n += s.nPrims(); return n; }
+    // primitives of the top-level aggregate
+    uint64_t totalPrims() const { uint64_t n = 0; for (auto &t : top) n += t.kind == 0 ? shapes[t.index].nPrims() : 1u; return n; }
 };
 
 bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *err);
