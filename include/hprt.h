@@ -92,6 +92,9 @@ void hprt_bvh_destroy(HprtBvh *b);
 int hprt_bvh_info(const HprtBvh *b, uint32_t info[4], float bounds6[6]);
 /* nodes32: n_nodes*32 bytes; prim_order: n_prims uint32 (ordered -> creation number) */
 int hprt_bvh_copy(const HprtBvh *b, void *nodes32, uint32_t *prim_order);
+/* The same for the aggregate of object definition `object` (core/api.cpp:1798-1806). */
+int hprt_bvh_object_info(const HprtBvh *b, uint32_t object, uint32_t info[4], float bounds6[6]);
+int hprt_bvh_object_copy(const HprtBvh *b, uint32_t object, void *nodes32, uint32_t *prim_order);
 
 /* ------------------------------------------------------------------------ */
 /* Device scene.  Upload step that follows the BVH build: stands in for the  */
@@ -132,8 +135,27 @@ typedef struct HprtLightDesc {       /* lights/point.cpp, lights/distant.cpp, li
     int32_t two_sided;
 } HprtLightDesc;
 
+/* Object instancing (pbrtObjectBegin/End/Instance, core/api.cpp:1752-1820; TransformedPrimitive,
+ * core/primitive.cpp:70-102).  An object definition owns a contiguous range of `shapes` and the
+ * aggregate ObjectInstance builds over their primitives (core/api.cpp:1798-1806; with a single
+ * primitive the reference wraps that primitive directly and the one-leaf tree is only used for
+ * its bounds).  An instance is one primitive of the top-level aggregate. */
+typedef struct HprtObjectDesc {
+    uint32_t first_shape, n_shapes;
+    const void *nodes; uint32_t n_nodes;            /* LinearBVHNode layout, primitives numbered within the object */
+    const uint32_t *prim_order; uint32_t n_prims;
+} HprtObjectDesc;
+typedef struct HprtInstanceDesc {
+    int32_t object;
+    float instance_to_world[16], world_to_instance[16];   /* row-major Transform::m / mInv at ObjectInstance */
+} HprtInstanceDesc;
+typedef struct HprtTopItem {         /* renderOptions->primitives in creation order */
+    int32_t kind;                    /* 0: all primitives of shapes[index]; 1: instances[index] */
+    uint32_t index;
+} HprtTopItem;
+
 typedef struct HprtSceneDesc {
-    const void *nodes;               /* n_nodes * 32 B, LinearBVHNode layout */
+    const void *nodes;               /* n_nodes * 32 B, LinearBVHNode layout: the top-level aggregate */
     uint32_t n_nodes;
     const uint32_t *prim_order;      /* n_prims: ordered position -> creation-order primitive number */
     uint32_t n_prims;
@@ -141,6 +163,10 @@ typedef struct HprtSceneDesc {
     const HprtMaterialDesc *materials; uint32_t n_materials;
     const HprtLightDesc *lights; uint32_t n_lights;
     int32_t light_strategy;
+    /* instancing; all NULL / 0 without it.  top == NULL: every shape, in order, is top-level */
+    const HprtObjectDesc *objects; uint32_t n_objects;
+    const HprtInstanceDesc *instances; uint32_t n_instances;
+    const HprtTopItem *top; uint32_t n_top;
 } HprtSceneDesc;
 
 /* device < 0 selects the current HIP device. */
@@ -166,6 +192,12 @@ int hprt_intersect(HprtScene *s, size_t n, const float *o, const float *d, const
                    int32_t *prim_out, float *bary_out, uint64_t counters[4]);
 int hprt_occluded(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, uint8_t *occluded_out,
                   uint64_t counters[4]);
+/* With object instances (TransformedPrimitive::Intersect, core/primitive.cpp:77-93) the ordered
+ * primitive index numbers the primitives of all aggregates — top level first, then object 0, 1, ... —
+ * and inst_out (may be NULL) receives the instance the hit went through (index into
+ * HprtSceneDesc::instances), -1 for none.  hprt_intersect is this call without inst_out. */
+int hprt_intersect_instanced(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, float *t_out,
+                             int32_t *prim_out, int32_t *inst_out, float *bary_out, uint64_t counters[4]);
 /* Same with rays/hits already resident in HBM (device pointers, SoA planes:
  * ox,oy,oz,dx,dy,dz,tmax each n floats).  `stream` is a hipStream_t or NULL.
  * Timed by bench.py's kernel microbenchmarks. */

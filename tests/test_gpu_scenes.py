@@ -1,7 +1,9 @@
 """GPU parity on procedurally generated scenes that exercise what killeroo-simple does not:
 point and distant lights, several lights (uniform strategy), matte-only and plastic-only
 sets, meshes with uv / without normals, depth of field, odd resolutions and crop windows,
-maxdepth 0 / 1 / 8 (Russian roulette), spp 1, an empty scene and a scene without lights.
+maxdepth 0 / 1 / 8 (Russian roulette), spp 1, an empty scene and a scene without lights,
+and object instancing (ObjectBegin/End/Instance: rotated, scaled, mirrored and identity
+instances of meshes and spheres, single-primitive objects, an instance-only top level).
 Each scene is written as .pbrt text, parsed by the product front-end, baked, and rendered by
 both the HIP path (through the C ABI) and the oracle; films must be bit-identical."""
 import numpy as np
@@ -59,6 +61,26 @@ CASES = {
     "maxdepth8_roulette": _scene(SPHERE_LIGHT + GEOM, maxdepth=8, spp=8, integ='"float rrthreshold" [1]'),
     "reverse_orientation_scaled": _scene(SPHERE_LIGHT + MATTE + 'Shape "trianglemesh" ' + FLOOR + '\nAttributeBegin\nScale 1 -1 1.5\nReverseOrientation\n' + PLASTIC +
                                          'Shape "trianglemesh" ' + BUMPY + "\nAttributeEnd\n"),
+    # ---- object instancing (core/api.cpp:1752-1820, core/primitive.cpp:70-102) ----
+    "instances_mesh": _scene(SPHERE_LIGHT + MATTE + 'Shape "trianglemesh" ' + FLOOR + "\n" + PLASTIC +
+                             'ObjectBegin "bump"\nScale .35 .35 .8\nShape "trianglemesh" ' + BUMPY + "\nObjectEnd\n" +
+                             'AttributeBegin\nTranslate -1.2 0.3 0.2\nRotate 30 0 0 1\nObjectInstance "bump"\nAttributeEnd\n'
+                             'AttributeBegin\nTranslate 1.1 -0.4 0.1\nRotate -50 0.2 0.1 1\nScale 1.3 0.8 1.1\nObjectInstance "bump"\nAttributeEnd\n'
+                             'AttributeBegin\nTranslate 0 1.2 0.5\nScale 1 -1 1\nObjectInstance "bump"\nAttributeEnd\n'
+                             'ObjectInstance "bump"\n'),
+    "instances_spheres_and_single_prims": _scene(
+        SPHERE_LIGHT + MATTE + 'Shape "trianglemesh" ' + FLOOR + "\n" +
+        'ObjectBegin "balls"\n' + PLASTIC + 'Translate 0 0 .3\nShape "sphere" "float radius" [.3]\nTranslate .5 0 0\nShape "sphere" "float radius" [.2]\n'
+        'Translate 0 .45 .1\n' + MATTE + 'Shape "sphere" "float radius" [.25] "float zmin" [-.1]\nObjectEnd\n'
+        'ObjectBegin "one"\nShape "sphere" "float radius" [.4]\nObjectEnd\n'
+        'ObjectBegin "tri"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [-.5 0 0  .5 0 0  0 0 1]\nObjectEnd\n'
+        'AttributeBegin\nTranslate -1.5 0 -.2\nRotate 25 0 1 0\nObjectInstance "balls"\nAttributeEnd\n'
+        'AttributeBegin\nTranslate 1 .5 -.1\nScale .8 .8 1.4\nObjectInstance "balls"\nAttributeEnd\n'
+        'AttributeBegin\nTranslate 0 -1 .2\nScale 1 .6 .8\nObjectInstance "one"\nAttributeEnd\n'
+        'AttributeBegin\nTranslate -.3 1.3 0\nRotate 40 0 0 1\nObjectInstance "tri"\nAttributeEnd\n', maxdepth=6),
+    "instances_only_point_light": _scene('LightSource "point" "point from" [1 -2 4] "color I" [30 30 30]\n' + MATTE +
+                                         'ObjectBegin "bump"\nShape "trianglemesh" ' + BUMPY + "\nObjectEnd\n" +
+                                         'ObjectInstance "bump"\nAttributeBegin\nTranslate 0 0 -1\nScale 2 2 1\nObjectInstance "bump"\nAttributeEnd\n'),
     "no_lights": _scene(GEOM),
     "empty_scene": _scene(""),
     "light_only": _scene(SPHERE_LIGHT),
@@ -77,6 +99,9 @@ def test_scene_film_parity(hprt, orc, tmp_path, name):
     oracle = orc.OracleScene(baked)
     n1, o1 = oracle.bvh_arrays(); n2, o2 = bvh.arrays()
     assert np.array_equal(n1, n2) and np.array_equal(o1, o2)
+    for k, (on, oo) in enumerate(oracle.object_bvh_arrays()):      # the aggregates ObjectInstance builds
+        pn, po = bvh.object_arrays(k)
+        assert np.array_equal(on, pn) and np.array_equal(oo, po)
     scene = hprt.Scene(model, bvh)
     rgb0, film0, c0, _, _ = oracle.render(threads=8)
     film1, st = scene.render(count_work=True)
@@ -89,3 +114,29 @@ def test_scene_film_parity(hprt, orc, tmp_path, name):
         assert st[k_dev] == c0[k_orc], (name, k_dev, st[k_dev], c0[k_orc])
     if name not in ("no_lights", "empty_scene"):
         assert film0[..., :3].max() > 0
+
+
+def test_instanced_hits_identify_instance_and_primitive(hprt, orc, tmp_path):
+    """Closest hits through TransformedPrimitive: t, primitive (numbered over all aggregates), instance id,
+    barycentrics and the traversal counters equal the oracle's; any-hit flags too."""
+    p = tmp_path / "inst.pbrt"
+    p.write_text(CASES["instances_spheres_and_single_prims"])
+    model = hprt.Model.parse(str(p))
+    baked = str(tmp_path / "inst.hprt"); model.save(baked)
+    bvh = hprt.Bvh(model); scene = hprt.Scene(model, bvh); oracle = orc.OracleScene(baked)
+    rng = np.random.default_rng(5)
+    n = 200000
+    o = (rng.uniform(-3, 3, (n, 3)) + np.array([0, 0, 1.5])).astype(np.float32)
+    tgt = rng.uniform(-1.8, 1.8, (n, 3)).astype(np.float32) * np.array([1, 1, 0.4], np.float32)
+    d = (tgt - o).astype(np.float32)
+    tmax = np.where(rng.random(n) < 0.5, np.inf, rng.uniform(0.2, 1.5, n)).astype(np.float32)
+    t0, p0, i0, b0, c0 = oracle.intersect_inst(o, d, tmax)
+    t1, p1, i1, b1, c1 = scene.intersect_instanced(o, d, tmax, count=True)
+    assert (i0 >= 0).sum() > 1000 and (p0 >= 0).sum() > (i0 >= 0).sum()
+    assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(p0, p1) and np.array_equal(i0, i1)
+    assert np.array_equal(b0.view(np.uint32), b1.view(np.uint32))
+    assert [int(x) for x in c1] == [c0["nodes_fetched"], c0["nodes_entered"], c0["tri_tests"], c0["sphere_tests"]]
+    occ0, k0 = oracle.occluded(o, d, tmax)
+    occ1, k1 = scene.occluded(o, d, tmax, count=True)
+    assert np.array_equal(occ0, occ1)
+    assert [int(x) for x in k1] == [k0["nodes_fetched_p"], k0["nodes_entered_p"], k0["tri_tests_p"], k0["sphere_tests_p"]]

@@ -96,11 +96,14 @@ def _load():
         "hprt_bvh_destroy": (None, [vp]),
         "hprt_bvh_info": (C.c_int, [vp, P(u32), P(C.c_float)]),
         "hprt_bvh_copy": (C.c_int, [vp, vp, vp]),
+        "hprt_bvh_object_info": (C.c_int, [vp, C.c_uint32, P(u32), P(C.c_float)]),
+        "hprt_bvh_object_copy": (C.c_int, [vp, C.c_uint32, vp, vp]),
         "hprt_scene_create": (C.c_int, [vp, C.c_int, P(vp)]),
         "hprt_scene_create_from_model": (C.c_int, [vp, vp, C.c_int, P(vp)]),
         "hprt_scene_destroy": (None, [vp]),
         "hprt_intersect": (C.c_int, [vp, sz, vp, vp, vp, vp, vp, vp, vp]),
         "hprt_occluded": (C.c_int, [vp, sz, vp, vp, vp, vp, vp]),
+        "hprt_intersect_instanced": (C.c_int, [vp, sz, vp, vp, vp, vp, vp, vp, vp, vp]),
         "hprt_intersect_device": (C.c_int, [vp, sz, vp, vp, vp, vp, vp]),
         "hprt_occluded_device": (C.c_int, [vp, sz, vp, vp, vp]),
         "hprt_render": (C.c_int, [vp, P(RenderDesc), vp, vp, P(RenderStats)]),
@@ -212,6 +215,15 @@ class Bvh:
         _check(lib.hprt_bvh_copy(self._h, _ptr(nodes), _ptr(order)))
         return nodes, order
 
+    def object_arrays(self, obj):
+        """(nodes, prim_order) of the aggregate of object definition `obj` (core/api.cpp:1798-1806)."""
+        i = (C.c_uint32 * 4)()
+        _check(lib.hprt_bvh_object_info(self._h, obj, i, None))
+        nodes = np.zeros((i[0], 8), np.uint32)
+        order = np.zeros(i[1], np.uint32)
+        _check(lib.hprt_bvh_object_copy(self._h, obj, _ptr(nodes), _ptr(order)))
+        return nodes, order
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib.hprt_bvh_destroy(self._h)
@@ -235,6 +247,17 @@ class Scene:
         ctr = np.zeros(4, np.uint64) if count else None
         _check(lib.hprt_intersect(self._h, n, _ptr(o), _ptr(d), _ptr(tmax), _ptr(t), _ptr(prim), _ptr(bary), _ptr(ctr)))
         return (t, prim, bary, ctr) if count else (t, prim, bary)
+
+    def intersect_instanced(self, o, d, tmax, count=False):
+        """As intersect, plus the instance each hit went through (-1: none); prim numbers the ordered
+        primitives of all aggregates (top level, then object 0, 1, ...)."""
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = tmax.shape[0]
+        t = np.zeros(n, np.float32); prim = np.zeros(n, np.int32); inst = np.zeros(n, np.int32); bary = np.zeros((n, 3), np.float32)
+        ctr = np.zeros(4, np.uint64) if count else None
+        _check(lib.hprt_intersect_instanced(self._h, n, _ptr(o), _ptr(d), _ptr(tmax), _ptr(t), _ptr(prim), _ptr(inst), _ptr(bary), _ptr(ctr)))
+        return (t, prim, inst, bary, ctr) if count else (t, prim, inst, bary)
 
     def occluded(self, o, d, tmax, count=False):
         o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)

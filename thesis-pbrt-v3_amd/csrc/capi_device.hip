@@ -53,7 +53,7 @@ template <typename T> hipError_t upload(DevBuf &b, const std::vector<T> &v) {
 struct HprtScene {
     int device = 0;
     DevScene dev;
-    DevBuf nodes, tris, primVtx, vN, vUV, vS, shapes, materials, lights, spheres, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
+    DevBuf nodes, tris, primVtx, vN, vUV, vS, shapes, materials, lights, spheres, instances, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
     DevBuf counters, workCounter;
     // render-time state
     DevBuf planes;                                    // backing store of the path streams (Workspace)
@@ -125,16 +125,16 @@ struct Workspace {
 };
 // 16-byte words per stream index: 2 x (ray a,b + beta + L) + hit a + shadow a,b + mis a,b + misHit a
 // + pendLight/Mis/Beta + Lfinal; plus b2 (4 B), occluded (1 B) and alignment slack
-const size_t kPlaneBytesPerSlot = 16 * (2 * 4 + 1 + 2 + 2 + 1 + 3 + 1) + 4 + 1;
+const size_t kPlaneBytesPerSlot = 16 * (2 * 4 + 1 + 2 + 2 + 1 + 3 + 1) + 8 + 1;
 size_t PlaneBytes(size_t n) { return n * kPlaneBytesPerSlot + 32 * 256; }
 
 void CarvePlanes(char *base, size_t n, Workspace *w) {
     PlaneAllocator a{base, 0, 0};
     auto rays = [&](RayStream &r) { r.a = a.take<float4>(n); r.b = a.take<float4>(n); };
     for (int k = 0; k < 2; ++k) { rays(w->path[k].ray); w->path[k].beta = a.take<float4>(n); w->path[k].L = a.take<float4>(n); }
-    w->hit.a = a.take<float4>(n); w->hit.b2 = a.take<float>(n);
+    w->hit.a = a.take<float4>(n); w->hit.b = a.take<float2>(n);
     rays(w->vs.shadow); w->vs.occluded = a.take<uint8_t>(n);
-    rays(w->vs.mis); w->vs.misHit.a = a.take<float4>(n); w->vs.misHit.b2 = nullptr;
+    rays(w->vs.mis); w->vs.misHit.a = a.take<float4>(n); w->vs.misHit.b = nullptr;
     w->vs.pendLight = a.take<float4>(n); w->vs.pendMis = a.take<float4>(n); w->vs.pendBeta = a.take<float4>(n);
     w->Lfinal = a.take<float4>(n);
 }
@@ -206,9 +206,11 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     if ((d->n_nodes && !d->nodes) || (d->n_prims && !d->prim_order) || (d->n_shapes && !d->shapes) ||
         (d->n_materials && !d->materials) || (d->n_lights && !d->lights))
         return SetError(HPRT_E_INVALID, "hprt_scene_create: null array with non-zero count");
+    if ((d->n_objects && !d->objects) || (d->n_instances && !d->instances) || (d->n_top && !d->top))
+        return SetError(HPRT_E_INVALID, "hprt_scene_create: null instancing array with non-zero count");
     // ---- validate the description against what the kernels assume ----
-    std::vector<uint64_t> firstPrim(d->n_shapes + 1, 0);
     std::vector<uint64_t> vtxBase(d->n_shapes + 1, 0);
+    std::vector<uint32_t> shapePrims(d->n_shapes, 0);
     uint32_t nSpheres = 0;
     for (uint32_t s = 0; s < d->n_shapes; ++s) {
         const HprtShapeDesc &sh = d->shapes[s];
@@ -219,25 +221,77 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
             for (uint64_t i = 0; i < 3ull * sh.n_tris; ++i)
                 if (sh.indices[i] < 0 || (uint32_t)sh.indices[i] >= sh.n_verts) return SetError(HPRT_E_INVALID, "mesh vertex index out of range");
             if (sh.area_light >= 0) return SetError(HPRT_E_UNSUPPORTED, "area lights on triangle meshes are outside the hot-path scope");
-            firstPrim[s + 1] = firstPrim[s] + sh.n_tris; vtxBase[s + 1] = vtxBase[s] + sh.n_verts;
+            shapePrims[s] = sh.n_tris; vtxBase[s + 1] = vtxBase[s] + sh.n_verts;
         } else if (sh.kind == 1) {
-            firstPrim[s + 1] = firstPrim[s] + 1; vtxBase[s + 1] = vtxBase[s]; ++nSpheres;
+            shapePrims[s] = 1; vtxBase[s + 1] = vtxBase[s]; ++nSpheres;
         } else return SetError(HPRT_E_INVALID, "unknown shape kind");
     }
-    if (firstPrim[d->n_shapes] != d->n_prims) return SetError(HPRT_E_INVALID, "prim_order length does not match the shapes' primitive count");
+    (void)nSpheres;
     if (vtxBase[d->n_shapes] > 0xffffffffull) return SetError(HPRT_E_UNSUPPORTED, "more than 2^32 vertices");
-    {   // BVH sanity: every child/primitive reference must stay inside the arrays
-        const BvhNode *nd = (const BvhNode *)d->nodes;
-        for (uint32_t i = 0; i < d->n_nodes; ++i) {
-            uint32_t axis = nd[i].countAxis & 3u, cnt = nd[i].countAxis >> 2;
-            if (axis == 3u) { if (nd[i].offset < 0 || cnt == 0 || (uint64_t)nd[i].offset + cnt > d->n_prims) return SetError(HPRT_E_INVALID, "BVH leaf is empty or references primitives out of range"); }
-            else if (nd[i].offset <= (int32_t)i || (uint32_t)nd[i].offset >= d->n_nodes || i + 1 >= d->n_nodes) return SetError(HPRT_E_INVALID, "BVH interior node has an invalid child");
+    // ---- aggregates: 0 = the top level (renderOptions->primitives), 1 + k = object definition k ----
+    struct AggPrim { int32_t shape; uint32_t local; };      // shape < 0: instance `local`
+    struct Agg { const BvhNode *nodes; uint32_t nNodes; const uint32_t *order; uint32_t nPrims; std::vector<AggPrim> prims; };
+    std::vector<Agg> aggs(1 + (size_t)d->n_objects);
+    std::vector<int32_t> objectOfShape(d->n_shapes, -1);
+    aggs[0].nodes = (const BvhNode *)d->nodes; aggs[0].nNodes = d->n_nodes; aggs[0].order = d->prim_order; aggs[0].nPrims = d->n_prims;
+    auto addShape = [&](Agg &a, uint32_t s) { for (uint32_t k = 0; k < shapePrims[s]; ++k) a.prims.push_back(AggPrim{(int32_t)s, k}); };
+    for (uint32_t k = 0; k < d->n_objects; ++k) {
+        const HprtObjectDesc &o = d->objects[k];
+        Agg &a = aggs[1 + (size_t)k];
+        if ((uint64_t)o.first_shape + o.n_shapes > d->n_shapes) return SetError(HPRT_E_INVALID, "object shape range out of bounds");
+        if ((o.n_nodes && !o.nodes) || (o.n_prims && !o.prim_order)) return SetError(HPRT_E_INVALID, "object without its aggregate arrays");
+        a.nodes = (const BvhNode *)o.nodes; a.nNodes = o.n_nodes; a.order = o.prim_order; a.nPrims = o.n_prims;
+        for (uint32_t s = o.first_shape; s < o.first_shape + o.n_shapes; ++s) {
+            if (objectOfShape[s] >= 0) return SetError(HPRT_E_INVALID, "a shape belongs to two objects");
+            if (d->shapes[s].area_light >= 0) return SetError(HPRT_E_UNSUPPORTED, "area lights are not supported with object instancing (core/api.cpp:1640)");
+            objectOfShape[s] = (int32_t)k;
+            addShape(a, s);
         }
-        for (uint32_t i = 0; i < d->n_prims; ++i) if (d->prim_order[i] >= d->n_prims) return SetError(HPRT_E_INVALID, "prim_order entry out of range");
-        // the kernels address primitives and node pairs with 32-bit byte offsets
-        if ((uint64_t)d->n_prims * 48ull > 0xffffffffull || (uint64_t)d->n_nodes * 32ull + 64ull > 0xffffffffull)
-            return SetError(HPRT_E_UNSUPPORTED, "more than 89,478,485 primitives in one aggregate");
     }
+    for (uint32_t i = 0; i < d->n_instances; ++i) {
+        const int32_t o = d->instances[i].object;
+        if (o < 0 || (uint32_t)o >= d->n_objects) return SetError(HPRT_E_INVALID, "instance object index out of range");
+        if (aggs[1 + (size_t)o].prims.empty()) return SetError(HPRT_E_INVALID, "instance of an empty object");
+    }
+    if (d->top) {
+        for (uint32_t t = 0; t < d->n_top; ++t) {
+            const HprtTopItem &it = d->top[t];
+            if (it.kind == 0) {
+                if (it.index >= d->n_shapes || objectOfShape[it.index] >= 0) return SetError(HPRT_E_INVALID, "top-level item references a missing or object-owned shape");
+                addShape(aggs[0], it.index);
+            } else if (it.kind == 1) {
+                if (it.index >= d->n_instances) return SetError(HPRT_E_INVALID, "top-level item references a missing instance");
+                aggs[0].prims.push_back(AggPrim{-1, it.index});
+            } else return SetError(HPRT_E_INVALID, "unknown top-level item kind");
+        }
+    } else {
+        if (d->n_instances) return SetError(HPRT_E_INVALID, "instances need the top-level item list");
+        for (uint32_t s = 0; s < d->n_shapes; ++s) if (objectOfShape[s] < 0) addShape(aggs[0], s);
+    }
+    // primitive records and node pairs of all aggregates share one array each; 32-bit byte offsets address them
+    std::vector<uint32_t> primBase(aggs.size() + 1, 0), pairBase(aggs.size() + 1, 0);
+    {
+        uint64_t np = 0, npair = 0;
+        for (size_t a = 0; a < aggs.size(); ++a) {
+            const Agg &g = aggs[a];
+            if (g.prims.size() != g.nPrims) return SetError(HPRT_E_INVALID, "prim_order length does not match the aggregate's primitive count");
+            // BVH sanity: every child/primitive reference must stay inside the arrays
+            uint32_t interior = 0;
+            for (uint32_t i = 0; i < g.nNodes; ++i) {
+                uint32_t axis = g.nodes[i].countAxis & 3u, cnt = g.nodes[i].countAxis >> 2;
+                if (axis == 3u) { if (g.nodes[i].offset < 0 || cnt == 0 || (uint64_t)g.nodes[i].offset + cnt > g.nPrims) return SetError(HPRT_E_INVALID, "BVH leaf is empty or references primitives out of range"); }
+                else { ++interior; if (g.nodes[i].offset <= (int32_t)i || (uint32_t)g.nodes[i].offset >= g.nNodes || i + 1 >= g.nNodes) return SetError(HPRT_E_INVALID, "BVH interior node has an invalid child"); }
+            }
+            if ((g.nPrims != 0) != (g.nNodes != 0)) return SetError(HPRT_E_INVALID, "aggregate with primitives but no nodes (or the reverse)");
+            for (uint32_t i = 0; i < g.nPrims; ++i) if (g.order[i] >= g.nPrims) return SetError(HPRT_E_INVALID, "prim_order entry out of range");
+            primBase[a] = (uint32_t)np; pairBase[a] = (uint32_t)npair;
+            np += g.nPrims; npair += g.nNodes ? interior + 1u : 0u;
+            if (np * 48ull > 0xffffffffull || npair * 64ull > 0xffffffffull)
+                return SetError(HPRT_E_UNSUPPORTED, "more than 89,478,485 primitives (or 67,108,863 interior nodes) over all aggregates");
+        }
+        primBase[aggs.size()] = (uint32_t)np; pairBase[aggs.size()] = (uint32_t)npair;
+    }
+    const uint32_t totalPrims = primBase[aggs.size()];
     for (uint32_t l = 0; l < d->n_lights; ++l) {
         const HprtLightDesc &L = d->lights[l];
         if (L.type < 0 || L.type > 2) return SetError(HPRT_E_INVALID, "unknown light type");
@@ -251,7 +305,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     if (rc != HPRT_OK) return rc;
 
     HprtScene *sc = new HprtScene();
-    sc->device = dev; sc->nPrims = d->n_prims;
+    sc->device = dev; sc->nPrims = totalPrims;
     std::unique_ptr<HprtScene> guard(sc);
     // ---- flatten ----
     const uint32_t nVtx = (uint32_t)vtxBase[d->n_shapes];
@@ -277,27 +331,34 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
             spheres.push_back(sp);
         }
     }
-    std::vector<float4> tris(3 * (size_t)d->n_prims);
-    std::vector<uint32_t> primVtx(3 * (size_t)d->n_prims, 0u);
-    for (uint32_t i = 0; i < d->n_prims; ++i) {
-        uint64_t pn = d->prim_order[i];
-        uint32_t s = (uint32_t)(std::upper_bound(firstPrim.begin(), firstPrim.end(), pn) - firstPrim.begin() - 1);
-        const HprtShapeDesc &sh = d->shapes[s];
-        float4 r0, r1, r2;
-        if (sh.kind == 0) {
-            uint64_t local = pn - firstPrim[s];
-            const int32_t *v = &sh.indices[3 * local];
-            const float *a = &sh.P[3 * (size_t)v[0]], *b = &sh.P[3 * (size_t)v[1]], *c = &sh.P[3 * (size_t)v[2]];
-            bool bogus = TriangleIsBogus(vec3(a[0], a[1], a[2]), vec3(b[0], b[1], b[2]), vec3(c[0], c[1], c[2]),
-                                         sh.UV ? &sh.UV[2 * (size_t)v[0]] : nullptr, sh.UV ? &sh.UV[2 * (size_t)v[1]] : nullptr,
-                                         sh.UV ? &sh.UV[2 * (size_t)v[2]] : nullptr);
-            uint32_t tag = bogus ? TAG_BOGUS : 0u;
-            r0 = make_float4(a[0], a[1], a[2], u2f(tag)); r1 = make_float4(b[0], b[1], b[2], u2f(s)); r2 = make_float4(c[0], c[1], c[2], u2f(0u));
-            for (int k = 0; k < 3; ++k) primVtx[3 * (size_t)i + k] = (uint32_t)(vtxBase[s] + (uint32_t)v[k]);
-        } else {
-            r0 = make_float4(0, 0, 0, u2f(TAG_SPHERE)); r1 = make_float4(0, 0, 0, u2f(s)); r2 = make_float4(0, 0, 0, u2f((uint32_t)sphereOfShape[s]));
+    std::vector<float4> tris(3 * (size_t)totalPrims);
+    std::vector<uint32_t> primVtx(3 * (size_t)totalPrims, 0u);
+    for (size_t ai = 0; ai < aggs.size(); ++ai) {
+        const Agg &g = aggs[ai];
+        for (uint32_t oi = 0; oi < g.nPrims; ++oi) {
+            const size_t i = (size_t)primBase[ai] + oi;
+            const AggPrim e = g.prims[g.order[oi]];
+            float4 r0, r1, r2;
+            if (e.shape < 0) {     // TransformedPrimitive
+                r0 = make_float4(0, 0, 0, u2f(TAG_INSTANCE)); r1 = make_float4(0, 0, 0, u2f(0u)); r2 = make_float4(0, 0, 0, u2f(e.local));
+            } else {
+                const uint32_t s = (uint32_t)e.shape;
+                const HprtShapeDesc &sh = d->shapes[s];
+                if (sh.kind == 0) {
+                    const int32_t *v = &sh.indices[3 * (size_t)e.local];
+                    const float *a = &sh.P[3 * (size_t)v[0]], *b = &sh.P[3 * (size_t)v[1]], *c = &sh.P[3 * (size_t)v[2]];
+                    bool bogus = TriangleIsBogus(vec3(a[0], a[1], a[2]), vec3(b[0], b[1], b[2]), vec3(c[0], c[1], c[2]),
+                                                 sh.UV ? &sh.UV[2 * (size_t)v[0]] : nullptr, sh.UV ? &sh.UV[2 * (size_t)v[1]] : nullptr,
+                                                 sh.UV ? &sh.UV[2 * (size_t)v[2]] : nullptr);
+                    uint32_t tag = bogus ? TAG_BOGUS : 0u;
+                    r0 = make_float4(a[0], a[1], a[2], u2f(tag)); r1 = make_float4(b[0], b[1], b[2], u2f(s)); r2 = make_float4(c[0], c[1], c[2], u2f(0u));
+                    for (int k = 0; k < 3; ++k) primVtx[3 * i + k] = (uint32_t)(vtxBase[s] + (uint32_t)v[k]);
+                } else {
+                    r0 = make_float4(0, 0, 0, u2f(TAG_SPHERE)); r1 = make_float4(0, 0, 0, u2f(s)); r2 = make_float4(0, 0, 0, u2f((uint32_t)sphereOfShape[s]));
+                }
+            }
+            tris[3 * i] = r0; tris[3 * i + 1] = r1; tris[3 * i + 2] = r2;
         }
-        tris[3 * (size_t)i] = r0; tris[3 * (size_t)i + 1] = r1; tris[3 * (size_t)i + 2] = r2;
     }
     std::vector<DevMaterial> mats(d->n_materials);
     for (uint32_t m = 0; m < d->n_materials; ++m) {
@@ -328,20 +389,22 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     }
     // Halton tables + 64-bit division magics
     const std::vector<uint16_t> &perms = HaltonPermutations();
-    // ---- child-pair layout of the BVH (device/dev_scene.h) ----
-    std::vector<DevPair> pairs;
-    if (d->n_nodes) {
-        const BvhNode *nd = (const BvhNode *)d->nodes;
-        std::vector<int32_t> ref(d->n_nodes);
-        int32_t nextPair = 1;
-        for (uint32_t i = 0; i < d->n_nodes; ++i) {
+    // ---- child-pair layout of the BVHs (device/dev_scene.h): one run of pairs per aggregate ----
+    std::vector<DevPair> pairs((size_t)pairBase[aggs.size()]);
+    bool nested = true;      // child bounds inside the parent's: what BVHAccel's builder produces; hand-made trees may not
+    for (size_t ai = 0; ai < aggs.size(); ++ai) {
+        const Agg &g = aggs[ai];
+        if (g.nNodes == 0) continue;
+        const BvhNode *nd = g.nodes;
+        std::vector<int32_t> ref(g.nNodes);
+        int32_t nextPair = (int32_t)pairBase[ai] + 1;
+        for (uint32_t i = 0; i < g.nNodes; ++i) {
             if ((nd[i].countAxis & 3u) == 3u) {
-                ref[i] = ~nd[i].offset;
-                const uint32_t last = (uint32_t)nd[i].offset + (nd[i].countAxis >> 2) - 1u;
-                tris[3 * (size_t)last].w = u2f(f2u(tris[3 * (size_t)last].w) | TAG_LAST);
+                ref[i] = ~(int32_t)(primBase[ai] + (uint32_t)nd[i].offset);
+                const size_t last = (size_t)primBase[ai] + (uint32_t)nd[i].offset + (nd[i].countAxis >> 2) - 1u;
+                tris[3 * last].w = u2f(f2u(tris[3 * last].w) | TAG_LAST);
             } else ref[i] = nextPair++;
         }
-        pairs.resize((size_t)nextPair);
         auto fill = [&](DevPair &p, uint32_t c0, uint32_t c1, uint32_t meta) {
             const BvhNode &a = nd[c0], &b = nd[c1];
             p.x[0] = a.bmin[0]; p.x[1] = b.bmin[0]; p.x[2] = a.bmax[0]; p.x[3] = b.bmax[0];
@@ -349,9 +412,28 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
             p.z[0] = a.bmin[2]; p.z[1] = b.bmin[2]; p.z[2] = a.bmax[2]; p.z[3] = b.bmax[2];
             p.ref0 = ref[c0]; p.ref1 = ref[c1]; p.meta = meta; p.pad = 0u;
         };
-        fill(pairs[0], 0u, 0u, PAIR_SINGLE);
-        for (uint32_t i = 0; i < d->n_nodes; ++i)
-            if ((nd[i].countAxis & 3u) != 3u) fill(pairs[(size_t)ref[i]], i + 1u, (uint32_t)nd[i].offset, nd[i].countAxis & 3u);
+        fill(pairs[pairBase[ai]], 0u, 0u, PAIR_SINGLE);      // synthetic parent of the root: carries the root's bounds test
+        for (uint32_t i = 0; i < g.nNodes; ++i) {
+            if ((nd[i].countAxis & 3u) == 3u) continue;
+            const uint32_t c[2] = {i + 1u, (uint32_t)nd[i].offset};
+            fill(pairs[(size_t)ref[i]], c[0], c[1], nd[i].countAxis & 3u);
+            for (int k = 0; k < 2; ++k)
+                for (int ax = 0; ax < 3; ++ax)
+                    if (!(nd[c[k]].bmin[ax] >= nd[i].bmin[ax] && nd[c[k]].bmax[ax] <= nd[i].bmax[ax])) nested = false;
+        }
+    }
+    (void)nested;
+    std::vector<DevInstance> instances(d->n_instances);
+    for (uint32_t i = 0; i < d->n_instances; ++i) {
+        const HprtInstanceDesc &in = d->instances[i];
+        DevInstance &o = instances[i];
+        memcpy(o.i2w.m, in.instance_to_world, 64); memcpy(o.w2i.m, in.world_to_instance, 64);
+        const size_t ai = 1 + (size_t)in.object;
+        // more than one primitive: the object's aggregate; one: that primitive itself, without a bounds test (core/api.cpp:1798-1806)
+        o.root = aggs[ai].nPrims > 1 ? (int32_t)pairBase[ai] : ~(int32_t)primBase[ai];
+        bool ident = true;                                   // Transform::IsIdentity, core/transform.h:148-155
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) if (o.i2w.m[r][c] != (r == c ? 1.f : 0.f)) ident = false;
+        o.identity = ident ? 1u : 0u; o.pad[0] = o.pad[1] = 0u;
     }
     std::vector<int32_t> primes(PrimeTable().begin(), PrimeTable().end()), primeSums(PrimeSumTable().begin(), PrimeSumTable().end());
     std::vector<uint64_t> magic(primes.size());
@@ -360,7 +442,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     HIP_TRY(upload(sc->nodes, pairs)); HIP_TRY(upload(sc->tris, tris)); HIP_TRY(upload(sc->primVtx, primVtx));
     HIP_TRY(upload(sc->vN, vN)); HIP_TRY(upload(sc->vUV, vUV)); HIP_TRY(upload(sc->vS, vS));
     HIP_TRY(upload(sc->shapes, shapes)); HIP_TRY(upload(sc->materials, mats)); HIP_TRY(upload(sc->lights, lights));
-    HIP_TRY(upload(sc->spheres, spheres)); HIP_TRY(upload(sc->lightFunc, func)); HIP_TRY(upload(sc->lightCdf, cdf));
+    HIP_TRY(upload(sc->spheres, spheres)); HIP_TRY(upload(sc->instances, instances)); HIP_TRY(upload(sc->lightFunc, func)); HIP_TRY(upload(sc->lightCdf, cdf));
     HIP_TRY(upload(sc->perms, perms)); HIP_TRY(upload(sc->primes, primes)); HIP_TRY(upload(sc->primeSums, primeSums));
     HIP_TRY(upload(sc->primeMagic, magic));
     HIP_TRY(sc->counters.alloc(sizeof(DevCounters)));
@@ -368,13 +450,14 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     HIP_TRY(sc->workCounter.alloc(64));
     DevScene &dv = sc->dev;
     dv.pairs = sc->nodes.as<DevPair>(); dv.nPairs = (uint32_t)pairs.size();
-    dv.tris = sc->tris.as<float4>(); dv.nPrims = d->n_prims;
+    dv.tris = sc->tris.as<float4>(); dv.nPrims = totalPrims;
     dv.primVtx = sc->primVtx.as<uint32_t>();
     dv.vN = sc->vN.as<float>(); dv.vUV = sc->vUV.as<float>(); dv.vS = sc->vS.as<float>();
     dv.shapes = sc->shapes.as<DevShape>(); dv.nShapes = d->n_shapes;
     dv.materials = sc->materials.as<DevMaterial>();
     dv.lights = sc->lights.as<DevLight>(); dv.nLights = d->n_lights;
     dv.spheres = sc->spheres.as<DevSphere>();
+    dv.instances = sc->instances.as<DevInstance>();
     dv.lightFunc = sc->lightFunc.as<float>(); dv.lightCdf = sc->lightCdf.as<float>(); dv.lightFuncInt = funcInt;
     dv.perms = sc->perms.as<uint16_t>(); dv.primes = sc->primes.as<int32_t>(); dv.primeSums = sc->primeSums.as<int32_t>();
     dv.primeMagic = sc->primeMagic.as<uint64_t>();
@@ -425,7 +508,32 @@ int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int devic
         const LightDesc &s = sm.lights[i];
         lights[i].type = s.type; memcpy(lights[i].pos, s.pos, 12); memcpy(lights[i].I, s.I, 12); lights[i].shape = s.shape; lights[i].two_sided = s.twoSided;
     }
+    if (b->objects.size() != sm.nObjects) return SetError(HPRT_E_INVALID, "the BVH was built for another model (object count differs)");
+    // object definitions: their shapes are contiguous (no nesting of definitions, core/api.cpp:1755-1756)
+    std::vector<HprtObjectDesc> objects(sm.nObjects);
+    for (uint32_t k = 0; k < sm.nObjects; ++k) {
+        HprtObjectDesc &o = objects[k];
+        memset(&o, 0, sizeof(o));
+        bool any = false;
+        for (size_t i = 0; i < sm.shapes.size(); ++i)
+            if (sm.shapes[i].object == (int32_t)k) { if (!any) { o.first_shape = (uint32_t)i; any = true; } o.n_shapes = (uint32_t)i + 1u - o.first_shape; }
+        const BvhTree &t = b->objects[k];
+        o.nodes = t.nodes.data(); o.n_nodes = (uint32_t)t.nodes.size(); o.prim_order = t.primOrder.data(); o.n_prims = (uint32_t)t.primOrder.size();
+    }
+    std::vector<HprtInstanceDesc> instances(sm.instances.size());
+    for (size_t i = 0; i < instances.size(); ++i) {
+        instances[i].object = sm.instances[i].object;
+        memcpy(instances[i].instance_to_world, sm.instances[i].instanceToWorld.m, 64);
+        memcpy(instances[i].world_to_instance, sm.instances[i].worldToInstance.m, 64);
+    }
+    std::vector<HprtTopItem> top(sm.top.size());
+    for (size_t i = 0; i < top.size(); ++i) { top[i].kind = sm.top[i].kind; top[i].index = sm.top[i].index; }
     HprtSceneDesc d;
+    memset(&d, 0, sizeof(d));
+    d.objects = objects.data(); d.n_objects = (uint32_t)objects.size();
+    d.instances = instances.data(); d.n_instances = (uint32_t)instances.size();
+    static const HprtTopItem kNoItems[1] = {{0, 0u}};
+    d.top = top.empty() ? kNoItems : top.data(); d.n_top = (uint32_t)top.size();
     d.nodes = b->tree.nodes.data(); d.n_nodes = (uint32_t)b->tree.nodes.size();
     d.prim_order = b->tree.primOrder.data(); d.n_prims = (uint32_t)b->tree.primOrder.size();
     d.shapes = shapes.data(); d.n_shapes = (uint32_t)shapes.size();
@@ -454,9 +562,9 @@ static void ReadCounters(HprtScene *s, bool anyHit, uint64_t out[4]) {
 // Stream copies for the plane-layout entry points ([7][n] rays in; t, prim, [3][n] barycentrics out)
 static int ApiStreams(HprtScene *s, size_t n, RayStream *rays, HitStream *hits) {
     HIP_TRY(s->apiRays.alloc(32 * n + 256));
-    HIP_TRY(s->apiHits.alloc(20 * n + 256));
+    HIP_TRY(s->apiHits.alloc(24 * n + 256));
     rays->a = s->apiRays.as<float4>(); rays->b = rays->a + n;
-    hits->a = s->apiHits.as<float4>(); hits->b2 = (float *)(hits->a + n);
+    hits->a = s->apiHits.as<float4>(); hits->b = (float2 *)(hits->a + n);
     return HPRT_OK;
 }
 
@@ -485,14 +593,14 @@ int hprt_occluded_device(HprtScene *s, size_t n, const float *d_rays7, uint8_t *
     if (rc != HPRT_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     LaunchPackRays(st, d_rays7, (uint32_t)n, rays);
-    HitStream none; none.a = nullptr; none.b2 = nullptr;
+    HitStream none; none.a = nullptr; none.b = nullptr;
     LaunchTrace(st, s->dev, true, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, rays, none, d_occ, nullptr, s->workCounter.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     return HPRT_OK;
 }
 
 static int TraceHost(HprtScene *s, bool anyHit, size_t n, const float *o, const float *d, const float *tmax, float *t_out,
-                     int32_t *prim_out, float *bary_out, uint8_t *occ_out, uint64_t counters[4]) {
+                     int32_t *prim_out, int32_t *inst_out, float *bary_out, uint8_t *occ_out, uint64_t counters[4]) {
     if (!s || (n && (!o || !d || !tmax))) return SetError(HPRT_E_INVALID, "trace: null argument");
     if (n > 0x7ffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
     if (n == 0) { if (counters) memset(counters, 0, 32); return HPRT_OK; }
@@ -512,18 +620,19 @@ static int TraceHost(HprtScene *s, bool anyHit, size_t n, const float *o, const 
     if (!anyHit) {
         LaunchTrace(nullptr, s->dev, false, count, nullptr, nullptr, (uint32_t)n, (uint32_t)n, rays, hits, nullptr, s->counters.as<DevCounters>(), s->workCounter.as<uint32_t>());
         HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
-        std::vector<float4> ha(n); std::vector<float> hb2(n);
+        std::vector<float4> ha(n); std::vector<float2> hb(n);
         HIP_TRY(hipMemcpy(ha.data(), hits.a, 16 * n, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(hb2.data(), hits.b2, 4 * n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hb.data(), hits.b, 8 * n, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; ++i) {
             if (t_out) t_out[i] = ha[i].x;
             if (prim_out) memcpy(&prim_out[i], &ha[i].y, 4);
-            if (bary_out) { bary_out[3 * i] = ha[i].z; bary_out[3 * i + 1] = ha[i].w; bary_out[3 * i + 2] = hb2[i]; }
+            if (inst_out) memcpy(&inst_out[i], &hb[i].y, 4);
+            if (bary_out) { bary_out[3 * i] = ha[i].z; bary_out[3 * i + 1] = ha[i].w; bary_out[3 * i + 2] = hb[i].x; }
         }
     } else {
         DevBuf outOcc;
         HIP_TRY(outOcc.alloc(n));
-        HitStream none; none.a = nullptr; none.b2 = nullptr;
+        HitStream none; none.a = nullptr; none.b = nullptr;
         LaunchTrace(nullptr, s->dev, true, count, nullptr, nullptr, (uint32_t)n, (uint32_t)n, rays, none, outOcc.as<uint8_t>(), s->counters.as<DevCounters>(), s->workCounter.as<uint32_t>());
         HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
         if (occ_out) HIP_TRY(hipMemcpy(occ_out, outOcc.p, n, hipMemcpyDeviceToHost));
@@ -533,10 +642,14 @@ static int TraceHost(HprtScene *s, bool anyHit, size_t n, const float *o, const 
 }
 int hprt_intersect(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, float *t_out, int32_t *prim_out,
                    float *bary_out, uint64_t counters[4]) {
-    return TraceHost(s, false, n, o, d, tmax, t_out, prim_out, bary_out, nullptr, counters);
+    return TraceHost(s, false, n, o, d, tmax, t_out, prim_out, nullptr, bary_out, nullptr, counters);
+}
+int hprt_intersect_instanced(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, float *t_out, int32_t *prim_out,
+                             int32_t *inst_out, float *bary_out, uint64_t counters[4]) {
+    return TraceHost(s, false, n, o, d, tmax, t_out, prim_out, inst_out, bary_out, nullptr, counters);
 }
 int hprt_occluded(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, uint8_t *occ, uint64_t counters[4]) {
-    return TraceHost(s, true, n, o, d, tmax, nullptr, nullptr, nullptr, occ, counters);
+    return TraceHost(s, true, n, o, d, tmax, nullptr, nullptr, nullptr, nullptr, occ, counters);
 }
 
 // ---------------------------------------------------------------------------
@@ -576,7 +689,7 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         if (nShadow) {
             hipEvent_t a = ev.get(), b = ev.get();
             HIP_TRY(hipEventRecord(a, st));
-            HitStream none; none.a = nullptr; none.b2 = nullptr;
+            HitStream none; none.a = nullptr; none.b = nullptr;
             LaunchTrace(st, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, w.vs.shadow, none, w.vs.occluded, ctr, s->workCounter.as<uint32_t>());
             HIP_TRY(hipEventRecord(b, st));
             evOcc.push_back({a, b}); bt->occludedRays += nShadow; ++bt->occludedLaunches;

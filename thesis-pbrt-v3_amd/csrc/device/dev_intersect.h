@@ -184,7 +184,7 @@ __device__ __noinline__ bool sphere_test(const DevSphere &s, const DRay &r, DRay
 
 struct TraceCount { unsigned int fetched, entered, tri, sphere; };
 
-// `cur` of a lane: >= 0 interior pair, REF_NONE finished, otherwise ~(parked primitive index)
-__device__ __forceinline__ bool is_parked(int cur) { return (uint32_t)cur > 0x80000000u; }
+// `cur` of a lane: >= 0 interior pair, REF_NONE finished, REF_EXIT leaving an instance, otherwise ~(parked primitive index)
+__device__ __forceinline__ bool is_parked(int cur) { return (uint32_t)cur > (uint32_t)REF_EXIT; }
 
 }  // namespace hprt

@@ -21,7 +21,10 @@
 //                                    shapes/triangle.cpp:309-316, IntersectP does not), bit 3
 //                                    "last primitive of its leaf" (ends the leaf loop of
 //                                    accelerators/bvh.cpp:370-373 without a count).
-//                                    For spheres aux = sphere index.
+//                                    For spheres aux = sphere index; kind 2 is an object
+//                                    instance (TransformedPrimitive) with aux = instance index.
+//                                    The primitives of all aggregates share this array: the top
+//                                    level first, then each object definition's.
 //   primVtx    uint32[3*nPrims]     global vertex ids of the ordered triangle (shading only)
 //   vN/vUV/vS  float[3|2|3 * nVtx]  shading attributes; a shape's presence bits say which
 //   shapes, materials, lights, spheres, lightCdf: small tables.
@@ -35,15 +38,20 @@ namespace hprt {
 // leaf child.  meta: split axis (bits 0-1) | PAIR_SINGLE.
 struct DevPair { float x[4], y[4], z[4]; int32_t ref0, ref1; uint32_t meta, pad; };
 enum : uint32_t { PAIR_SINGLE = 4u };
-enum : int32_t { REF_NONE = (int32_t)0x80000000 };
+// REF_NONE: nothing left.  REF_EXIT: stack sentinel under an instance's walk — popping it ends the
+// instance (TransformedPrimitive::Intersect returns, core/primitive.cpp:77-93)
+enum : int32_t { REF_NONE = (int32_t)0x80000000, REF_EXIT = (int32_t)0x80000001 };
 
-enum : uint32_t { TAG_KIND_MASK = 3u, TAG_SPHERE = 1u, TAG_BOGUS = 4u, TAG_LAST = 8u };
+enum : uint32_t { TAG_KIND_MASK = 3u, TAG_SPHERE = 1u, TAG_INSTANCE = 2u, TAG_BOGUS = 4u, TAG_LAST = 8u };
 enum : uint32_t { SHAPE_FLIP = 1u, SHAPE_HAS_N = 2u, SHAPE_HAS_UV = 4u, SHAPE_HAS_S = 8u, SHAPE_REVERSE = 16u };
 
 struct DevShape { int32_t material, areaLight; uint32_t flags; int32_t sphere; };
 struct DevMaterial { int32_t type; float Kd[3]; float Ks[3]; float alpha; };   // alpha: RoughnessToAlpha applied on the host
 struct DevLight { int32_t type; float pos[3]; float I[3]; int32_t shape; int32_t twoSided; int32_t sphere; uint32_t shapeFlags; };
 struct DevSphere { mat4 o2w, w2o; float radius, zMin, zMax, thetaMin, thetaMax, phiMax; };
+// ObjectInstance: the wrapped aggregate's entry (pair index, or ~primitive when the object holds a
+// single primitive: no aggregate, no bounds test) and the static instance transform
+struct DevInstance { mat4 i2w, w2i; int32_t root; uint32_t identity; uint32_t pad[2]; };
 
 struct DevScene {
     const DevPair *pairs; uint32_t nPairs;
@@ -54,6 +62,7 @@ struct DevScene {
     const DevMaterial *materials;
     const DevLight *lights; uint32_t nLights;
     const DevSphere *spheres;
+    const DevInstance *instances;
     const float *lightFunc, *lightCdf; float lightFuncInt;      // Distribution1D (core/sampling.h:55-109)
     float worldRadius;                                           // DistantLight::Preprocess
     // Halton tables

@@ -14,7 +14,7 @@ namespace hprt {
 // (in ascending runs, one per workgroup), so gathers stay almost sequential however thin the
 // paths become.
 struct RayStream { float4 *a, *b; };                 // a = {o.xyz, tMax}   b = {d.xyz, aux}
-struct HitStream { float4 *a; float *b2; };          // a = {t, prim, b0, b1}; b2 may be null
+struct HitStream { float4 *a; float2 *b; };           // a = {t, prim, b0, b1}   b = {b2, instance or -1}; b may be null
 struct PathStream {
     RayStream ray;          // current path segment; ray.b.w = sampler dimension (bits 0-7) | bounces (bits 8-15)
     float4 *beta;           // {beta.rgb, path id}   path id = sampleInBatch * nPix + pixel
@@ -76,7 +76,7 @@ void LaunchStoreRadiance(hipStream_t st, const float4 *Lfinal, float *LallR, flo
                          uint32_t nSlots);
 // the *_device entry points of include/hprt.h keep their plane layouts: [7][n] rays in, t / prim / [3][n] barycentrics out
 void LaunchPackRays(hipStream_t st, const float *rays7, uint32_t n, const RayStream &out);
-void LaunchUnpackHits(hipStream_t st, const HitStream &hits, uint32_t n, float *t, int32_t *prim, float *bary3);
+void LaunchUnpackHits(hipStream_t st, const HitStream &hits, uint32_t n, float *t, int32_t *prim, float *bary3);   // instance ids stay in hits.b
 void LaunchFindIrregular(hipStream_t st, const DevScene &sc, const RenderParams &rp, const FilmGeom &fg, uint32_t spp, uint32_t *count,
                          uint32_t capacity, IrregularSample *out);
 void LaunchFilmOwn(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, const float *LallR, const float *LallG, const float *LallB,

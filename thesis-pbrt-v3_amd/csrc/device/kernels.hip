@@ -189,7 +189,14 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
     bool negX = false, negY = false, negZ = false;
     int sp = 0, cur = REF_NONE;
     int32_t prim = -1; float hb0 = 0.f, hb1 = 0.f, hb2 = 0.f;
-    bool sphereWait = false; uint32_t sphereInfo = 0u;   // the parked primitive is a quadric awaiting its (batched) test
+    // A parked primitive that is not a triangle waits for the batched slow phase: wait 1 = quadric test,
+    // 2 = entering an object instance (TransformedPrimitive, core/primitive.cpp:77-102); waitInfo = sphere /
+    // instance index | bit 31 "last primitive of its leaf".  cur == REF_EXIT waits there too (leaving one).
+    uint32_t wait = 0u, waitInfo = 0u;
+    int inst = -1, hitInst = -1;          // instance being walked / instance of the closest hit so far
+    bool instHit = false;                 // a hit was recorded inside the instance being walked
+    uint32_t instPrim = 0u;               // top-level ordered index of that instance's primitive | bit 31 "last of its leaf"
+    float savedTMax = 0.f;                // world tMax at the moment the instance was entered
     volatile uint32_t spillRef[HPRT_SPILL_STACK], spillT[HPRT_SPILL_STACK];   // volatile: keeps the rare scratch path out of the LDS one
     bool moreWork = n > 0 && sc.nPairs > 0;
 
@@ -199,6 +206,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
             --sp;
             uint2 e;
             if (sp < HPRT_LDS_STACK) e = ldsStack[sp * HPRT_TRACE_BLOCK]; else e = make_uint2(spillRef[sp - HPRT_LDS_STACK], spillT[sp - HPRT_LDS_STACK]);
+            if ((int)e.x == REF_EXIT) { savedTMax = __uint_as_float(e.y); return REF_EXIT; }     // the instance's walk is over
             if (COUNT) ++cnt.fetched;
             if (__uint_as_float(e.y) < rayTMax) { if (COUNT) ++cnt.entered; return (int)e.x; }
         }
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
             const uint32_t s = queue ? queue[i] : i;
             if (ANY_HIT) occ[s] = 0;
-            else { hits.a[s] = make_float4(rays.a[s].w, __int_as_float(-1), 0.f, 0.f); if (hits.b2) hits.b2[s] = 0.f; }
+            else { hits.a[s] = make_float4(rays.a[s].w, __int_as_float(-1), 0.f, 0.f); if (hits.b) hits.b[s] = make_float2(0.f, __int_as_float(-1)); }
         }
     }
     while (true) {
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                         negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
                         shear = ray_shear(rd);
                         sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
-                        sphereWait = false;
+                        wait = 0u; inst = -1; hitInst = -1; instHit = false;
                         active = true;
                     }
                 }
@@ -299,17 +307,17 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                     }
                 }
                 ++steps;
-                if (steps >= tune.stepLimit || __popcll(__ballot(active && is_parked(cur) && !sphereWait)) >= tune.parkLimit) break;
+                if (steps >= tune.stepLimit || __popcll(__ballot(active && is_parked(cur) && wait == 0u)) >= tune.parkLimit) break;
             }
             const unsigned long long pfT2 = PROF ? clock64() : 0ull;
             if (PROF) pf[2] += pfT2 - pfT1;
             unsigned long long pfSphere = 0ull;
             // phase 2: the parked primitives (wave-uniform loop over the longest leaf run).
             // Quadric primitives are expensive (interval arithmetic) and reached by lanes at
-            // different times, so a lane that meets one waits (sphereWait) until `sphereLimit`
+            // different times, so a lane that meets one waits (wait = 1) until `sphereLimit`
             // lanes wait or nothing else can run, and the test runs once for all of them.
             while (true) {
-                const bool pending = active && is_parked(cur) && !sphereWait;
+                const bool pending = active && is_parked(cur) && wait == 0u;
                 const int nPending = __popcll(__ballot(pending));
                 // too few parked lanes for a primitive test to pay: let the others walk first
                 if (nPending != 0 && nPending < tune.primMin && __ballot(active && cur >= 0) != 0ull) break;
@@ -332,36 +340,82 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                                          vec3(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
                                          vec3(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z)), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
                                 if (ANY_HIT) { hit = true; done = true; }
-                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = b0; hb1 = b1; hb2 = b2; }
+                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = b0; hb1 = b1; hb2 = b2; hitInst = inst; instHit = inst >= 0; }
                             }
                             if (done) cur = REF_NONE;
                             else if (tag & TAG_LAST) cur = pop();
                             else --cur;                                  // ~(pi + 1)
-                        } else { sphereWait = true; sphereInfo = v2.w | ((tag & TAG_LAST) ? 0x80000000u : 0u); }
+                        } else { wait = tag & TAG_KIND_MASK; waitInfo = v2.w | ((tag & TAG_LAST) ? 0x80000000u : 0u); }
                     }
                     continue;
                 }
-                const int nWait = __popcll(__ballot(sphereWait));
+                const bool slow = active && (wait != 0u || cur == REF_EXIT);
+                const int nWait = __popcll(__ballot(slow));
                 if (nWait == 0) break;
                 const bool canWalk = __ballot(active && cur >= 0) != 0ull;
                 if (nWait < tune.sphereLimit && canWalk) break;      // keep waiting, let the others walk
                 const unsigned long long pfT3 = PROF ? clock64() : 0ull;
                 if (PROF) { pf[11] += 1; pf[12] += nWait; }
-                if (sphereWait) {
+                if (wait == 1u) {
                     const uint32_t pi = (uint32_t)~cur;
-                    sphereWait = false;
+                    wait = 0u;
                     if (COUNT) ++cnt.sphere;
                     DRay rr; rr.o = ro; rr.tMax = rayTMax;
                     { const float4 rb = rays.b[slot]; rr.d = vec3(rb.x, rb.y, rb.z); }
+                    if (inst >= 0) rr.d = xf_vector(sc.instances[inst].w2i, rr.d);      // the instance-space direction, recomputed
                     DRay robj; vec3 ph; float phi, t;
                     bool done = false;
-                    if (sphere_test(sc.spheres[sphereInfo & 0x7fffffffu], rr, &robj, &ph, &phi, &t)) {
+                    if (sphere_test(sc.spheres[waitInfo & 0x7fffffffu], rr, &robj, &ph, &phi, &t)) {
                         if (ANY_HIT) { hit = true; done = true; }
-                        else { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; }
+                        else { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; hitInst = inst; instHit = inst >= 0; }
                     }
                     if (done) cur = REF_NONE;
-                    else if (sphereInfo & 0x80000000u) cur = pop();
+                    else if (waitInfo & 0x80000000u) cur = pop();
                     else --cur;
+                }
+                if (wait == 2u) {
+                    // TransformedPrimitive::Intersect: Ray ray = Inverse(InterpolatedPrimToWorld)(r), i.e.
+                    // Transform::operator()(const Ray &) (core/transform.h:251-264); then walk the object's aggregate
+                    const uint32_t pi = (uint32_t)~cur;
+                    wait = 0u;
+                    inst = (int)(waitInfo & 0x7fffffffu);
+                    instPrim = pi | (waitInfo & 0x80000000u);
+                    instHit = false;
+                    const DevInstance &in = sc.instances[inst];
+                    const float4 rb = rays.b[slot];
+                    vec3 oErr;
+                    vec3 o2 = xf_point_err(in.w2i, ro, &oErr);
+                    const vec3 d2 = xf_vector(in.w2i, vec3(rb.x, rb.y, rb.z));
+                    const float lengthSquared = d2.x * d2.x + d2.y * d2.y + d2.z * d2.z;
+                    float tm = rayTMax;
+                    if (lengthSquared > 0) {
+                        const float dt = dot(vabs(d2), oErr) / lengthSquared;
+                        o2 = o2 + d2 * dt;
+                        tm -= dt;
+                    }
+                    const uint2 e = make_uint2((uint32_t)REF_EXIT, __float_as_uint(rayTMax));
+                    if (sp < HPRT_LDS_STACK) ldsStack[sp * HPRT_TRACE_BLOCK] = e;
+                    else if (sp < HPRT_LDS_STACK + HPRT_SPILL_STACK) { spillRef[sp - HPRT_LDS_STACK] = e.x; spillT[sp - HPRT_LDS_STACK] = e.y; }
+                    ++sp;       // a full stack cannot take the sentinel: such depths are outside what the reference supports either (64 entries)
+                    ro = o2; rayTMax = tm;
+                    invDir = vec3(1 / d2.x, 1 / d2.y, 1 / d2.z);
+                    negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
+                    shear = ray_shear(d2);
+                    cur = in.root;
+                }
+                if (cur == REF_EXIT) {
+                    // back in world space: r.tMax = ray.tMax only if the instance was hit (core/primitive.cpp:85-86)
+                    const float worldT = instHit ? rayTMax : savedTMax;
+                    const float4 ra = rays.a[slot], rb = rays.b[slot];
+                    ro = vec3(ra.x, ra.y, ra.z);
+                    const vec3 rd(rb.x, rb.y, rb.z);
+                    invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
+                    negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
+                    shear = ray_shear(rd);
+                    rayTMax = worldT;
+                    inst = -1; instHit = false;
+                    if (instPrim & 0x80000000u) cur = pop();
+                    else cur = ~(int)((instPrim & 0x7fffffffu) + 1u);
                 }
                 if (PROF) pfSphere += clock64() - pfT3;
             }
@@ -371,7 +425,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                 if (ANY_HIT) occ[slot] = hit ? 1 : 0;
                 else {
                     hits.a[slot] = make_float4(rayTMax, __int_as_float(hit ? prim : -1), hb0, hb1);
-                    if (hits.b2) hits.b2[slot] = hb2;
+                    if (hits.b) hits.b[slot] = make_float2(hb2, __int_as_float(hit ? hitInst : -1));
                 }
                 active = false;
             }
@@ -437,7 +491,9 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
         const int bounces = (int)((__float_as_uint(in.ray.b[slot].w) >> 8) & 0xffu);
         if (prim >= 0) {
             const uint32_t tag = __float_as_uint(sc.tris[3 * prim].w);
-            const bool isTri = (tag & TAG_KIND_MASK) == 0u;
+            // triangles reached directly go to the material-specialised variants; quadrics and hits inside
+            // object instances (surface interaction transformed back to world space) to the generic one
+            const bool isTri = (tag & TAG_KIND_MASK) == 0u && __float_as_int(hit.b[slot].y) < 0;
             if (bounces >= maxDepth) { if (bounces == 0 && !isTri) bin = 2; }   // only an emitter hit by a camera ray matters
             else if (!isTri) bin = 2;
             else bin = sc.materials[sc.shapes[__float_as_uint(sc.tris[3 * prim + 1].w)].material].type == 1 ? 1 : 0;
@@ -493,12 +549,39 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
         DevSI si;
         if (found) {
             const float4 v0 = sc.tris[3 * prim];
+            const float2 hitB = hit.b[slot];
+            // A hit inside an object instance was found by the instance-space ray: the surface interaction is
+            // filled there and transformed back (TransformedPrimitive::Intersect, core/primitive.cpp:77-93)
+            const int inst = MODE == 2 ? __float_as_int(hitB.y) : -1;
+            DRay r0; r0.o = rayO; r0.d = rayD; r0.tMax = rayA.w;
+            if (MODE == 2 && inst >= 0) {      // Transform::operator()(const Ray &), core/transform.h:251-264
+                const DevInstance &in = sc.instances[inst];
+                vec3 oErr;
+                r0.o = xf_point_err(in.w2i, rayO, &oErr);
+                r0.d = xf_vector(in.w2i, rayD);
+                const float lengthSquared = r0.d.x * r0.d.x + r0.d.y * r0.d.y + r0.d.z * r0.d.z;
+                if (lengthSquared > 0) {
+                    const float dt = dot(vabs(r0.d), oErr) / lengthSquared;
+                    r0.o = r0.o + r0.d * dt;
+                    r0.tMax -= dt;
+                }
+            }
             if (MODE != 2 || (__float_as_uint(v0.w) & TAG_KIND_MASK) == 0u)
-                fill_triangle(sc, (uint32_t)prim, hitA.z, hitA.w, hit.b2[slot], rayD, &si);
+                fill_triangle(sc, (uint32_t)prim, hitA.z, hitA.w, hitB.x, r0.d, &si);
             else {
-                DRay r0; r0.o = rayO; r0.d = rayD; r0.tMax = rayA.w;
                 float tt;
                 fill_sphere(sc, (int)__float_as_uint(sc.tris[3 * prim + 1].w), r0, &si, &tt);
+            }
+            if (MODE == 2 && inst >= 0 && !sc.instances[inst].identity) {
+                // Transform::operator()(const SurfaceInteraction &), core/transform.cpp:262-297
+                const DevInstance &in = sc.instances[inst];
+                vec3 pErr;
+                si.p = xf_point_err_in(in.i2w, si.p, si.pErr, &pErr); si.pErr = pErr;
+                si.n = normalize(xf_normal(in.w2i, si.n));
+                si.wo = normalize(xf_vector(in.i2w, si.wo));
+                si.ns = normalize(xf_normal(in.w2i, si.ns));
+                si.sdpdu = xf_vector(in.i2w, si.sdpdu);
+                si.ns = face_forward(si.ns, si.n);
             }
             // emitted radiance at the first vertex (path.cpp:97-107; no specular lobes exist here).
             // Triangle meshes carry no area lights in this build, so only the generic variant looks.
@@ -876,7 +959,7 @@ __global__ __launch_bounds__(256) void k_unpack_hits(HitStream h, uint32_t n, fl
     if (i >= n) return;
     const float4 a = h.a[i];
     t[i] = a.x; prim[i] = __float_as_int(a.y);
-    if (bary3) { const size_t N = n; bary3[i] = a.z; bary3[N + i] = a.w; bary3[2 * N + i] = h.b2[i]; }
+    if (bary3) { const size_t N = n; bary3[i] = a.z; bary3[N + i] = a.w; bary3[2 * N + i] = h.b[i].x; }
 }
 void LaunchPackRays(hipStream_t st, const float *rays7, uint32_t n, const RayStream &out) {
     if (n) hipLaunchKernelGGL(k_pack_rays, dim3(blocks_for(n, 256)), dim3(256), 0, st, rays7, n, out);
