@@ -457,7 +457,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     dv.materials = sc->materials.as<DevMaterial>();
     dv.lights = sc->lights.as<DevLight>(); dv.nLights = d->n_lights;
     dv.spheres = sc->spheres.as<DevSphere>();
-    dv.instances = sc->instances.as<DevInstance>();
+    dv.instances = sc->instances.as<DevInstance>(); dv.nInstances = d->n_instances;
     dv.lightFunc = sc->lightFunc.as<float>(); dv.lightCdf = sc->lightCdf.as<float>(); dv.lightFuncInt = funcInt;
     dv.perms = sc->perms.as<uint16_t>(); dv.primes = sc->primes.as<int32_t>(); dv.primeSums = sc->primeSums.as<int32_t>();
     dv.primeMagic = sc->primeMagic.as<uint64_t>();

@@ -62,7 +62,7 @@ struct DevScene {
     const DevMaterial *materials;
     const DevLight *lights; uint32_t nLights;
     const DevSphere *spheres;
-    const DevInstance *instances;
+    const DevInstance *instances; uint32_t nInstances;
     const float *lightFunc, *lightCdf; float lightFuncInt;      // Distribution1D (core/sampling.h:55-109)
     float worldRadius;                                           // DistantLight::Preprocess
     // Halton tables

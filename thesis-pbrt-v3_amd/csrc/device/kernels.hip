@@ -160,8 +160,9 @@ __device__ __forceinline__ bool slab_test(float lox, float hix, float loy, float
 // [9] refills [10] refilled lanes [11] quadric batches [12] quadric lanes [13] waves.
 __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31] any hit
 
-// MODE 0: plain; 1: work counters (HprtRenderStats); 2: phase profile (diagnostics only)
-template <bool ANY_HIT, int MODE>
+// MODE 0: plain; 1: work counters (HprtRenderStats); 2: phase profile (diagnostics only).
+// INST: the scene has object instances (two-level walk); without them that code and its registers are compiled out.
+template <bool ANY_HIT, int MODE, bool INST>
 __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ,
                                                             DevCounters *counters, uint32_t *workCounter, uint32_t chunk, TraceTune tune) {
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
             --sp;
             uint2 e;
             if (sp < HPRT_LDS_STACK) e = ldsStack[sp * HPRT_TRACE_BLOCK]; else e = make_uint2(spillRef[sp - HPRT_LDS_STACK], spillT[sp - HPRT_LDS_STACK]);
-            if ((int)e.x == REF_EXIT) { savedTMax = __uint_as_float(e.y); return REF_EXIT; }     // the instance's walk is over
+            if (INST && (int)e.x == REF_EXIT) { savedTMax = __uint_as_float(e.y); return REF_EXIT; }     // the instance's walk is over
             if (COUNT) ++cnt.fetched;
             if (__uint_as_float(e.y) < rayTMax) { if (COUNT) ++cnt.entered; return (int)e.x; }
         }
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                                          vec3(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
                                          vec3(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z)), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
                                 if (ANY_HIT) { hit = true; done = true; }
-                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = b0; hb1 = b1; hb2 = b2; hitInst = inst; instHit = inst >= 0; }
+                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = b0; hb1 = b1; hb2 = b2; if (INST) { hitInst = inst; instHit = inst >= 0; } }
                             }
                             if (done) cur = REF_NONE;
                             else if (tag & TAG_LAST) cur = pop();
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                     }
                     continue;
                 }
-                const bool slow = active && (wait != 0u || cur == REF_EXIT);
+                const bool slow = active && (wait != 0u || (INST && cur == REF_EXIT));
                 const int nWait = __popcll(__ballot(slow));
                 if (nWait == 0) break;
                 const bool canWalk = __ballot(active && cur >= 0) != 0ull;
@@ -362,18 +363,18 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                     if (COUNT) ++cnt.sphere;
                     DRay rr; rr.o = ro; rr.tMax = rayTMax;
                     { const float4 rb = rays.b[slot]; rr.d = vec3(rb.x, rb.y, rb.z); }
-                    if (inst >= 0) rr.d = xf_vector(sc.instances[inst].w2i, rr.d);      // the instance-space direction, recomputed
+                    if (INST && inst >= 0) rr.d = xf_vector(sc.instances[inst].w2i, rr.d);      // the instance-space direction, recomputed
                     DRay robj; vec3 ph; float phi, t;
                     bool done = false;
                     if (sphere_test(sc.spheres[waitInfo & 0x7fffffffu], rr, &robj, &ph, &phi, &t)) {
                         if (ANY_HIT) { hit = true; done = true; }
-                        else { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; hitInst = inst; instHit = inst >= 0; }
+                        else { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; if (INST) { hitInst = inst; instHit = inst >= 0; } }
                     }
                     if (done) cur = REF_NONE;
                     else if (waitInfo & 0x80000000u) cur = pop();
                     else --cur;
                 }
-                if (wait == 2u) {
+                if (INST && wait == 2u) {
                     // TransformedPrimitive::Intersect: Ray ray = Inverse(InterpolatedPrimToWorld)(r), i.e.
                     // Transform::operator()(const Ray &) (core/transform.h:251-264); then walk the object's aggregate
                     const uint32_t pi = (uint32_t)~cur;
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                     shear = ray_shear(d2);
                     cur = in.root;
                 }
-                if (cur == REF_EXIT) {
+                if (INST && cur == REF_EXIT) {
                     // back in world space: r.tMax = ray.tMax only if the instance was hit (core/primitive.cpp:85-86)
                     const float worldT = instHit ? rayTMax : savedTMax;
                     const float4 ra = rays.a[slot], rb = rays.b[slot];
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                 if (ANY_HIT) occ[slot] = hit ? 1 : 0;
                 else {
                     hits.a[slot] = make_float4(rayTMax, __int_as_float(hit ? prim : -1), hb0, hb1);
-                    if (hits.b) hits.b[slot] = make_float2(hb2, __int_as_float(hit ? hitInst : -1));
+                    if (hits.b) hits.b[slot] = make_float2(hb2, __int_as_float(INST && hit ? hitInst : -1));
                 }
                 active = false;
             }
@@ -894,15 +895,16 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     chunk = std::max(64u, std::min(512u, chunk)) & ~63u;
     static const TraceTune tune = DefaultTraceTune();
     static const bool profile = getenv("HPRT_TRACE_PROFILE") != nullptr;
+    const bool inst = sc.nInstances != 0u;
+#define HPRT_TRACE_LAUNCH(A, M, I) hipLaunchKernelGGL((k_trace<A, M, I>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune)
+#define HPRT_TRACE_PICK(A, M) do { if (inst) HPRT_TRACE_LAUNCH(A, M, true); else HPRT_TRACE_LAUNCH(A, M, false); } while (0)
     if (anyHit) {
-        if (count) hipLaunchKernelGGL((k_trace<true, 1>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
-        else if (profile) hipLaunchKernelGGL((k_trace<true, 2>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
-        else hipLaunchKernelGGL((k_trace<true, 0>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
+        if (count) HPRT_TRACE_PICK(true, 1); else if (profile) HPRT_TRACE_PICK(true, 2); else HPRT_TRACE_PICK(true, 0);
     } else {
-        if (count) hipLaunchKernelGGL((k_trace<false, 1>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
-        else if (profile) hipLaunchKernelGGL((k_trace<false, 2>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
-        else hipLaunchKernelGGL((k_trace<false, 0>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune);
+        if (count) HPRT_TRACE_PICK(false, 1); else if (profile) HPRT_TRACE_PICK(false, 2); else HPRT_TRACE_PICK(false, 0);
     }
+#undef HPRT_TRACE_PICK
+#undef HPRT_TRACE_LAUNCH
 }
 // diagnostics hook (not part of include/hprt.h): read and optionally clear the phase profile
 extern "C" __attribute__((visibility("default"))) int hprt_debug_trace_profile(unsigned long long out[32], int reset) {
