@@ -182,6 +182,69 @@ def test_baked_scene_roundtrip_and_corruption(hprt, tmp_path):
         hprt.Model.load(str(tmp_path / "magic.hprt"))
 
 
+INSTANCED = HEADER + """
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-3 -3 0  3 -3 0  3 3 0  -3 3 0]
+ObjectBegin "pair"
+  Translate 0 0 .5
+  Shape "sphere" "float radius" [.5]
+  Translate 1.2 0 0
+  Material "plastic"
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 0 3 1 1 3 2] "point P" [0 0 0  1 0 0  0 1 0  0 0 1]
+ObjectEnd
+ObjectBegin "empty"
+ObjectEnd
+ObjectBegin "single"
+  Shape "sphere" "float radius" [.3]
+ObjectEnd
+AttributeBegin
+  Translate -1 0 0
+  Rotate 45 0 0 1
+  ObjectInstance "pair"
+AttributeEnd
+ObjectInstance "empty"
+Shape "sphere" "float radius" [.1]
+AttributeBegin
+  Scale 2 1 1
+  ObjectInstance "single"
+  ObjectInstance "pair"
+AttributeEnd
+WorldEnd
+"""
+
+
+def test_frontend_object_instancing(hprt, orc, tmp_path):
+    """pbrtObjectBegin/End/Instance (core/api.cpp:1752-1820): object shapes stay out of the top level, an
+    empty object instantiates nothing, the attribute stack is restored at ObjectEnd, and the aggregates built
+    per object and for the top level (instances bounded by their transformed object bounds) are byte-identical
+    to the oracle's.  The baked container (version 2) carries all of it."""
+    m = _parse_text(hprt, tmp_path, INSTANCED)
+    assert m.warnings() == []
+    assert m.counts()["shapes"] == 5 and m.counts()["spheres"] == 3 and m.counts()["triangles"] == 6
+    baked = str(tmp_path / "inst.hprt")
+    m.save(baked)
+    assert open(baked, "rb").read()[8:12] == (2).to_bytes(4, "little")
+    m2 = hprt.Model.load(baked)
+    again = str(tmp_path / "inst2.hprt"); m2.save(again)
+    assert open(baked, "rb").read() == open(again, "rb").read()
+    bvh = hprt.Bvh(m2)
+    # top level: 2 floor triangles + instance + sphere + 2 instances ("empty" adds none)
+    assert bvh.info()["prims"] == 2 + 1 + 1 + 2
+    o = orc.OracleScene(baked)
+    n1, o1 = o.bvh_arrays(); n2, o2 = bvh.arrays()
+    assert np.array_equal(n1, n2) and np.array_equal(o1, o2)
+    objs = o.object_bvh_arrays()
+    assert [x[1].shape[0] for x in objs] == [5, 0, 1]
+    for k, (on, oo) in enumerate(objs):
+        pn, po = bvh.object_arrays(k)
+        assert np.array_equal(on, pn) and np.array_equal(oo, po)
+    with pytest.raises(hprt.HprtError):
+        _parse_text(hprt, tmp_path, HEADER + 'ObjectInstance "nobody"\nWorldEnd\n', name="bad1.pbrt")
+    with pytest.raises(hprt.HprtError):
+        _parse_text(hprt, tmp_path, HEADER + 'ObjectBegin "a"\nObjectBegin "b"\nObjectEnd\nObjectEnd\nWorldEnd\n', name="bad2.pbrt")
+    w = _parse_text(hprt, tmp_path, HEADER + 'ObjectBegin "l"\nAreaLightSource "area"\nShape "sphere"\nObjectEnd\nObjectInstance "l"\nWorldEnd\n', name="w.pbrt")
+    assert any("instancing" in x for x in w.warnings())
+
+
 def test_halton_tables_match_oracle(hprt, orc):
     mine = hprt.halton_permutations()
     buf = np.zeros(mine.size, np.uint16)
