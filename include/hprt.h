@@ -223,6 +223,7 @@ typedef struct HprtRenderDesc {
     int32_t flags;                 /* HPRT_RENDER_* */
 } HprtRenderDesc;
 #define HPRT_RENDER_COUNT_WORK 1   /* collect node/triangle counters (slower) */
+#define HPRT_RENDER_PIXEL_STATS 2  /* also keep them per pixel: the fork's GeneralStats heat-map data (implies COUNT_WORK) */
 
 typedef struct HprtRenderStats {
     uint64_t camera_rays;          /* nCameraRays, core/integrator.cpp:48,293 */
@@ -244,6 +245,18 @@ typedef struct HprtRenderStats {
  * elsewhere — what Film::MergeFilmTile leaves in Film::pixels.  Summing such
  * buffers over GPUs (RCCL reduce) reproduces the single-GPU film exactly. */
 int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, void *stream, HprtRenderStats *stats);
+/* Pixel::stats (core/film.h:91; GeneralStats, core/geometry.h:1078-1173) of the last hprt_render that had
+ * HPRT_RENDER_PIXEL_STATS set: per film pixel, row-major over the cropped pixel bounds, 7 values —
+ * rays (= samples), primitiveIntersections, primitiveIntersectionsP, leafNodeTraversals,
+ * leafNodeTraversalsP, bvhTreeNodeTraversals, bvhTreeNodeTraversalsP — every ray of a pixel's samples
+ * adds its counters once (core/integrator.cpp:327-328, integrators/path.cpp:92-200, core/light.cpp:62).
+ * Pixels of tiles that were not rendered hold zeros, so per-rank results add up like the film. */
+int hprt_pixel_stats_read(HprtScene *s, uint64_t *out7, size_t n_pixels);
+/* Film::WriteGeneralStats (core/film.cpp:170-264): writes <prefix>-primitiveIntersections.txt,
+ * -primitiveIntersectionsP.txt, -leafNodeTraversals.txt, -leafNodeTraversalsP.txt (one row of the
+ * image per line, values separated by blanks) and the all-zero kd-tree / BSP matrices the fork
+ * writes for a BVH render.  Its -renderTime.txt (wall-clock per pixel) has no counterpart here. */
+int hprt_write_pixel_stats(const char *prefix, const uint64_t *stats7, int width, int height);
 /* Film::WriteImage arithmetic (core/film.cpp:266-303) on a host copy of a film
  * state: rgb_out = 3*W*H floats, top row first. */
 int hprt_film_resolve(const float *xyzw, size_t n_pixels, float film_scale, float *rgb_out);

@@ -231,6 +231,11 @@ int orc_render_tiles(void *h, int spp, int nThreads, int tileBegin, int tileStri
     if (counters13) export_counters(r->total, counters13);
     return r->nThreads;
 }
+// Per-pixel GeneralStats of the last render: 7 uint64 per pixel (see Film::stats)
+void orc_pixel_stats(void *h, uint64_t *out7) {
+    Renderer *r = (Renderer *)h;
+    memcpy(out7, r->film.stats.data(), r->film.stats.size() * 7 * sizeof(uint64_t));
+}
 // Raw film state (xyz + weight per pixel) for exact film comparisons
 void orc_film_raw(void *h, float *xyzw) {
     Renderer *r = (Renderer *)h;

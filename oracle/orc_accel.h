@@ -15,12 +15,14 @@ namespace orc {
 struct Counters {
     uint64_t nodesFetched = 0, nodesFetchedP = 0;    // traversal-loop iterations
     uint64_t nodesEntered = 0, nodesEnteredP = 0;    // slab test passed (reference counter)
+    uint64_t leavesEntered = 0, leavesEnteredP = 0;  // of those, leaves: ray.stats.leafNodeTraversals[P] (bvh.cpp:370,411)
     uint64_t triTests = 0, triTestsP = 0, triHits = 0, triHitsP = 0;
     uint64_t sphereTests = 0, sphereTestsP = 0;
     uint64_t rays = 0, shadowRays = 0, cameraRays = 0;
     void add(const Counters &o) {
         nodesFetched += o.nodesFetched; nodesFetchedP += o.nodesFetchedP;
         nodesEntered += o.nodesEntered; nodesEnteredP += o.nodesEnteredP;
+        leavesEntered += o.leavesEntered; leavesEnteredP += o.leavesEnteredP;
         triTests += o.triTests; triTestsP += o.triTestsP; triHits += o.triHits; triHitsP += o.triHitsP;
         sphereTests += o.sphereTests; sphereTestsP += o.sphereTestsP;
         rays += o.rays; shadowRays += o.shadowRays; cameraRays += o.cameraRays;
@@ -643,6 +645,7 @@ struct BVH {
             if (slabHit) {
                 ++ctr.nodesEntered;
                 if (node->IsLeaf()) {
+                    ++ctr.leavesEntered;
                     for (uint32_t i = 0; i < node->nPrimitives(); ++i)
                         if (PrimIntersect(node->offset + i, ray, isect, ctr)) {
                             hit = true;
@@ -679,6 +682,7 @@ struct BVH {
             if (SlabTest(node, ray, invDir, dirIsNeg)) {
                 ++ctr.nodesEnteredP;
                 if (node->IsLeaf()) {
+                    ++ctr.leavesEnteredP;
                     for (uint32_t i = 0; i < node->nPrimitives(); ++i)
                         if (PrimIntersectP(node->offset + i, ray, ctr)) return true;
                     if (toVisitOffset == 0) break;

@@ -3,6 +3,7 @@
 // cameras/perspective.cpp, core/camera.h, core/film.{h,cpp}, core/integrator.cpp,
 // integrators/path.cpp, core/light.cpp, core/lightdistrib.cpp, core/sampling.h.
 #pragma once
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -140,6 +141,10 @@ struct Film {
     static const int filterTableWidth = 16;
     Float filterTable[filterTableWidth * filterTableWidth];
     std::vector<FilmPixel> pixels;
+    // Pixel::stats (core/film.h:91), the fork's per-pixel GeneralStats (core/geometry.h:1078-1173), BVH fields:
+    // rays, primitiveIntersections, primitiveIntersectionsP, leafNodeTraversals, leafNodeTraversalsP,
+    // bvhTreeNodeTraversals, bvhTreeNodeTraversalsP
+    std::vector<std::array<uint64_t, 7>> stats;
     std::mutex mutex;
     void Init(const SceneParams &p) {
         xres = p.xres; yres = p.yres;
@@ -149,6 +154,7 @@ struct Film {
         scale = p.filmScale; maxSampleLuminance = p.maxSampleLuminance;
         for (int i = 0; i < filterTableWidth * filterTableWidth; ++i) filterTable[i] = 1.f;   // BoxFilter::Evaluate
         pixels.assign((size_t)smax(0, (cx1 - cx0) * (cy1 - cy0)), FilmPixel());
+        stats.assign(pixels.size(), std::array<uint64_t, 7>{{0, 0, 0, 0, 0, 0, 0}});
     }
     void GetSampleBounds(int *x0, int *y0, int *x1, int *y1) const {   // film.cpp:81-87
         *x0 = (int)std::floor((Float)cx0 + 0.5f - radius[0]);
@@ -489,6 +495,7 @@ struct Renderer {
         int sx0, sy0, sx1, sy1;
         film.GetSampleBounds(&sx0, &sy0, &sx1, &sy1);
         for (auto &p : film.pixels) p = FilmPixel();
+        for (auto &p : film.stats) p = std::array<uint64_t, 7>{{0, 0, 0, 0, 0, 0, 0}};
         const int tileSize = 16;
         int ntx = (sx1 - sx0 + tileSize - 1) / tileSize, nty = (sy1 - sy0 + tileSize - 1) / tileSize;
         std::atomic<int> next(0);
@@ -508,12 +515,24 @@ struct Renderer {
                 for (int y = y0; y < y1; ++y)
                     for (int x = x0; x < x1; ++x) {
                         sampler.StartPixel(x, y);
+                        const Counters before = ctr;
                         // pixelBounds == sample bounds for PathIntegrator without "pixelbounds" (path.cpp:212)
                         do {
                             P2 pFilm; Float w;
                             Spec L = RenderSample(sampler, x, y, &pFilm, &w, ctr);
                             tile.AddSample(pFilm, L, w);
                         } while (sampler.StartNextSample());
+                        // filmTile->GetPixel(pixel).stats += ray.stats (core/integrator.cpp:327-328): every ray of the
+                        // pixel's samples adds its counters once (integrators/path.cpp:92-200, core/integrator.cpp:213,
+                        // core/light.cpp:62); MergeFilmTile sums them into the film (core/film.cpp:130)
+                        std::array<uint64_t, 7> &ps = film.stats[(size_t)(x - film.cx0) + (size_t)(y - film.cy0) * (film.cx1 - film.cx0)];
+                        ps[0] += ctr.cameraRays - before.cameraRays;
+                        ps[1] += (ctr.triTests + ctr.sphereTests) - (before.triTests + before.sphereTests);
+                        ps[2] += (ctr.triTestsP + ctr.sphereTestsP) - (before.triTestsP + before.sphereTestsP);
+                        ps[3] += ctr.leavesEntered - before.leavesEntered;
+                        ps[4] += ctr.leavesEnteredP - before.leavesEnteredP;
+                        ps[5] += (ctr.nodesEntered - ctr.leavesEntered) - (before.nodesEntered - before.leavesEntered);
+                        ps[6] += (ctr.nodesEnteredP - ctr.leavesEnteredP) - (before.nodesEnteredP - before.leavesEnteredP);
                     }
                 MergeFilmTile(&film, tile);
             }

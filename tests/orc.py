@@ -55,6 +55,7 @@ def _load():
     lib.orc_sample_radiance.argtypes = [vp, C.c_size_t, vp, vp, vp, vp]
     lib.orc_render.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     lib.orc_film_raw.argtypes = [vp, vp]
+    lib.orc_pixel_stats.argtypes = [vp, vp]
     for n in ("orc_det_sinf", "orc_det_cosf", "orc_det_acosf"):
         getattr(lib, n).restype = C.c_float
         getattr(lib, n).argtypes = [C.c_float]
@@ -160,6 +161,13 @@ class OracleScene:
         film = np.zeros((y1 - y0, x1 - x0, 4), np.float32)
         lib.orc_film_raw(self._h, _p(film))
         return rgb, film, dict(zip(COUNTER_NAMES, [int(x) for x in ctr])), sec.value, nt
+
+    def pixel_stats(self):
+        """[H, W, 7] uint64 of the last render: rays, primitiveIntersections[P], leafNodeTraversals[P], bvhTreeNodeTraversals[P]"""
+        x0, y0, x1, y1 = self.film_bounds()
+        out = np.zeros((y1 - y0, x1 - x0, 7), np.uint64)
+        lib.orc_pixel_stats(self._h, _p(out))
+        return out
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -154,3 +154,32 @@ def test_two_ranks_sharing_the_gpu_reproduce_the_film(tmp_path, killeroo_oracle)
     _, film0, _, _, _ = killeroo_oracle.render(spp=8, threads=8)
     killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
     assert np.array_equal(got.view(np.uint32), film0.view(np.uint32))
+
+
+def test_per_pixel_statistics_match(hprt, orc, killeroo_scene, killeroo_oracle, tmp_path):
+    """The fork's heat-map data (Pixel::stats / Film::WriteGeneralStats, core/film.cpp:170-264): per pixel, the sums over
+    all rays of the pixel's samples of primitive tests and leaf / interior node traversals, closest-hit and any-hit —
+    identical to the oracle's for every pixel, and written in the reference's text-matrix format."""
+    opt = killeroo_scene._model.options.copy()
+    for i, v in enumerate((0.37, 0.63, 0.41, 0.66)):
+        opt.crop[i] = v
+    opt.spp = 8
+    killeroo_oracle.set_film(crop=(0.37, 0.63, 0.41, 0.66), spp=8)
+    killeroo_oracle.render(threads=8)
+    ref = killeroo_oracle.pixel_stats()
+    film, st = killeroo_scene.render(opt, pixel_stats=True)
+    got = killeroo_scene.pixel_stats()
+    assert got.shape == ref.shape and ref[..., 1].sum() > 0
+    assert np.array_equal(got, ref)
+    assert int(got[..., 1].sum()) == st["tri_tests"] + st["sphere_tests"] and int(got[..., 0].sum()) == st["camera_rays"]
+    # tile-sharded: the two halves add up (what the multi-GPU gather does with the film)
+    killeroo_scene.render(opt, tile_begin=0, tile_stride=2, pixel_stats=True); a = killeroo_scene.pixel_stats()
+    killeroo_scene.render(opt, tile_begin=1, tile_stride=2, pixel_stats=True); b = killeroo_scene.pixel_stats()
+    assert np.array_equal(a + b, ref)
+    prefix = str(tmp_path / "killeroo")
+    hprt.write_pixel_stats(prefix, got)
+    m = np.loadtxt(prefix + "-leafNodeTraversalsP.txt", dtype=np.uint64)
+    assert np.array_equal(m, ref[..., 4])
+    assert np.loadtxt(prefix + "-kdTreeNodeTraversals.txt").sum() == 0
+    with pytest.raises(hprt.HprtError):
+        killeroo_scene.render(opt); killeroo_scene.pixel_stats()

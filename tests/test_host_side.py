@@ -266,3 +266,14 @@ def test_film_resolve_and_pfm(hprt, killeroo_oracle, tmp_path):
     assert head[0] == b"PF" and head[1] == b"%d %d" % (rgb1.shape[1], rgb1.shape[0]) and float(head[2]) < 0
     back = np.frombuffer(rest, np.float32).reshape(rgb1.shape)[::-1]
     assert np.array_equal(back, rgb1)
+
+
+def test_pixel_stats_text_matrices(hprt, tmp_path):
+    """Film::WriteGeneralStatMatrix (core/film.cpp:189-210): one image row per line, blanks between values."""
+    st = np.arange(3 * 4 * 7, dtype=np.uint64).reshape(3, 4, 7)
+    hprt.write_pixel_stats(str(tmp_path / "img"), st)
+    txt = open(tmp_path / "img-primitiveIntersections.txt").read()
+    assert txt == "1 8 15 22\n29 36 43 50\n57 64 71 78\n"
+    names = sorted(p.name for p in tmp_path.iterdir())
+    assert names == sorted("img-%s.txt" % n for n in ("primitiveIntersections", "primitiveIntersectionsP", "kdTreeNodeTraversals", "kdTreeNodeTraversalsP",
+                                                    "bspTreeNodeTraversals", "bspTreeNodeTraversalsP", "leafNodeTraversals", "leafNodeTraversalsP"))

@@ -30,6 +30,7 @@ class HprtError(RuntimeError):
 
 E_INVALID, E_IO, E_PARSE, E_NO_DEVICE, E_DEVICE, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 RENDER_COUNT_WORK = 1
+RENDER_PIXEL_STATS = 2
 
 
 class RenderOptions(C.Structure):
@@ -109,6 +110,8 @@ def _load():
         "hprt_render": (C.c_int, [vp, P(RenderDesc), vp, vp, P(RenderStats)]),
         "hprt_film_resolve": (C.c_int, [vp, sz, C.c_float, vp]),
         "hprt_film_read": (C.c_int, [vp, vp, sz]),
+        "hprt_pixel_stats_read": (C.c_int, [vp, vp, sz]),
+        "hprt_write_pixel_stats": (C.c_int, [cp, vp, C.c_int, C.c_int]),
         "hprt_write_pfm": (C.c_int, [cp, vp, C.c_int, C.c_int]),
         "hprt_sample_radiance": (C.c_int, [vp, P(RenderOptions), sz, vp, vp, vp, vp]),
         "hprt_halton_permutations": (C.c_int, [vp, sz, P(sz)]),
@@ -275,14 +278,15 @@ class Scene:
         _check(lib.hprt_occluded_device(self._h, n, rays7_ptr, occ_ptr, stream))
 
     def render(self, opt=None, tile_begin=0, tile_end=0, tile_stride=1, spp_chunk=0, count_work=False, film_ptr=None,
-               stream=None):
+               stream=None, pixel_stats=False):
         """Render(): returns (film_xyzw [H,W,4] float32 or None when film_ptr is given, stats dict)."""
         opt = opt or self._model.options
         desc = RenderDesc()
         desc.opt = opt
         desc.tile_begin, desc.tile_end, desc.tile_stride = tile_begin, tile_end, tile_stride
         desc.spp_chunk = spp_chunk
-        desc.flags = RENDER_COUNT_WORK if count_work else 0
+        desc.flags = (RENDER_COUNT_WORK if count_work else 0) | (RENDER_PIXEL_STATS if pixel_stats else 0)
+        self._film_shape = tuple(int(v) for v in (opt.film_bounds()[3] - opt.film_bounds()[1], opt.film_bounds()[2] - opt.film_bounds()[0]))
         st = RenderStats()
         _check(lib.hprt_render(self._h, C.byref(desc), film_ptr, stream, C.byref(st)))
         film = None
@@ -291,6 +295,14 @@ class Scene:
             film = np.zeros((y1 - y0, x1 - x0, 4), np.float32)
             _check(lib.hprt_film_read(self._h, _ptr(film), film.shape[0] * film.shape[1]))
         return film, st.as_dict()
+
+    def pixel_stats(self):
+        """[H, W, 7] uint64 Pixel::stats of the last render(pixel_stats=True): rays, primitiveIntersections[P],
+        leafNodeTraversals[P], bvhTreeNodeTraversals[P] (the fork's heat-map data, core/film.cpp:170-264)."""
+        h, w = self._film_shape
+        out = np.zeros((h, w, 7), np.uint64)
+        _check(lib.hprt_pixel_stats_read(self._h, _ptr(out), h * w))
+        return out
 
     def sample_radiance(self, px, py, sample, opt=None):
         opt = opt or self._model.options
@@ -312,6 +324,12 @@ def film_resolve(film_xyzw, scale=1.0):
     rgb = np.zeros(f.shape[:-1] + (3,), np.float32)
     _check(lib.hprt_film_resolve(_ptr(f), f.size // 4, C.c_float(scale), _ptr(rgb)))
     return rgb
+
+
+def write_pixel_stats(prefix, stats7):
+    """Film::WriteGeneralStats: the fork's per-pixel text matrices, '<prefix>-<counter>.txt'."""
+    stats7 = np.ascontiguousarray(stats7, np.uint64)
+    _check(lib.hprt_write_pixel_stats(prefix.encode(), _ptr(stats7), stats7.shape[1], stats7.shape[0]))
 
 
 def write_pfm(path, rgb):

@@ -55,6 +55,7 @@ struct HprtScene {
     DevScene dev;
     DevBuf nodes, tris, primVtx, vN, vUV, vS, shapes, materials, lights, spheres, instances, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
     DevBuf counters, workCounter;
+    DevBuf rayStats, pixelStatsLocal, pixelStatsFilm; bool pixelStatsValid = false;   // HPRT_RENDER_PIXEL_STATS
     // render-time state
     DevBuf planes;                                    // backing store of the path streams (Workspace)
     DevBuf apiRays, apiHits;                          // stream copies of the plane-layout arguments of the *_device calls
@@ -660,8 +661,11 @@ namespace {
 struct BatchTimers { double extendMs = 0, occludedMs = 0; uint64_t extendLaunches = 0, occludedLaunches = 0, extendRays = 0, occludedRays = 0; };
 
 // Runs the bounce loop for one batch of nSlots freshly generated paths.
+// pixelStats (or null): [6][nPix] per-pixel counters of the local pixels, fed from the per-ray counts of every trace
 int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspace &w, const QueueSet &qa, const QueueSet &qb,
-             const BinSet &bins, uint32_t s0, uint32_t nSlots, bool count, EventTimer &ev, BatchTimers *bt, HprtRenderStats *stats) {
+             const BinSet &bins, uint32_t s0, uint32_t nSlots, bool count, EventTimer &ev, BatchTimers *bt, HprtRenderStats *stats,
+             uint32_t *pixelStats = nullptr) {
+    uint4 *rayStats = pixelStats ? s->rayStats.as<uint4>() : nullptr;
     LaunchGenerate(st, s->dev, rp, w.path[0], s0, nSlots);
     const uint32_t *activeQ = nullptr; uint32_t active = nSlots;
     QueueSet q[2] = {qa, qb};
@@ -672,7 +676,8 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         const PathStream &in = w.path[bounce & 1], &out = w.path[(bounce + 1) & 1];
         hipEvent_t e0 = ev.get(), e1 = ev.get();
         HIP_TRY(hipEventRecord(e0, st));
-        LaunchTrace(st, s->dev, false, count, activeQ, nullptr, active, active, in.ray, w.hit, nullptr, ctr, s->workCounter.as<uint32_t>());
+        LaunchTrace(st, s->dev, false, count, activeQ, nullptr, active, active, in.ray, w.hit, nullptr, ctr, s->workCounter.as<uint32_t>(), rayStats);
+        if (pixelStats) LaunchPixelStats(st, rayStats, in.beta, activeQ, nullptr, active, active, rp.nPix, false, pixelStats);
         HIP_TRY(hipEventRecord(e1, st));
         evExt.push_back({e0, e1}); bt->extendRays += active; ++bt->extendLaunches;
         stats->rays += active;
@@ -690,7 +695,8 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
             hipEvent_t a = ev.get(), b = ev.get();
             HIP_TRY(hipEventRecord(a, st));
             HitStream none; none.a = nullptr; none.b = nullptr;
-            LaunchTrace(st, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, w.vs.shadow, none, w.vs.occluded, ctr, s->workCounter.as<uint32_t>());
+            LaunchTrace(st, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, w.vs.shadow, none, w.vs.occluded, ctr, s->workCounter.as<uint32_t>(), rayStats);
+            if (pixelStats) LaunchPixelStats(st, rayStats, w.vs.pendBeta, cur.shadow, nullptr, nShadow, nShadow, rp.nPix, true, pixelStats);
             HIP_TRY(hipEventRecord(b, st));
             evOcc.push_back({a, b}); bt->occludedRays += nShadow; ++bt->occludedLaunches;
             stats->shadow_rays += nShadow;
@@ -698,7 +704,8 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         if (nMis) {
             hipEvent_t a = ev.get(), b = ev.get();
             HIP_TRY(hipEventRecord(a, st));
-            LaunchTrace(st, s->dev, false, count, cur.mis, nullptr, nMis, nMis, w.vs.mis, w.vs.misHit, nullptr, ctr, s->workCounter.as<uint32_t>());
+            LaunchTrace(st, s->dev, false, count, cur.mis, nullptr, nMis, nMis, w.vs.mis, w.vs.misHit, nullptr, ctr, s->workCounter.as<uint32_t>(), rayStats);
+            if (pixelStats) LaunchPixelStats(st, rayStats, w.vs.pendBeta, cur.mis, nullptr, nMis, nMis, rp.nPix, false, pixelStats);
             HIP_TRY(hipEventRecord(b, st));
             evExt.push_back({a, b}); bt->extendRays += nMis; ++bt->extendLaunches;
             stats->rays += nMis;
@@ -782,7 +789,18 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     rp.hal.samplePixelCenter = o.sample_pixel_center;
     rp.pixelXY = s->pixelXY.as<uint32_t>(); rp.pixelOffset = s->pixelOffset.as<uint64_t>(); rp.nPix = nPix;
     rp.maxDepth = o.max_depth; rp.rrThreshold = o.rr_threshold;
-    const bool count = (desc->flags & HPRT_RENDER_COUNT_WORK) != 0;
+    const bool wantPixelStats = (desc->flags & HPRT_RENDER_PIXEL_STATS) != 0;
+    const bool count = (desc->flags & HPRT_RENDER_COUNT_WORK) != 0 || wantPixelStats;
+    uint32_t *pixelStats = nullptr;
+    if (wantPixelStats) {
+        HIP_TRY(s->rayStats.alloc(sizeof(uint4) * maxSlots));
+        HIP_TRY(s->pixelStatsLocal.alloc(6ull * nPix * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(s->pixelStatsLocal.p, 0, 6ull * nPix * sizeof(uint32_t), st));
+        HIP_TRY(s->pixelStatsFilm.alloc(7ull * s->filmPixels * sizeof(uint64_t)));
+        HIP_TRY(hipMemsetAsync(s->pixelStatsFilm.p, 0, 7ull * s->filmPixels * sizeof(uint64_t), st));
+        pixelStats = s->pixelStatsLocal.as<uint32_t>();
+    }
+    s->pixelStatsValid = false;
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, sizeof(DevCounters), st));
 
     auto wall0 = std::chrono::high_resolution_clock::now();
@@ -856,12 +874,16 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     EventTimer ev; BatchTimers bt;
     for (uint32_t s0 = 0; s0 < spp; s0 += chunk) {
         const uint32_t c = std::min(chunk, spp - s0), nSlots = c * nPix;
-        rc = RunBatch(s, st, rp, ps, qa, qb, bins, s0, nSlots, count, ev, &bt, stats);
+        rc = RunBatch(s, st, rp, ps, qa, qb, bins, s0, nSlots, count, ev, &bt, stats, pixelStats);
         if (rc != HPRT_OK) return rc;
         LaunchStoreRadiance(st, ps.Lfinal, LallR, LallG, LallB, nPix, s0, nSlots);
     }
     LaunchFilmOwn(st, rp, f.fg, LallR, LallG, LallB, spp, ex, film);
     LaunchFilmForeign(st, rp, f.fg, LallR, LallG, LallB, ex, film);
+    if (pixelStats) {
+        LaunchPixelStatsToFilm(st, pixelStats, rp.pixelXY, nPix, spp, f.fg.cx0, f.fg.cy0, f.W, s->pixelStatsFilm.as<unsigned long long>());
+        s->pixelStatsValid = true;
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     stats->render_seconds = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - wall0).count();
@@ -878,6 +900,15 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     return HPRT_OK;
 }
 
+// Pixel::stats of the last hprt_render with HPRT_RENDER_PIXEL_STATS (core/film.h:91): 7 values per film pixel
+int hprt_pixel_stats_read(HprtScene *s, uint64_t *out7, size_t n_pixels) {
+    if (!s || !out7) return SetError(HPRT_E_INVALID, "hprt_pixel_stats_read: null argument");
+    if (!s->pixelStatsValid) return SetError(HPRT_E_INVALID, "no per-pixel statistics: render with HPRT_RENDER_PIXEL_STATS first");
+    if (n_pixels != s->filmPixels) return SetError(HPRT_E_INVALID, "hprt_pixel_stats_read: pixel count differs from the last render's film");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpy(out7, s->pixelStatsFilm.p, 7 * n_pixels * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return HPRT_OK;
+}
 int hprt_film_read(HprtScene *s, float *xyzw_out, size_t n_pixels) {
     if (!s || !xyzw_out) return SetError(HPRT_E_INVALID, "hprt_film_read: null argument");
     if (!s->film.p || n_pixels != s->filmPixels) return SetError(HPRT_E_INVALID, "hprt_film_read: no library-owned film of that size (render with d_film_xyzw == NULL first)");

@@ -186,6 +186,31 @@ int hprt_film_resolve(const float *xyzw, size_t n, float scale, float *rgb) {
     return HPRT_OK;
 }
 
+// Film::WriteGeneralStatMatrix, core/film.cpp:189-210: "<file minus extension>-<name>.txt", one image row per line
+int hprt_write_pixel_stats(const char *prefix, const uint64_t *stats7, int width, int height) {
+    if (!prefix || !stats7 || width <= 0 || height <= 0) return SetError(HPRT_E_INVALID, "hprt_write_pixel_stats: bad argument");
+    // the matrices Film::WriteGeneralStats writes (core/film.cpp:170-187), with the index of the value in stats7 (-1: zero for a BVH render)
+    static const struct { const char *name; int field; } kMatrices[] = {
+        {"primitiveIntersections", 1}, {"primitiveIntersectionsP", 2}, {"kdTreeNodeTraversals", -1}, {"kdTreeNodeTraversalsP", -1},
+        {"bspTreeNodeTraversals", -1}, {"bspTreeNodeTraversalsP", -1}, {"leafNodeTraversals", 3}, {"leafNodeTraversalsP", 4}};
+    for (const auto &m : kMatrices) {
+        const std::string path = std::string(prefix) + "-" + m.name + ".txt";
+        FILE *fp = fopen(path.c_str(), "w");
+        if (!fp) return SetError(HPRT_E_IO, "cannot create " + path);
+        bool ok = true;
+        for (int y = 0; y < height && ok; ++y) {
+            for (int x = 0; x < width; ++x) {
+                const unsigned long long v = m.field < 0 ? 0ull : (unsigned long long)stats7[7 * ((size_t)y * width + x) + m.field];
+                ok = ok && fprintf(fp, x ? " %llu" : "%llu", v) > 0;
+            }
+            ok = ok && fputc('\n', fp) != EOF;
+        }
+        if (fclose(fp) != 0) ok = false;
+        if (!ok) return SetError(HPRT_E_IO, "write error on " + path);
+    }
+    return HPRT_OK;
+}
+
 // WritePFM, core/imageio.cpp:437+ : "PF", width height, scale -1 (little endian), rows bottom to top
 int hprt_write_pfm(const char *path, const float *rgb, int width, int height) {
     if (!path || !rgb || width <= 0 || height <= 0) return SetError(HPRT_E_INVALID, "hprt_write_pfm: bad argument");

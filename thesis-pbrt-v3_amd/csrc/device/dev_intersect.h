@@ -182,7 +182,7 @@ __device__ __noinline__ bool sphere_test(const DevSphere &s, const DRay &r, DRay
 #define HPRT_SPILL_STACK 48
 #define HPRT_TRACE_BLOCK 256
 
-struct TraceCount { unsigned int fetched, entered, tri, sphere; };
+struct TraceCount { unsigned int fetched, entered, tri, sphere, leaf; };   // leaf: of the entered nodes, leaves
 
 // `cur` of a lane: >= 0 interior pair, REF_NONE finished, REF_EXIT leaving an instance, otherwise ~(parked primitive index)
 __device__ __forceinline__ bool is_parked(int cur) { return (uint32_t)cur > (uint32_t)REF_EXIT; }

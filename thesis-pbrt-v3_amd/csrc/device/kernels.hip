@@ -165,7 +165,8 @@ __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31
 template <bool ANY_HIT, int MODE, bool INST>
 __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ,
-                                                            DevCounters *counters, uint32_t *workCounter, uint32_t chunk, TraceTune tune) {
+                                                            DevCounters *counters, uint4 *rayStats, uint32_t *workCounter, uint32_t chunk,
+                                                            TraceTune tune) {
     constexpr bool COUNT = MODE == 1, PROF = MODE == 2;
     unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long pfStart = PROF ? clock64() : 0ull;
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
     const auto pairRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.pairs, 0, (int)(sc.nPairs * 64u), 0x00020000);
     const auto triRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.tris, 0, (int)(sc.nPrims * 48u), 0x00020000);
     const float robust = 1 + 2 * gamma_n(3);
-    TraceCount cnt = {0u, 0u, 0u, 0u};
+    TraceCount cnt = {0u, 0u, 0u, 0u, 0u};
+    unsigned int snapEntered = 0u, snapLeaf = 0u, snapPrim = 0u;     // counter values when the lane's current ray started (per-ray statistics)
     // per-lane ray state
     bool active = false, hit = false;
     uint32_t slot = 0;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
             if (sp < HPRT_LDS_STACK) e = ldsStack[sp * HPRT_TRACE_BLOCK]; else e = make_uint2(spillRef[sp - HPRT_LDS_STACK], spillT[sp - HPRT_LDS_STACK]);
             if (INST && (int)e.x == REF_EXIT) { savedTMax = __uint_as_float(e.y); return REF_EXIT; }     // the instance's walk is over
             if (COUNT) ++cnt.fetched;
-            if (__uint_as_float(e.y) < rayTMax) { if (COUNT) ++cnt.entered; return (int)e.x; }
+            if (__uint_as_float(e.y) < rayTMax) { if (COUNT) { ++cnt.entered; if ((int)e.x < 0) ++cnt.leaf; } return (int)e.x; }
         }
         return REF_NONE;
     };
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                         shear = ray_shear(rd);
                         sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
                         wait = 0u; inst = -1; hitInst = -1; instHit = false;
+                        if (COUNT) { snapEntered = cnt.entered; snapLeaf = cnt.leaf; snapPrim = cnt.tri + cnt.sphere; }
                         active = true;
                     }
                 }
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                     const float tN = isNeg ? t1 : t0, tF = isNeg ? t0 : t1;
                     const bool hitN = (isNeg ? s1 : s0) && tN < rayTMax;
                     const bool slabF = (isNeg ? s0 : s1) && !single;
-                    if (COUNT) { ++cnt.fetched; if (hitN) ++cnt.entered; }
+                    if (COUNT) { ++cnt.fetched; if (hitN) { ++cnt.entered; if (refN < 0) ++cnt.leaf; } }
                     if (hitN) {
                         cur = refN;
                         if (COUNT ? !single : (slabF && tF < rayTMax)) {
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                         }
                     } else {
                         const bool hitF = slabF && tF < rayTMax;
-                        if (COUNT && !single) { ++cnt.fetched; if (hitF) ++cnt.entered; }
+                        if (COUNT && !single) { ++cnt.fetched; if (hitF) { ++cnt.entered; if (refF < 0) ++cnt.leaf; } }
                         cur = hitF ? refF : pop();
                     }
                 }
@@ -423,6 +426,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
             if (PROF) { pf[3] += clock64() - pfT2 - pfSphere; pf[4] += pfSphere; }
             // retire finished rays
             if (active && cur == REF_NONE) {
+                // per-ray Ray::stats of the fork (core/geometry.h:1078-1173): interior nodes entered, leaves entered, primitive tests
+                if (COUNT && rayStats) rayStats[slot] = make_uint4(cnt.entered - snapEntered - (cnt.leaf - snapLeaf), cnt.leaf - snapLeaf, cnt.tri + cnt.sphere - snapPrim, 0u);
                 if (ANY_HIT) occ[slot] = hit ? 1 : 0;
                 else {
                     hits.a[slot] = make_float4(rayTMax, __int_as_float(hit ? prim : -1), hb0, hb1);
@@ -883,7 +888,7 @@ static inline uint32_t blocks_for(size_t n, uint32_t bs) { return (uint32_t)((n 
 
 void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
                  uint32_t countImm, uint32_t gridItems, const RayStream &rays, const HitStream &hits, uint8_t *occ,
-                 DevCounters *counters, uint32_t *workCounter) {
+                 DevCounters *counters, uint32_t *workCounter, uint4 *rayStats) {
     if (gridItems == 0) return;
     (void)hipMemsetAsync(workCounter, 0, sizeof(uint32_t), st);
     // persistent waves: enough blocks to fill 256 CUs at this kernel's occupancy, never more than the rays need
@@ -896,7 +901,7 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     static const TraceTune tune = DefaultTraceTune();
     static const bool profile = getenv("HPRT_TRACE_PROFILE") != nullptr;
     const bool inst = sc.nInstances != 0u;
-#define HPRT_TRACE_LAUNCH(A, M, I) hipLaunchKernelGGL((k_trace<A, M, I>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, workCounter, chunk, tune)
+#define HPRT_TRACE_LAUNCH(A, M, I) hipLaunchKernelGGL((k_trace<A, M, I>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, rayStats, workCounter, chunk, tune)
 #define HPRT_TRACE_PICK(A, M) do { if (inst) HPRT_TRACE_LAUNCH(A, M, true); else HPRT_TRACE_LAUNCH(A, M, false); } while (0)
     if (anyHit) {
         if (count) HPRT_TRACE_PICK(true, 1); else if (profile) HPRT_TRACE_PICK(true, 2); else HPRT_TRACE_PICK(true, 0);
@@ -962,6 +967,41 @@ __global__ __launch_bounds__(256) void k_unpack_hits(HitStream h, uint32_t n, fl
     const float4 a = h.a[i];
     t[i] = a.x; prim[i] = __float_as_int(a.y);
     if (bary3) { const size_t N = n; bary3[i] = a.z; bary3[N + i] = a.w; bary3[2 * N + i] = h.b[i].x; }
+}
+// Per-pixel GeneralStats (the fork's heat-map data, core/film.h:91 + core/integrator.cpp:327-328): every traced ray adds
+// its counters to the pixel of the camera sample it belongs to.  ids[slot].w is the path id; pix: [6][nPix] =
+// primitiveIntersections, ...P, leafNodeTraversals, ...P, bvhTreeNodeTraversals, ...P.
+__global__ __launch_bounds__(256) void k_pixel_stats(const uint4 *rayStats, const float4 *ids, const uint32_t *queue, const uint32_t *countPtr,
+                                                     uint32_t countImm, uint32_t nPix, int anyHit, uint32_t *pix) {
+    const uint32_t n = countPtr ? *countPtr : countImm;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = queue ? queue[i] : i;
+    const uint4 c = rayStats[slot];
+    const uint32_t p = __float_as_uint(ids[slot].w) % nPix;
+    uint32_t *base = pix + (anyHit ? nPix : 0u) + p;
+    if (c.z) atomicAdd(base, c.z);
+    if (c.y) atomicAdd(base + 2 * (size_t)nPix, c.y);
+    if (c.x) atomicAdd(base + 4 * (size_t)nPix, c.x);
+}
+void LaunchPixelStats(hipStream_t st, const uint4 *rayStats, const float4 *ids, const uint32_t *queue, const uint32_t *countPtr,
+                      uint32_t countImm, uint32_t gridItems, uint32_t nPix, bool anyHit, uint32_t *pix) {
+    if (gridItems) hipLaunchKernelGGL(k_pixel_stats, dim3(blocks_for(gridItems, 256)), dim3(256), 0, st, rayStats, ids, queue, countPtr, countImm, nPix, anyHit ? 1 : 0, pix);
+}
+// local pixel -> film pixel: out[filmIndex][7] = {rays, the six counters}
+__global__ __launch_bounds__(256) void k_pixel_stats_to_film(const uint32_t *pix, const uint32_t *pixelXY, uint32_t nPix, uint32_t spp, int cx0, int cy0,
+                                                             int width, unsigned long long *out7) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nPix) return;
+    const uint32_t pxy = pixelXY[p];
+    const size_t f = (size_t)((int)(pxy >> 16) - cy0) * (size_t)width + (size_t)((int)(pxy & 0xffffu) - cx0);
+    unsigned long long *o = out7 + 7 * f;
+    o[0] = spp;
+    for (int k = 0; k < 6; ++k) o[1 + k] = pix[(size_t)k * nPix + p];
+}
+void LaunchPixelStatsToFilm(hipStream_t st, const uint32_t *pix, const uint32_t *pixelXY, uint32_t nPix, uint32_t spp, int cx0, int cy0, int width,
+                            unsigned long long *out7) {
+    if (nPix) hipLaunchKernelGGL(k_pixel_stats_to_film, dim3(blocks_for(nPix, 256)), dim3(256), 0, st, pix, pixelXY, nPix, spp, cx0, cy0, width, out7);
 }
 void LaunchPackRays(hipStream_t st, const float *rays7, uint32_t n, const RayStream &out) {
     if (n) hipLaunchKernelGGL(k_pack_rays, dim3(blocks_for(n, 256)), dim3(256), 0, st, rays7, n, out);
