@@ -351,7 +351,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
                     bool bogus = TriangleIsBogus(vec3(a[0], a[1], a[2]), vec3(b[0], b[1], b[2]), vec3(c[0], c[1], c[2]),
                                                  sh.UV ? &sh.UV[2 * (size_t)v[0]] : nullptr, sh.UV ? &sh.UV[2 * (size_t)v[1]] : nullptr,
                                                  sh.UV ? &sh.UV[2 * (size_t)v[2]] : nullptr);
-                    uint32_t tag = bogus ? TAG_BOGUS : 0u;
+                    uint32_t tag = (bogus ? TAG_BOGUS : 0u) | (d->materials[sh.material].type == 1 ? TAG_PLASTIC : 0u);
                     r0 = make_float4(a[0], a[1], a[2], u2f(tag)); r1 = make_float4(b[0], b[1], b[2], u2f(s)); r2 = make_float4(c[0], c[1], c[2], u2f(0u));
                     for (int k = 0; k < 3; ++k) primVtx[3 * i + k] = (uint32_t)(vtxBase[s] + (uint32_t)v[k]);
                 } else {

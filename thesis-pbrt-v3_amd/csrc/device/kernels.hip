@@ -502,7 +502,7 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
             const bool isTri = (tag & TAG_KIND_MASK) == 0u && __float_as_int(hit.b[slot].y) < 0;
             if (bounces >= maxDepth) { if (bounces == 0 && !isTri) bin = 2; }   // only an emitter hit by a camera ray matters
             else if (!isTri) bin = 2;
-            else bin = sc.materials[sc.shapes[__float_as_uint(sc.tris[3 * prim + 1].w)].material].type == 1 ? 1 : 0;
+            else bin = (tag & TAG_PLASTIC) ? 1 : 0;
         }
         if (bin < 0) Lfinal[__float_as_uint(in.beta[slot].w)] = in.L[slot];      // the path ends here
     }
