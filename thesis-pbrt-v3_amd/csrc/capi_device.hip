@@ -626,7 +626,7 @@ static int TraceHost(HprtScene *s, bool anyHit, size_t n, const float *o, const 
         HIP_TRY(hipMemcpy(hb.data(), hits.b, 8 * n, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; ++i) {
             if (t_out) t_out[i] = ha[i].x;
-            if (prim_out) memcpy(&prim_out[i], &ha[i].y, 4);
+            if (prim_out) { int32_t w; memcpy(&w, &ha[i].y, 4); prim_out[i] = hit_prim(w); }
             if (inst_out) memcpy(&inst_out[i], &hb[i].y, 4);
             if (bary_out) { bary_out[3 * i] = ha[i].z; bary_out[3 * i + 1] = ha[i].w; bary_out[3 * i + 2] = hb[i].x; }
         }
@@ -683,7 +683,7 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         stats->rays += active;
         HIP_TRY(hipMemsetAsync(cur.nextCount, 0, 4 * sizeof(uint32_t), st));   // the four counters are contiguous
         HIP_TRY(hipMemsetAsync(bins.count, 0, 4 * sizeof(uint32_t), st));
-        LaunchBin(st, s->dev, in, w.hit, activeQ, nullptr, active, active, rp.maxDepth, bins, w.Lfinal);
+        LaunchBin(st, s->dev, in, w.hit, activeQ, nullptr, active, active, rp.maxDepth, bounce, bins, w.Lfinal);
         HIP_TRY(hipMemcpyAsync(bins.count + 3, bins.count + 2, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));   // bin 2 before deferrals
         // one launch per material bin; grids are sized for the upper bound, surplus blocks exit on the bin's count
         for (int mode = 0; mode < 3; ++mode)

@@ -38,6 +38,11 @@ namespace hprt {
 // leaf child.  meta: split axis (bits 0-1) | PAIR_SINGLE.
 struct DevPair { float x[4], y[4], z[4]; int32_t ref0, ref1; uint32_t meta, pad; };
 enum : uint32_t { PAIR_SINGLE = 4u };
+// The primitive word of a hit record: ordered index (< 2^28) | shading-bin code << 28 (k_bin then needs
+// nothing but this word): HIT_PLASTIC triangle of a plastic material, HIT_GENERIC quadric or hit inside an instance
+enum : uint32_t { HIT_PRIM_MASK = 0x0fffffffu, HIT_PLASTIC = 1u << 28, HIT_GENERIC = 2u << 28 };
+__host__ __device__ inline int32_t hit_prim(int32_t word) { return word < 0 ? word : (int32_t)((uint32_t)word & HIT_PRIM_MASK); }
+
 // REF_NONE: nothing left.  REF_EXIT: stack sentinel under an instance's walk — popping it ends the
 // instance (TransformedPrimitive::Intersect returns, core/primitive.cpp:77-93)
 enum : int32_t { REF_NONE = (int32_t)0x80000000, REF_EXIT = (int32_t)0x80000001 };

@@ -70,7 +70,8 @@ void LaunchPixelStatsToFilm(hipStream_t st, const uint32_t *pix, const uint32_t 
                             unsigned long long *out7);
 void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathStream &out, uint32_t s0, uint32_t nSlots);
 void LaunchBin(hipStream_t st, const DevScene &sc, const PathStream &in, const HitStream &hit, const uint32_t *queue,
-               const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, int32_t maxDepth, const BinSet &bins, float4 *Lfinal);
+               const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, int32_t maxDepth, int32_t bounces, const BinSet &bins,
+               float4 *Lfinal);
 void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathStream &in, const HitStream &hit,
                  uint32_t gridItems, uint32_t s0, const PathStream &out, const VertexStreams &vs, const QueueSet &q,
                  const BinSet &bins, float4 *Lfinal);

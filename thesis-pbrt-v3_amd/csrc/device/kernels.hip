@@ -344,7 +344,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                                          vec3(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
                                          vec3(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z)), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
                                 if (ANY_HIT) { hit = true; done = true; }
-                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = b0; hb1 = b1; hb2 = b2; if (INST) { hitInst = inst; instHit = inst >= 0; } }
+                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)(pi | ((tag & TAG_PLASTIC) ? HIT_PLASTIC : 0u) | (INST && inst >= 0 ? HIT_GENERIC : 0u)); hb0 = b0; hb1 = b1; hb2 = b2; if (INST) { hitInst = inst; instHit = inst >= 0; } }
                             }
                             if (done) cur = REF_NONE;
                             else if (tag & TAG_LAST) cur = pop();
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                     bool done = false;
                     if (sphere_test(sc.spheres[waitInfo & 0x7fffffffu], rr, &robj, &ph, &phi, &t)) {
                         if (ANY_HIT) { hit = true; done = true; }
-                        else { hit = true; rayTMax = t; prim = (int32_t)pi; hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; if (INST) { hitInst = inst; instHit = inst >= 0; } }
+                        else { hit = true; rayTMax = t; prim = (int32_t)(pi | HIT_GENERIC); hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; if (INST) { hitInst = inst; instHit = inst >= 0; } }
                     }
                     if (done) cur = REF_NONE;
                     else if (waitInfo & 0x80000000u) cur = pop();
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, 
 // only added at bounce 0 (path.cpp:97).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStream hit, const uint32_t *queue, const uint32_t *countPtr,
-                                              uint32_t countImm, int32_t maxDepth, BinSet bins, float4 *Lfinal) {
+                                              uint32_t countImm, int32_t maxDepth, int32_t bounces, BinSet bins, float4 *Lfinal) {
     __shared__ BlockAppendLds al;
     const uint32_t n = countPtr ? *countPtr : countImm;
     if (blockIdx.x * blockDim.x >= n) return;      // whole block beyond the queue (grids are sized for the batch)
@@ -493,16 +493,15 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
     uint32_t slot = 0;
     if (i < n) {
         slot = queue ? queue[i] : i;
-        const int32_t prim = __float_as_int(hit.a[slot].y);
-        const int bounces = (int)((__float_as_uint(in.ray.b[slot].w) >> 8) & 0xffu);
-        if (prim >= 0) {
-            const uint32_t tag = __float_as_uint(sc.tris[3 * prim].w);
+        // the hit's primitive word carries the bin (dev_scene.h); every path of this pass is at the same bounce
+        const int32_t word = __float_as_int(hit.a[slot].y);
+        if (word >= 0) {
             // triangles reached directly go to the material-specialised variants; quadrics and hits inside
             // object instances (surface interaction transformed back to world space) to the generic one
-            const bool isTri = (tag & TAG_KIND_MASK) == 0u && __float_as_int(hit.b[slot].y) < 0;
-            if (bounces >= maxDepth) { if (bounces == 0 && !isTri) bin = 2; }   // only an emitter hit by a camera ray matters
-            else if (!isTri) bin = 2;
-            else bin = (tag & TAG_PLASTIC) ? 1 : 0;
+            const bool generic = ((uint32_t)word & HIT_GENERIC) != 0u;
+            if (bounces >= maxDepth) { if (bounces == 0 && generic) bin = 2; }   // only an emitter hit by a camera ray matters
+            else if (generic) bin = 2;
+            else bin = ((uint32_t)word & HIT_PLASTIC) ? 1 : 0;
         }
         if (bin < 0) Lfinal[__float_as_uint(in.beta[slot].w)] = in.L[slot];      // the path ends here
     }
@@ -546,7 +545,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
         const uint32_t pathId = __float_as_uint(beta4.w);
         const uint32_t pix = pathId % rp.nPix, sIdx = pathId / rp.nPix;
         const uint64_t index = (uint64_t)rp.pixelOffset[pix] + (uint64_t)(s0 + sIdx) * (uint64_t)rp.hal.sampleStride;
-        const int32_t prim = __float_as_int(hitA.y);
+        const int32_t prim = hit_prim(__float_as_int(hitA.y));
         const vec3 rayO(rayA.x, rayA.y, rayA.z);
         const vec3 rayD(rayB.x, rayB.y, rayB.z);
         rgb beta(beta4.x, beta4.y, beta4.z);
@@ -739,7 +738,7 @@ __global__ __launch_bounds__(256) void k_resolve(DevScene sc, VertexStreams vs, 
     rgb Ld(0.f);
     if ((info & 0x40000000u) && !vs.occluded[j]) Ld = Ld + rgb(pl.x, pl.y, pl.z);
     if (info & 0x80000000u) {
-        const int32_t prim = __float_as_int(vs.misHit.a[j].y);
+        const int32_t prim = hit_prim(__float_as_int(vs.misHit.a[j].y));
         if (prim >= 0) {
             const int shapeId = (int)__float_as_uint(sc.tris[3 * prim + 1].w);
             if (sc.shapes[shapeId].areaLight == lightNum) {
@@ -921,8 +920,9 @@ void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, 
     if (nSlots) hipLaunchKernelGGL(k_generate, dim3(blocks_for(nSlots, 256)), dim3(256), 0, st, sc, rp, out, s0, nSlots);
 }
 void LaunchBin(hipStream_t st, const DevScene &sc, const PathStream &in, const HitStream &hit, const uint32_t *queue,
-               const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, int32_t maxDepth, const BinSet &bins, float4 *Lfinal) {
-    if (gridItems) hipLaunchKernelGGL(k_bin, dim3(blocks_for(gridItems, 1024)), dim3(1024), 0, st, sc, in, hit, queue, countPtr, countImm, maxDepth, bins, Lfinal);
+               const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, int32_t maxDepth, int32_t bounces, const BinSet &bins,
+               float4 *Lfinal) {
+    if (gridItems) hipLaunchKernelGGL(k_bin, dim3(blocks_for(gridItems, 1024)), dim3(1024), 0, st, sc, in, hit, queue, countPtr, countImm, maxDepth, bounces, bins, Lfinal);
 }
 void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathStream &in, const HitStream &hit,
                  uint32_t gridItems, uint32_t s0, const PathStream &out, const VertexStreams &vs, const QueueSet &q,
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256) void k_unpack_hits(HitStream h, uint32_t n, fl
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 a = h.a[i];
-    t[i] = a.x; prim[i] = __float_as_int(a.y);
+    t[i] = a.x; prim[i] = hit_prim(__float_as_int(a.y));
     if (bary3) { const size_t N = n; bary3[i] = a.z; bary3[N + i] = a.w; bary3[2 * N + i] = h.b[i].x; }
 }
 // Per-pixel GeneralStats (the fork's heat-map data, core/film.h:91 + core/integrator.cpp:327-328): every traced ray adds
