@@ -132,7 +132,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if world == 1 and args.spp == 256 and os.path.exists(tpath):
             try:
-                tk = json.load(open(tpath))["kernels"].get("k_trace<false, 0>")      # closest hit, plain (not the counting pass)
+                kernels = json.load(open(tpath))["kernels"]
+                tk = next((v for k, v in kernels.items() if k.startswith("k_trace<false, 0")), None)   # closest hit, plain (not the counting pass)
                 if tk:
                     traffic, traffic_from = round(tk["hbm_bytes_per_launch"]), "profiles/r01_traffic.json"
             except Exception:
