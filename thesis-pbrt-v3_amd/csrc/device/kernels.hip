@@ -220,6 +220,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
     // a single word retires only ~90 atomics per microsecond) and hands them to idle lanes
     // from its private range [localNext, localEnd).
     uint32_t localNext = 0u, localEnd = 0u;
+    uint32_t window = 0u, windowBase = 0xffffffffu;
     if (sc.nPairs == 0 && n > 0) {
         // empty aggregate: every ray misses (accelerators/bvh.cpp:355)
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -245,10 +246,20 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                 const uint32_t want = (uint32_t)__popcll(idle);
                 const uint32_t base = localNext;
                 localNext = (localNext + want < localEnd) ? localNext + want : localEnd;
+                // Queue entries are taken from a per-wave window (lane l holds queue[windowBase + l]) that was
+                // loaded during the previous refill, so a refill pays one memory round trip (the rays), not two.
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                uint32_t slotW = 0u;
+                if (queue) {
+                    if (windowBase != base) { window = (base + lane < localEnd) ? queue[base + lane] : 0u; windowBase = base; }   // new chunk
+                    slotW = __shfl(window, (int)rank);
+                    window = (localNext + lane < localEnd) ? queue[localNext + lane] : 0u;      // for the next refill; arrives with the rays below
+                    windowBase = localNext;
+                }
                 if (!active) {
-                    const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    const uint32_t idx = base + rank;
                     if (idx < localEnd) {
-                        slot = queue ? queue[idx] : idx;
+                        slot = queue ? slotW : idx;
                         const float4 ra = rays.a[slot], rb = rays.b[slot];
                         ro = vec3(ra.x, ra.y, ra.z);
                         const vec3 rd(rb.x, rb.y, rb.z);
