@@ -169,3 +169,31 @@ def test_ten_million_instanced_triangles(hprt, orc, tmp_path):
     assert np.array_equal(film0.view(np.uint32), film1.view(np.uint32))
     assert st["nodes_fetched"] == c0["nodes_fetched"] and st["tri_tests"] == c0["tri_tests"] and st["tri_tests_p"] == c0["tri_tests_p"]
     assert film0[..., :3].max() > 0
+
+
+def test_sponza_class_interior(hprt, orc, tmp_path):
+    """BASELINE.json config 2's shape of scene (the reference's Sponza assets are not in its repository):
+    tools/scene_gen.atrium, 312 k triangles — coarse walls next to finely tessellated columns, arches and cloth, a
+    point light, matte + plastic.  BVH arrays byte-identical to the oracle's; film of a crop and the counters equal."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import scene_gen
+    text, ntri = scene_gen.atrium(1.0, xres=256, yres=192, spp=2)
+    assert ntri > 260000
+    p = tmp_path / "atrium.pbrt"; p.write_text(text)
+    model = hprt.Model.parse(str(p))
+    assert model.warnings() == []
+    opt = model.options.copy()
+    for i, v in enumerate((0.3, 0.62, 0.35, 0.7)):
+        opt.crop[i] = v
+    model.options = opt
+    baked = str(tmp_path / "atrium.hprt"); model.save(baked)
+    bvh = hprt.Bvh(model); oracle = orc.OracleScene(baked)
+    n1, o1 = oracle.bvh_arrays(); n2, o2 = bvh.arrays()
+    assert np.array_equal(n1, n2) and np.array_equal(o1, o2)
+    scene = hprt.Scene(model, bvh)
+    _, film0, c0, _, _ = oracle.render(threads=8)
+    film1, st = scene.render(count_work=True)
+    assert np.array_equal(film0.view(np.uint32), film1.view(np.uint32))
+    for k in ("rays", "shadow_rays", "nodes_fetched", "nodes_fetched_p", "tri_tests", "tri_tests_p"):
+        assert st[k] == c0[k], k

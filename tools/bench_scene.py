@@ -1,0 +1,46 @@
+"""Frame throughput of an arbitrary scene (not the contract bench: bench.py stays on BASELINE.json's config[1]).
+usage: python tools/bench_scene.py <scene.pbrt | scene.hprt | atrium[:detail]> [--spp N] [--steps K] [--cpu-spp M]
+Prints one JSON line: ms/frame, Mrays/s, Msamples/s, kernel rates, and the oracle's rate on a sample of the frame."""
+import argparse, importlib, json, os, sys, tempfile, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+hprt = importlib.import_module("thesis-pbrt-v3_amd")
+ap = argparse.ArgumentParser()
+ap.add_argument("scene"); ap.add_argument("--spp", type=int, default=0); ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--cpu-spp", type=int, default=0)
+args = ap.parse_args()
+tmp = tempfile.mkdtemp()
+if args.scene.startswith("atrium"):
+    import scene_gen
+    detail = float(args.scene.split(":")[1]) if ":" in args.scene else 1.0
+    text, ntri = scene_gen.atrium(detail)
+    path = os.path.join(tmp, "atrium.pbrt"); open(path, "w").write(text)
+    model = hprt.Model.parse(path)
+elif args.scene.endswith(".hprt"):
+    model = hprt.Model.load(args.scene)
+else:
+    model = hprt.Model.parse(args.scene, {"$acc": '"bvh"'})
+t0 = time.perf_counter(); bvh = hprt.Bvh(model); t_bvh = time.perf_counter() - t0
+scene = hprt.Scene(model, bvh, device=0)
+opt = model.options
+if args.spp: opt.spp = args.spp
+scene.render(opt); torch.cuda.synchronize()
+best = None
+for _ in range(args.steps):
+    t0 = time.perf_counter(); _, st = scene.render(opt); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    if best is None or dt < best[0]: best = (dt, st)
+dt, st = best
+out = {"scene": args.scene, "counts": model.counts(), "bvh_nodes": bvh.info()["nodes"], "bvh_build_s": round(t_bvh, 3), "spp": int(opt.spp),
+       "ms_per_frame": round(dt * 1e3, 2), "mrays_per_s": round((st["rays"] + st["shadow_rays"]) / dt / 1e6, 1),
+       "msamples_per_s": round(st["camera_rays"] / dt / 1e6, 1), "rays": st["rays"], "shadow_rays": st["shadow_rays"],
+       "closest_kernel_mrays_per_s": round(st["extend_rays"] / max(st["extend_seconds"], 1e-12) / 1e6, 1),
+       "any_hit_kernel_mrays_per_s": round(st["occluded_rays"] / max(st["occluded_seconds"], 1e-12) / 1e6, 1)}
+if args.cpu_spp:
+    import orc
+    baked = os.path.join(tmp, "scene.hprt"); model.save(baked)
+    o = orc.OracleScene(baked)
+    _, _, c, sec, nt = o.render(spp=args.cpu_spp, threads=os.cpu_count())
+    out["cpu_port"] = {"mrays_per_s": round((c["rays"] + c["shadow_rays"]) / sec / 1e6, 2), "threads": nt, "spp": args.cpu_spp, "seconds": round(sec, 2)}
+    out["gpu_over_cpu"] = round(out["mrays_per_s"] / out["cpu_port"]["mrays_per_s"], 1)
+print(json.dumps(out))

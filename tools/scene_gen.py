@@ -1,0 +1,84 @@
+"""Procedural stand-ins for BASELINE.json's larger configurations (the reference's Sponza and conference-room
+assets are not part of its repository: scenes/sponza includes files under scenes/geometry/sponza that do not exist).
+`atrium(n)` writes .pbrt text of a Sponza-class interior: two storeys of arcades around a courtyard — flat walls and
+floors (few large triangles), tessellated round columns and arches (many small ones), wavy curtains — lit by a point
+light as scenes/sponza is, with constant-colour matte/plastic materials (image textures are not built).
+~262 k triangles at the default detail."""
+import numpy as np
+
+
+def _mesh(P, idx):
+    return ('Shape "trianglemesh" "integer indices" [' + " ".join(map(str, np.asarray(idx, np.int64).ravel())) + '] "point P" [' +
+            " ".join("%.7g" % v for v in np.asarray(P, np.float32).ravel()) + "]\n")
+
+
+def _grid(f, nu, nv):
+    """f(u, v) -> xyz over [0,1]^2, (nu x nv quads)"""
+    u, v = np.meshgrid(np.linspace(0, 1, nu + 1), np.linspace(0, 1, nv + 1), indexing="ij")
+    P = np.stack(f(u, v), axis=-1).reshape(-1, 3)
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    a = (i * (nv + 1) + j).ravel(); b = a + nv + 1
+    idx = np.stack([a, b, b + 1, a, b + 1, a + 1], axis=1).reshape(-1, 3)
+    return P, idx
+
+
+def _column(cx, cy, z0, z1, r, seg, rings):
+    return _grid(lambda u, v: (cx + r * (1 + 0.06 * np.sin(12 * np.pi * v)) * np.cos(2 * np.pi * u),
+                               cy + r * (1 + 0.06 * np.sin(12 * np.pi * v)) * np.sin(2 * np.pi * u), z0 + (z1 - z0) * v), seg, rings)
+
+
+def _arch(x0, x1, y, z0, rise, depth, seg):
+    # half-torus-like arch between two columns along x at height z0
+    c, R = 0.5 * (x0 + x1), 0.5 * (x1 - x0)
+    return _grid(lambda u, v: (c - R * np.cos(np.pi * u), y + depth * (v - 0.5), z0 + rise * np.sin(np.pi * u) * (1 + 0.05 * np.cos(2 * np.pi * v))), seg, 6)
+
+
+def atrium(detail=1.0, xres=700, yres=700, spp=64, maxdepth=5):
+    rng = np.random.default_rng(3)
+    parts = {"stone": [], "plaster": [], "cloth": [], "floor": []}
+    W, D, H = 12.0, 6.0, 7.0
+    # floor, ceiling, walls: coarse grids
+    parts["floor"].append(_grid(lambda u, v: (W * (u - .5), D * (v - .5), 0 * u), 24, 12))
+    parts["plaster"].append(_grid(lambda u, v: (W * (u - .5), D * (v - .5), H + 0 * u), 8, 4))
+    for s in (-1, 1):
+        parts["plaster"].append(_grid(lambda u, v, s=s: (W * (u - .5), s * D / 2 + 0 * u, H * v), 16, 8))
+        parts["plaster"].append(_grid(lambda u, v, s=s: (s * W / 2 + 0 * u, D * (u - .5), H * v), 8, 8))
+    seg = max(8, int(40 * detail)); rings = max(8, int(60 * detail))
+    xs = np.linspace(-W / 2 + 1, W / 2 - 1, 9)
+    for storey, (z0, z1) in enumerate(((0.0, 3.0), (3.4, 6.2))):
+        for s in (-1, 1):
+            y = s * (D / 2 - 1.2)
+            for x in xs:
+                parts["stone"].append(_column(x, y, z0, z1, 0.18 - 0.03 * storey, seg, rings))
+            for a, b in zip(xs[:-1], xs[1:]):
+                parts["stone"].append(_arch(a, b, y, z1, 0.45, 0.4, max(8, int(48 * detail))))
+        # gallery floor slab between the storeys
+        if storey == 0:
+            for s in (-1, 1):
+                parts["plaster"].append(_grid(lambda u, v, s=s: (W * (u - .5), s * (D / 2 - 0.6 * v - 0.05), 3.2 + 0 * u), 24, 3))
+    # curtains: wavy sheets hanging in some arches
+    for k in range(6):
+        x = xs[k + 1] - 0.6; s = 1 if k % 2 else -1
+        ph = rng.uniform(0, 6)
+        parts["cloth"].append(_grid(lambda u, v, x=x, s=s, ph=ph: (x + 1.1 * u, s * (D / 2 - 1.2) + 0.08 * np.sin(18 * u + ph) * (1 - 0.5 * v), 0.4 + 2.4 * v),
+                                    max(8, int(110 * detail)), max(8, int(90 * detail))))
+    mats = {"stone": 'Material "matte" "color Kd" [.62 .58 .5]\n', "plaster": 'Material "matte" "color Kd" [.75 .72 .66]\n',
+            "cloth": 'Material "plastic" "color Kd" [.5 .12 .1] "color Ks" [.15 .15 .15] "float roughness" [.3]\n',
+            "floor": 'Material "plastic" "color Kd" [.35 .33 .3] "color Ks" [.25 .25 .25] "float roughness" [.12]\n'}
+    body, ntri = [], 0
+    for name, meshes in parts.items():
+        body.append(mats[name])
+        for P, idx in meshes:
+            body.append(_mesh(P, idx)); ntri += len(idx)
+    text = ("LookAt -5.2 -0.3 1.7  1 0.2 2.2  0 0 1\nCamera \"perspective\" \"float fov\" [58]\n"
+            "Film \"image\" \"integer xresolution\" [%d] \"integer yresolution\" [%d]\nSampler \"halton\" \"integer pixelsamples\" [%d]\n"
+            "Integrator \"path\" \"integer maxdepth\" [%d]\nAccelerator \"bvh\"\nWorldBegin\n"
+            "LightSource \"point\" \"point from\" [0 0 5.2] \"color I\" [60 58 52]\n%sWorldEnd\n" % (xres, yres, spp, maxdepth, "".join(body)))
+    return text, ntri
+
+
+if __name__ == "__main__":
+    import sys
+    text, n = atrium(float(sys.argv[2]) if len(sys.argv) > 2 else 1.0)
+    open(sys.argv[1], "w").write(text)
+    print(n, "triangles")
