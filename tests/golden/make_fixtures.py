@@ -10,6 +10,11 @@ gets the resulting files with the repository snapshot.
                          (scenes/killeroo-simple.png, 8 spp, 8-bit sRGB) as a uint8 array —
                          a data file the reference ships as its regression image
                          (scripts/render.sh:4).
+  dodecahedron.hprt, killeroo.hprt + *_8spp_srgb8.npz
+                         two more of the reference's regression pairs (scenes/dodecahedron[.png]: two plastic
+                         dodecahedra, distant light; scenes/killeroo[.png]: one plastic killeroo, distant light —
+                         killeroo-test1..4.png are the same image, byte for byte).  Template tokens replaced as
+                         scripts/render_simple.sh does.
   simple_instanced.hprt  baked scene of scenes/simple (eight spheres in one object definition,
                          one ObjectInstance, distant light) — the reference's object-instancing
                          scene — with the camera and light of the version its checked-in render
@@ -40,6 +45,14 @@ def main():
     from PIL import Image
     png = np.asarray(Image.open(os.path.join(REF, "killeroo-simple.png")).convert("RGB"))
     np.savez_compressed(os.path.join(HERE, "killeroo_simple_8spp_srgb8.npz"), srgb8=png)
+    sub = {"$acc": '"bvh"', "$accnr": "0", "$splitalpha": "0", "$alphatype": "0", "$axisselectiontype": "0", "$axisselectionamount": "0",
+           "/Programming/Thesis/pbrt-v3/scenes/": REF + "/", "../../../../scenes/": REF + "/"}
+    for name in ("dodecahedron", "killeroo"):
+        m = hprt.Model.parse(os.path.join(REF, name), sub)
+        print(name + ":", m.counts(), m.warnings())
+        m.save(os.path.join(HERE, name + ".hprt"))
+        png = np.asarray(Image.open(os.path.join(REF, name + ".png")).convert("RGB"))
+        np.savez_compressed(os.path.join(HERE, name + "_8spp_srgb8.npz"), srgb8=png)
     import tempfile
     text = open(os.path.join(REF, "simple")).read()
     text = text.replace("LookAt -5 -5 0", "LookAt -5 0 0").replace('"point from" [-1 -1 0]', '"point from" [-1 0 0]')

@@ -183,3 +183,20 @@ def test_per_pixel_statistics_match(hprt, orc, killeroo_scene, killeroo_oracle, 
     assert np.loadtxt(prefix + "-kdTreeNodeTraversals.txt").sum() == 0
     with pytest.raises(hprt.HprtError):
         killeroo_scene.render(opt); killeroo_scene.pixel_stats()
+
+
+@pytest.mark.parametrize("name", ["dodecahedron", "killeroo", "simple_instanced"])
+def test_reference_regression_scenes_full_frame(hprt, orc, name):
+    """The reference's other regression scenes (tests/golden/make_fixtures.py), whole 700x700 frame at their 8 spp:
+    the film state of the HIP path equals the oracle's bit for bit — and the oracle reproduces the reference's
+    checked-in renders of exactly these scenes (tests/test_oracle_pins.py)."""
+    import os
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, name + ".hprt")
+    model = hprt.Model.load(path); bvh = hprt.Bvh(model); scene = hprt.Scene(model, bvh)
+    oracle = orc.OracleScene(path)
+    _, film0, c0, _, _ = oracle.render(threads=16)
+    film1, st = scene.render(count_work=True)
+    assert np.array_equal(film0.view(np.uint32), film1.view(np.uint32))
+    assert st["rays"] == c0["rays"] and st["shadow_rays"] == c0["shadow_rays"] and st["nodes_fetched"] == c0["nodes_fetched"]
+    assert st["tri_tests"] == c0["tri_tests"] and st["sphere_tests_p"] == c0["sphere_tests_p"]
