@@ -392,7 +392,6 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     const std::vector<uint16_t> &perms = HaltonPermutations();
     // ---- child-pair layout of the BVHs (device/dev_scene.h): one run of pairs per aggregate ----
     std::vector<DevPair> pairs((size_t)pairBase[aggs.size()]);
-    bool nested = true;      // child bounds inside the parent's: what BVHAccel's builder produces; hand-made trees may not
     for (size_t ai = 0; ai < aggs.size(); ++ai) {
         const Agg &g = aggs[ai];
         if (g.nNodes == 0) continue;
@@ -418,12 +417,8 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
             if ((nd[i].countAxis & 3u) == 3u) continue;
             const uint32_t c[2] = {i + 1u, (uint32_t)nd[i].offset};
             fill(pairs[(size_t)ref[i]], c[0], c[1], nd[i].countAxis & 3u);
-            for (int k = 0; k < 2; ++k)
-                for (int ax = 0; ax < 3; ++ax)
-                    if (!(nd[c[k]].bmin[ax] >= nd[i].bmin[ax] && nd[c[k]].bmax[ax] <= nd[i].bmax[ax])) nested = false;
         }
     }
-    (void)nested;
     std::vector<DevInstance> instances(d->n_instances);
     for (uint32_t i = 0; i < d->n_instances; ++i) {
         const HprtInstanceDesc &in = d->instances[i];
