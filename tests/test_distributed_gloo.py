@@ -44,8 +44,12 @@ def _worker(rank, world, port, out_path):
     tiles.gather_film(t, dist, dst=0)
     counts = torch.tensor([own], dtype=torch.int64)
     dist.all_reduce(counts)
+    # the per-pixel traversal statistics shard and merge the same way (Film::MergeFilmTile, core/film.cpp:130)
+    st = torch.from_numpy(o.pixel_stats().astype(np.int64))
+    tiles.gather_pixel_stats(st, dist, dst=0)
     if rank == 0:
         np.save(out_path, np.concatenate([t.numpy().ravel(), np.array([float(counts.item())], np.float32)]))
+        np.save(out_path + ".stats.npy", st.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,8 +61,10 @@ def test_two_rank_tile_sharding_reproduces_the_film(tmp_path, killeroo_oracle):
     got = np.load(out)
     killeroo_oracle.set_film(crop=CROP, spp=SPP)
     _, film, _, _, _ = killeroo_oracle.render(spp=SPP, threads=4)
+    stats = killeroo_oracle.pixel_stats()
     killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
     assert np.array_equal(got[:-1].view(np.uint32), film.ravel().view(np.uint32))
+    assert np.array_equal(np.load(out + ".stats.npy"), stats.astype(np.int64)) and stats[..., 1].sum() > 0
     # some pixels were written by both ranks (cross-tile filter footprint) -> the reduce really summed
     assert got[-1] >= film.shape[0] * film.shape[1]
 

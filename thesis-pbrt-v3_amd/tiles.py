@@ -31,3 +31,9 @@ def gather_film(film, dist, dst=0):
     else:
         dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
     return film
+
+
+def gather_pixel_stats(stats, dist, dst=0):
+    """Sum per-rank Pixel::stats tensors (int64 [H, W, 7] from Scene.pixel_stats(); zeros outside a rank's
+    tiles) onto `dst`: Film::MergeFilmTile's `mergePixel.stats += tilePixel.stats` (core/film.cpp:130)."""
+    return gather_film(stats, dist, dst)
