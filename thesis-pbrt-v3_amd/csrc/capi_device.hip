@@ -168,6 +168,9 @@ struct FrameSetup {
     std::vector<uint32_t> pixelXY; std::vector<uint64_t> pixelOffset;
     std::vector<int32_t> localIndex;   // cropped-film index -> local pixel index or -1
     int W, H;
+    // HaltonSampler::GetIndexForSample's per-pixel offset (samplers/halton.cpp:101-118) depends on the pixel
+    // coordinates modulo kMaxResolution only: offset = (offX[x mod 128] + offY[y mod 128]) mod sampleStride
+    uint64_t offX[128], offY[128];
 };
 int SetupFrame(const HprtRenderOptions &o, FrameSetup *f) {
     if (o.xres <= 0 || o.yres <= 0 || o.xres > 32768 || o.yres > 32768) return SetError(HPRT_E_INVALID, "film resolution out of range");
@@ -184,17 +187,24 @@ int SetupFrame(const HprtRenderOptions &o, FrameSetup *f) {
     if (f->W <= 0 || f->H <= 0) return SetError(HPRT_E_INVALID, "empty crop window");
     f->ntx = (fg.sx1 - fg.sx0 + 15) / 16; f->nty = (fg.sy1 - fg.sy0 + 15) / 16;                   // core/integrator.cpp:237-239
     f->hal = MakeHaltonLayout(fg.sx1 - fg.sx0, fg.sy1 - fg.sy0);
+    // the two addends of the offset (each already reduced), from the layout's own function on (m, 0) and (0, m)
+    const uint64_t base = (uint64_t)HaltonPixelOffset(f->hal, 0, 0), stride = (uint64_t)std::max(1, f->hal.sampleStride);
+    for (int m = 0; m < 128; ++m) {
+        f->offX[m] = (uint64_t)HaltonPixelOffset(f->hal, m, 0);
+        f->offY[m] = ((uint64_t)HaltonPixelOffset(f->hal, 0, m) + stride - base) % stride;
+    }
     return HPRT_OK;
 }
 void AddTilePixels(FrameSetup *f, int tile) {
     const FilmGeom &fg = f->fg;
     int tx = tile % f->ntx, ty = tile / f->ntx;
     int x0 = fg.sx0 + tx * 16, x1 = std::min(x0 + 16, fg.sx1), y0 = fg.sy0 + ty * 16, y1 = std::min(y0 + 16, fg.sy1);
+    const uint64_t stride = (uint64_t)std::max(1, f->hal.sampleStride);
     for (int y = y0; y < y1; ++y)
         for (int x = x0; x < x1; ++x) {
             f->localIndex[(size_t)(y - fg.cy0) * f->W + (x - fg.cx0)] = (int32_t)f->pixelXY.size();
             f->pixelXY.push_back((uint32_t)x | ((uint32_t)y << 16));
-            f->pixelOffset.push_back((uint64_t)HaltonPixelOffset(f->hal, x, y));
+            f->pixelOffset.push_back(f->hal.sampleStride > 1 ? (f->offX[((x % 128) + 128) % 128] + f->offY[((y % 128) + 128) % 128]) % stride : 0ull);
         }
 }
 
@@ -756,6 +766,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     const int nTiles = f.ntx * f.nty;
     int tb = std::max(0, desc->tile_begin), te = desc->tile_end <= 0 ? nTiles : std::min(desc->tile_end, nTiles), ts = std::max(1, desc->tile_stride);
     f.localIndex.assign((size_t)f.W * f.H, -1);
+    f.pixelXY.reserve((size_t)f.W * f.H / (size_t)ts + 256); f.pixelOffset.reserve((size_t)f.W * f.H / (size_t)ts + 256);
     std::vector<uint8_t> tileIsLocal(nTiles, 0);
     for (int t = tb; t < te; t += ts) { tileIsLocal[t] = 1; AddTilePixels(&f, t); }
     const uint32_t nPix = (uint32_t)f.pixelXY.size();
