@@ -53,7 +53,7 @@ template <typename T> hipError_t upload(DevBuf &b, const std::vector<T> &v) {
 struct HprtScene {
     int device = 0;
     DevScene dev;
-    DevBuf nodes, tris, primVtx, vN, vUV, vS, shapes, materials, lights, spheres, instances, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
+    DevBuf nodes, tris, primVtx, primN, vUV, vS, shapes, materials, lights, spheres, instances, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
     DevBuf counters, workCounter;
     DevBuf rayStats, pixelStatsLocal, pixelStatsFilm; bool pixelStatsValid = false;   // HPRT_RENDER_PIXEL_STATS
     // render-time state
@@ -320,7 +320,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     std::unique_ptr<HprtScene> guard(sc);
     // ---- flatten ----
     const uint32_t nVtx = (uint32_t)vtxBase[d->n_shapes];
-    std::vector<float> vN(3 * (size_t)nVtx, 0.f), vUV(2 * (size_t)nVtx, 0.f), vS(3 * (size_t)nVtx, 0.f);
+    std::vector<float> vUV(2 * (size_t)nVtx, 0.f), vS(3 * (size_t)nVtx, 0.f);
     std::vector<DevShape> shapes(d->n_shapes);
     std::vector<DevSphere> spheres; std::vector<int> sphereOfShape(d->n_shapes, -1);
     for (uint32_t s = 0; s < d->n_shapes; ++s) {
@@ -331,7 +331,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
         if (sh.reverse_orientation) o.flags |= SHAPE_REVERSE;
         if (sh.kind == 0) {
             size_t b = vtxBase[s];
-            if (sh.N) { o.flags |= SHAPE_HAS_N; memcpy(&vN[3 * b], sh.N, 12 * (size_t)sh.n_verts); }
+            if (sh.N) o.flags |= SHAPE_HAS_N;
             if (sh.UV) { o.flags |= SHAPE_HAS_UV; memcpy(&vUV[2 * b], sh.UV, 8 * (size_t)sh.n_verts); }
             if (sh.S) { o.flags |= SHAPE_HAS_S; memcpy(&vS[3 * b], sh.S, 12 * (size_t)sh.n_verts); }
         } else {
@@ -344,6 +344,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     }
     std::vector<float4> tris(3 * (size_t)totalPrims);
     std::vector<uint32_t> primVtx(3 * (size_t)totalPrims, 0u);
+    std::vector<float4> primN(3 * (size_t)totalPrims, make_float4(0.f, 0.f, 0.f, 0.f));
     for (size_t ai = 0; ai < aggs.size(); ++ai) {
         const Agg &g = aggs[ai];
         for (uint32_t oi = 0; oi < g.nPrims; ++oi) {
@@ -363,7 +364,10 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
                                                  sh.UV ? &sh.UV[2 * (size_t)v[2]] : nullptr);
                     uint32_t tag = (bogus ? TAG_BOGUS : 0u) | (d->materials[sh.material].type == 1 ? TAG_PLASTIC : 0u);
                     r0 = make_float4(a[0], a[1], a[2], u2f(tag)); r1 = make_float4(b[0], b[1], b[2], u2f(s)); r2 = make_float4(c[0], c[1], c[2], u2f(0u));
-                    for (int k = 0; k < 3; ++k) primVtx[3 * i + k] = (uint32_t)(vtxBase[s] + (uint32_t)v[k]);
+                    for (int k = 0; k < 3; ++k) {
+                        primVtx[3 * i + k] = (uint32_t)(vtxBase[s] + (uint32_t)v[k]);
+                        if (sh.N) { const float *nn = &sh.N[3 * (size_t)v[k]]; primN[3 * i + k] = make_float4(nn[0], nn[1], nn[2], 0.f); }
+                    }
                 } else {
                     r0 = make_float4(0, 0, 0, u2f(TAG_SPHERE)); r1 = make_float4(0, 0, 0, u2f(s)); r2 = make_float4(0, 0, 0, u2f((uint32_t)sphereOfShape[s]));
                 }
@@ -446,7 +450,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     for (size_t i = 0; i < primes.size(); ++i) magic[i] = 0xffffffffffffffffull / (uint64_t)primes[i] + 1ull;
     // ---- upload ----
     HIP_TRY(upload(sc->nodes, pairs)); HIP_TRY(upload(sc->tris, tris)); HIP_TRY(upload(sc->primVtx, primVtx));
-    HIP_TRY(upload(sc->vN, vN)); HIP_TRY(upload(sc->vUV, vUV)); HIP_TRY(upload(sc->vS, vS));
+    HIP_TRY(upload(sc->primN, primN)); HIP_TRY(upload(sc->vUV, vUV)); HIP_TRY(upload(sc->vS, vS));
     HIP_TRY(upload(sc->shapes, shapes)); HIP_TRY(upload(sc->materials, mats)); HIP_TRY(upload(sc->lights, lights));
     HIP_TRY(upload(sc->spheres, spheres)); HIP_TRY(upload(sc->instances, instances)); HIP_TRY(upload(sc->lightFunc, func)); HIP_TRY(upload(sc->lightCdf, cdf));
     HIP_TRY(upload(sc->perms, perms)); HIP_TRY(upload(sc->primes, primes)); HIP_TRY(upload(sc->primeSums, primeSums));
@@ -458,7 +462,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     dv.pairs = sc->nodes.as<DevPair>(); dv.nPairs = (uint32_t)pairs.size();
     dv.tris = sc->tris.as<float4>(); dv.nPrims = totalPrims;
     dv.primVtx = sc->primVtx.as<uint32_t>();
-    dv.vN = sc->vN.as<float>(); dv.vUV = sc->vUV.as<float>(); dv.vS = sc->vS.as<float>();
+    dv.primN = sc->primN.as<float4>(); dv.vUV = sc->vUV.as<float>(); dv.vS = sc->vS.as<float>();
     dv.shapes = sc->shapes.as<DevShape>(); dv.nShapes = d->n_shapes;
     dv.materials = sc->materials.as<DevMaterial>();
     dv.lights = sc->lights.as<DevLight>(); dv.nLights = d->n_lights;

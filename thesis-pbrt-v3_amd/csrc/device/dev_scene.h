@@ -26,7 +26,10 @@
 //                                    The primitives of all aggregates share this array: the top
 //                                    level first, then each object definition's.
 //   primVtx    uint32[3*nPrims]     global vertex ids of the ordered triangle (shading only)
-//   vN/vUV/vS  float[3|2|3 * nVtx]  shading attributes; a shape's presence bits say which
+//   primN      float4[3*nPrims]     the three shading normals of the ordered triangle, gathered like
+//                                    its positions: one more contiguous read instead of the index ->
+//                                    vertex chase (zeros for meshes without normals)
+//   vUV/vS     float[2|3 * nVtx]    remaining per-vertex shading attributes (rare), reached through primVtx
 //   shapes, materials, lights, spheres, lightCdf: small tables.
 #pragma once
 #include "../hprt_math.h"
@@ -63,7 +66,8 @@ struct DevScene {
     const DevPair *pairs; uint32_t nPairs;
     const float4 *tris; uint32_t nPrims;
     const uint32_t *primVtx;
-    const float *vN, *vUV, *vS;
+    const float4 *primN;                                         // shading normals pre-gathered like the positions: float4[3] per ordered primitive
+    const float *vUV, *vS;
     const DevShape *shapes; uint32_t nShapes;
     const DevMaterial *materials;
     const DevLight *lights; uint32_t nLights;

@@ -159,7 +159,8 @@ __device__ __forceinline__ void fill_triangle(const DevScene &sc, uint32_t prim,
     const int shapeId = (int)__float_as_uint(v1.w);
     const DevShape sh = sc.shapes[shapeId];
     const bool flip = (sh.flags & SHAPE_FLIP) != 0;
-    const uint32_t i0 = sc.primVtx[3 * prim], i1 = sc.primVtx[3 * prim + 1], i2 = sc.primVtx[3 * prim + 2];
+    uint32_t i0 = 0u, i1 = 0u, i2 = 0u;      // vertex ids: only the rare uv / tangent attributes are reached through them
+    if (sh.flags & (SHAPE_HAS_UV | SHAPE_HAS_S)) { i0 = sc.primVtx[3 * prim]; i1 = sc.primVtx[3 * prim + 1]; i2 = sc.primVtx[3 * prim + 2]; }
     float uv0x = 0, uv0y = 0, uv1x = 1, uv1y = 0, uv2x = 1, uv2y = 1;   // triangle.h:114-118
     if (sh.flags & SHAPE_HAS_UV) {
         uv0x = sc.vUV[2 * i0]; uv0y = sc.vUV[2 * i0 + 1]; uv1x = sc.vUV[2 * i1]; uv1y = sc.vUV[2 * i1 + 1];
@@ -192,8 +193,8 @@ __device__ __forceinline__ void fill_triangle(const DevScene &sc, uint32_t prim,
     if (sh.flags & (SHAPE_HAS_N | SHAPE_HAS_S)) {
         vec3 ns;
         if (sh.flags & SHAPE_HAS_N) {
-            vec3 n0(sc.vN[3 * i0], sc.vN[3 * i0 + 1], sc.vN[3 * i0 + 2]), n1(sc.vN[3 * i1], sc.vN[3 * i1 + 1], sc.vN[3 * i1 + 2]),
-                n2(sc.vN[3 * i2], sc.vN[3 * i2 + 1], sc.vN[3 * i2 + 2]);
+            const float4 m0 = sc.primN[3 * prim], m1 = sc.primN[3 * prim + 1], m2 = sc.primN[3 * prim + 2];
+            const vec3 n0(m0.x, m0.y, m0.z), n1(m1.x, m1.y, m1.z), n2(m2.x, m2.y, m2.z);
             ns = (b0 * n0 + b1 * n1 + b2 * n2);
             if (length2(ns) > 0) ns = normalize(ns); else ns = si->n;
         } else ns = si->n;
