@@ -119,14 +119,15 @@ __device__ __forceinline__ void wave_count_add(DevCounters *c, bool anyHit, cons
 // -1), b0, b1} and b2; any hit writes one byte.
 // ---------------------------------------------------------------------------
 // Scheduling knobs of the persistent walk (defaults from a per-ray trace simulation of
-// killeroo-simple bounce rays; overridable through HPRT_TRACE_TUNE="R,P,K,S").
+// killeroo-simple bounce rays; overridable through HPRT_TRACE_TUNE / HPRT_TRACE_TUNE_ANY =
+// "refillBelow,parkLimit,stepLimit,sphereLimit,primMin").
 struct TraceTune { int refillBelow, parkLimit, stepLimit, sphereLimit, primMin; };
-static TraceTune DefaultTraceTune() {
-    TraceTune t = {52, 24, 6, 16, 8};
-    if (const char *e = getenv("HPRT_TRACE_TUNE")) {
-        int r, p, k, q = t.sphereLimit, m = t.primMin;
-        if (sscanf(e, "%d,%d,%d,%d,%d", &r, &p, &k, &q, &m) >= 3) { t.refillBelow = r; t.parkLimit = p; t.stepLimit = k; t.sphereLimit = q; t.primMin = m; }
-    }
+static TraceTune DefaultTraceTune(bool anyHit) {
+    // closest-hit and any-hit rays want different schedules: shadow rays mostly cross the scene unoccluded, with
+    // few primitive tests each, so their tests should not wait for company (full-frame sweeps, tools/sweep_bench.sh)
+    TraceTune t = anyHit ? TraceTune{52, 24, 10, 16, 3} : TraceTune{52, 24, 6, 16, 8};
+    if (const char *e = getenv(anyHit ? "HPRT_TRACE_TUNE_ANY" : "HPRT_TRACE_TUNE"))
+        sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin);
     return t;
 }
 
@@ -908,7 +909,8 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     const uint32_t nWaves = grid.x * (HPRT_TRACE_BLOCK / 64);
     uint32_t chunk = gridItems / (nWaves * 4u);
     chunk = std::max(64u, std::min(512u, chunk)) & ~63u;
-    static const TraceTune tune = DefaultTraceTune();
+    static const TraceTune tuneClosest = DefaultTraceTune(false), tuneAny = DefaultTraceTune(true);
+    const TraceTune tune = anyHit ? tuneAny : tuneClosest;
     static const bool profile = getenv("HPRT_TRACE_PROFILE") != nullptr;
     const bool inst = sc.nInstances != 0u;
 #define HPRT_TRACE_LAUNCH(A, M, I) hipLaunchKernelGGL((k_trace<A, M, I>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, rayStats, workCounter, chunk, tune)
