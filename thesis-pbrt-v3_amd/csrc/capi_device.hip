@@ -480,7 +480,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
         bool inside = c.x >= lo.x && c.x <= hi.x && c.y >= lo.y && c.y <= hi.y && c.z >= lo.z && c.z <= hi.z;
         dv.worldRadius = inside ? dist(c, hi) : 0.f;
     }
-    HIP_TRY(hipHostMalloc((void **)&sc->hostCounts, 64 * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void **)&sc->hostCounts, (4096 + 256) * sizeof(uint32_t)));
     *out = guard.release();
     return HPRT_OK;
 }
@@ -690,16 +690,16 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         HIP_TRY(hipEventRecord(e1, st));
         evExt.push_back({e0, e1}); bt->extendRays += active; ++bt->extendLaunches;
         stats->rays += active;
-        HIP_TRY(hipMemsetAsync(cur.nextCount, 0, 4 * sizeof(uint32_t), st));   // the four counters are contiguous
+        HIP_TRY(hipMemsetAsync(cur.nextCount, 0, 256 * sizeof(uint32_t), st));   // the four counters, 64 words apart
         HIP_TRY(hipMemsetAsync(bins.count, 0, 4 * sizeof(uint32_t), st));
         LaunchBin(st, s->dev, in, w.hit, activeQ, nullptr, active, active, rp.maxDepth, bounce, bins, w.Lfinal);
         HIP_TRY(hipMemcpyAsync(bins.count + 3, bins.count + 2, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));   // bin 2 before deferrals
         // one launch per material bin; grids are sized for the upper bound, surplus blocks exit on the bin's count
         for (int mode = 0; mode < 3; ++mode)
             LaunchShade(st, mode, s->dev, rp, in, w.hit, active, s0, out, w.vs, cur, bins, w.Lfinal);
-        HIP_TRY(hipMemcpyAsync(s->hostCounts, cur.nextCount, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(s->hostCounts + 4096, cur.nextCount, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        const uint32_t nNext = s->hostCounts[0], nShadow = s->hostCounts[1], nMis = s->hostCounts[2], nResolve = s->hostCounts[3];
+        const uint32_t nNext = s->hostCounts[4096], nShadow = s->hostCounts[4096 + 64], nMis = s->hostCounts[4096 + 128], nResolve = s->hostCounts[4096 + 192];
         if (nShadow) {
             hipEvent_t a = ev.get(), b = ev.get();
             HIP_TRY(hipEventRecord(a, st));
@@ -735,17 +735,18 @@ int EnsureWorkspace(HprtScene *s, size_t nSlots, Workspace *ps, QueueSet *qa, Qu
     HIP_TRY(s->planes.alloc(PlaneBytes(nSlots)));
     CarvePlanes(s->planes.as<char>(), nSlots, ps);
     HIP_TRY(s->queues.alloc(12 * nSlots * sizeof(uint32_t) + 4096));
-    HIP_TRY(s->queueCounts.alloc(64 * sizeof(uint32_t)));
+    HIP_TRY(s->queueCounts.alloc(1024 * sizeof(uint32_t)));
     uint32_t *qbase = s->queues.as<uint32_t>(), *cbase = s->queueCounts.as<uint32_t>();
     QueueSet *qs[2] = {qa, qb};
     for (int k = 0; k < 2; ++k) {
         qs[k]->next = qbase + (4 * k + 0) * nSlots; qs[k]->shadow = qbase + (4 * k + 1) * nSlots;
         qs[k]->mis = qbase + (4 * k + 2) * nSlots; qs[k]->resolve = qbase + (4 * k + 3) * nSlots;
-        qs[k]->nextCount = cbase + 16 * k; qs[k]->shadowCount = cbase + 16 * k + 1; qs[k]->misCount = cbase + 16 * k + 2; qs[k]->resolveCount = cbase + 16 * k + 3;
+        // one counter per 256-byte line: atomics of different queues do not serialise on a shared line
+        qs[k]->nextCount = cbase + 256 * k; qs[k]->shadowCount = cbase + 256 * k + 64; qs[k]->misCount = cbase + 256 * k + 128; qs[k]->resolveCount = cbase + 256 * k + 192;
     }
     for (int k = 0; k < 3; ++k) bins->q[k] = qbase + (8 + k) * nSlots;
     bins->aux = qbase + 11 * nSlots;
-    bins->count = cbase + 32;
+    bins->count = cbase + 512;
     return HPRT_OK;
 }
 
