@@ -63,14 +63,18 @@ typedef struct HprtRenderOptions {
  * scripts/render_simple.sh:23-29 does with sed) and, for keys that end in '/',
  * path prefixes of Include/plymesh file names. */
 int hprt_model_parse(const char *pbrt_path, const char *const *subst, int n_subst, HprtModel **out);
+/* Image textures of a parsed model (built MIPMaps): count[0] = textures; info = {levels, trilinear, wrap, width
+ * and height of level 0}; hprt_model_texture_level copies 3*w*h floats of one level (rgb may be NULL to query w,h). */
+int hprt_model_texture_info(const HprtModel *m, uint32_t texture, int32_t info[5], float *max_anisotropy);
+int hprt_model_texture_level(const HprtModel *m, uint32_t texture, uint32_t level, int32_t wh[2], float *rgb);
 /* Baked scene container (post-parse, world-space; DESIGN.md "Baked scene"). */
 int hprt_model_load(const char *baked_path, HprtModel **out);
 int hprt_model_save(const HprtModel *m, const char *baked_path);
 void hprt_model_destroy(HprtModel *m);
 int hprt_model_get_options(const HprtModel *m, HprtRenderOptions *out);
 int hprt_model_set_options(HprtModel *m, const HprtRenderOptions *in);
-/* counts[0..5] = shapes, primitives, triangles, spheres, materials, lights */
-int hprt_model_counts(const HprtModel *m, uint64_t counts[6]);
+/* counts[0..6] = shapes, primitives, triangles, spheres, materials, lights, image textures */
+int hprt_model_counts(const HprtModel *m, uint64_t counts[7]);
 /* Front-end warnings (out-of-scope features that were substituted), '\n' separated. */
 const char *hprt_model_warnings(const HprtModel *m);
 
@@ -125,7 +129,21 @@ typedef struct HprtMaterialDesc {    /* materials/matte.cpp:64-72, materials/pla
     int32_t type;                    /* 0 matte, 1 plastic */
     float Kd[3], sigma, Ks[3], roughness;
     int32_t remap_roughness;
+    int32_t kd_texture, ks_texture;  /* index into HprtSceneDesc::textures when Kd / Ks is an image texture, else -1 */
 } HprtMaterialDesc;
+
+/* ImageTexture<RGBSpectrum, Spectrum> (textures/imagemap.h:71-122) with its built MIPMap (core/mipmap.h):
+ * level 0 is the power-of-two image after ImageTexture::GetTexture's conversion (scale, inverse gamma, y flip:
+ * (0,0) is the lower left texel), level k the 2x2 box filter of level k-1; rgb holds 3*w*h floats per level. */
+typedef struct HprtTextureLevel { int32_t w, h; const float *rgb; } HprtTextureLevel;
+typedef struct HprtTextureDesc {
+    const HprtTextureLevel *levels; uint32_t n_levels;
+    int32_t trilinear;               /* "trilinear" (default false: EWA, core/mipmap.h:262-290) */
+    float max_anisotropy;            /* "maxanisotropy", 8 */
+    int32_t wrap;                    /* 0 repeat, 1 black, 2 clamp */
+    float su, sv, du, dv;            /* UVMapping2D (core/texture.cpp:93-99) */
+    const float *weight_lut;         /* MIPMap::weightLut, 128 floats */
+} HprtTextureDesc;
 
 typedef struct HprtLightDesc {       /* lights/point.cpp, lights/distant.cpp, lights/diffuse.cpp */
     int32_t type;                    /* 0 point, 1 distant, 2 diffuse area */
@@ -163,6 +181,7 @@ typedef struct HprtSceneDesc {
     const HprtMaterialDesc *materials; uint32_t n_materials;
     const HprtLightDesc *lights; uint32_t n_lights;
     int32_t light_strategy;
+    const HprtTextureDesc *textures; uint32_t n_textures;
     /* instancing; all NULL / 0 without it.  top == NULL: every shape, in order, is top-level */
     const HprtObjectDesc *objects; uint32_t n_objects;
     const HprtInstanceDesc *instances; uint32_t n_instances;

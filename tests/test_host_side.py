@@ -131,7 +131,7 @@ WorldEnd
 """
     m = _parse_text(hprt, tmp_path, text)
     c = m.counts()
-    assert c == {"shapes": 2, "primitives": 3, "triangles": 2, "spheres": 1, "materials": 2, "lights": 2}
+    assert c == {"shapes": 2, "primitives": 3, "triangles": 2, "spheres": 1, "materials": 2, "lights": 2, "textures": 0}
     o = m.options
     assert (o.xres, o.yres, o.spp, o.max_depth) == (700, 700, 8, 5)
     assert abs(o.fov - 39.0) < 1e-6 and o.max_node_prims == 4 and o.isect_cost == 8 and o.trav_cost == 1
@@ -277,3 +277,105 @@ def test_pixel_stats_text_matrices(hprt, tmp_path):
     names = sorted(p.name for p in tmp_path.iterdir())
     assert names == sorted("img-%s.txt" % n for n in ("primitiveIntersections", "primitiveIntersectionsP", "kdTreeNodeTraversals", "kdTreeNodeTraversalsP",
                                                     "bspTreeNodeTraversals", "bspTreeNodeTraversalsP", "leafNodeTraversals", "leafNodeTraversalsP"))
+
+
+# ---- image textures (host side): readers and the MIPMap constructor ----
+def _write_tga(path, img8, rle=False, top_to_bottom=False):
+    """img8: uint8 [h, w, 3] RGB, row 0 = top of the picture"""
+    h, w, _ = img8.shape
+    rows = img8 if top_to_bottom else img8[::-1]
+    bgr = rows[..., ::-1].reshape(-1, 3)
+    hdr = bytes([0, 0, 10 if rle else 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, w & 255, w >> 8, h & 255, h >> 8, 24, 0x20 if top_to_bottom else 0])
+    if not rle:
+        body = bgr.tobytes()
+    else:   # one raw packet of up to 128 pixels after one run packet per row start (exercises both packet kinds)
+        body = b""
+        i = 0
+        while i < len(bgr):
+            n = min(128, len(bgr) - i)
+            if n >= 2 and (bgr[i] == bgr[i + 1]).all():
+                body += bytes([0x80 | 1]) + bgr[i].tobytes(); i += 2
+            else:
+                body += bytes([n - 1]) + bgr[i:i + n].tobytes(); i += n
+    open(path, "wb").write(hdr + body)
+
+
+def _write_png(path, img8):
+    import struct, zlib
+    h, w, c = img8.shape
+    raw = b"".join(b"\x00" + img8[y].tobytes() for y in range(h))
+    def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0)) +
+                           chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def _write_pfm(path, img, little=True):
+    h, w, _ = img.shape
+    data = img[::-1].astype("<f4" if little else ">f4").tobytes()
+    open(path, "wb").write(b"PF\n%d %d\n%s\n" % (w, h, b"-1.0" if little else b"1.0") + data)
+
+
+def _inverse_gamma(v):
+    v = np.asarray(v, np.float32)
+    return np.where(v <= np.float32(0.04045), v * np.float32(1) / np.float32(12.92),
+                    np.power((v + np.float32(0.055)) * np.float32(1) / np.float32(1.055), np.float32(2.4))).astype(np.float32)
+
+
+TEX_SCENE = HEADER + 'Texture "img" "spectrum" "imagemap" "string filename" "%s" %s\nMaterial "matte" "texture Kd" "img"\n' \
+    'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [0 0 0 1 0 0 1 1 0 0 1 0] "float uv" [0 0 1 0 1 1 0 1]\nWorldEnd\n'
+
+
+def test_image_texture_readers_and_mipmap(hprt, tmp_path):
+    """ReadImage (.tga raw / RLE / top-to-bottom, .png RGB / RGBA, .pfm both endiannesses) and MIPMap::MIPMap
+    (core/mipmap.h:113-201): level 0 of a power-of-two image is the converted input with (0,0) at the lower left,
+    every further level is the exact 2x2 box filter of the previous one (0.25f * (a + b + c + d) in float)."""
+    rng = np.random.default_rng(4)
+    img8 = rng.integers(0, 256, (16, 32, 3), dtype=np.uint8)
+    want0 = _inverse_gamma(img8[::-1].astype(np.float32) / np.float32(255))          # y flip + InverseGammaCorrect (8-bit formats)
+    variants = {"a.tga": lambda p: _write_tga(p, img8), "b.tga": lambda p: _write_tga(p, img8, rle=True),
+                "c.tga": lambda p: _write_tga(p, img8, top_to_bottom=True), "d.png": lambda p: _write_png(p, img8),
+                "e.png": lambda p: _write_png(p, np.concatenate([img8, np.full((16, 32, 1), 200, np.uint8)], axis=2))}
+    for name, write in variants.items():
+        write(str(tmp_path / name))
+        m = _parse_text(hprt, tmp_path, TEX_SCENE % (str(tmp_path / name), ""), name=name + ".pbrt")
+        assert m.warnings() == [] and m.counts()["textures"] == 1
+        info, levels = m.texture(0)
+        assert info == {"levels": 6, "trilinear": False, "wrap": 0, "max_anisotropy": 8.0}
+        assert np.abs(levels[0] - want0).max() <= 1e-7, name        # powf of the host libm against numpy's: last-bit differences only
+        for k in range(1, 6):
+            a = levels[k - 1]
+            s = np.float32(0.25) * (((a[0::2, 0::2] + a[0::2, 1::2]) + a[1::2, 0::2]) + a[1::2, 1::2]) if a.shape[0] > 1 else \
+                np.float32(0.25) * (((a[:, 0::2] + a[:, 1::2]) + a[:, 0::2]) + a[:, 1::2])
+            assert levels[k].shape == (max(1, a.shape[0] // 2), max(1, a.shape[1] // 2), 3) and np.array_equal(levels[k], s), (name, k)
+    # PFM: linear floats (no gamma), both byte orders; "scale" and "trilinear" / "wrap" / "maxanisotropy" parameters
+    imgf = rng.random((8, 8, 3)).astype(np.float32)
+    for little in (True, False):
+        _write_pfm(str(tmp_path / "f.pfm"), imgf, little)
+        m = _parse_text(hprt, tmp_path, TEX_SCENE % (str(tmp_path / "f.pfm"), '"float scale" [2] "bool trilinear" ["true"] "string wrap" "clamp" "float maxanisotropy" [4]'), name="f.pbrt")
+        info, levels = m.texture(0)
+        assert info == {"levels": 4, "trilinear": True, "wrap": 2, "max_anisotropy": 4.0}
+        assert np.array_equal(levels[0], np.float32(2) * imgf[::-1])
+    # a missing file becomes the constant grey texture, with a warning (textures/imagemap.cpp:66-72)
+    m = _parse_text(hprt, tmp_path, TEX_SCENE % (str(tmp_path / "nope.png"), ""), name="n.pbrt")
+    assert len(m.warnings()) == 1 and "grey" in m.warnings()[0]
+    assert np.abs(m.texture(0)[1][0] - _inverse_gamma(np.full((1, 1, 3), 0.5, np.float32))).max() <= 1e-7
+
+
+def test_image_texture_resampling_and_bake(hprt, tmp_path):
+    """Images that are not a power of two are resampled with the Lanczos weights of MIPMap::resampleWeights: a constant
+    image stays constant (weights are normalised), sizes round up; the baked container (version 3) carries the pyramid."""
+    img8 = np.full((5, 12, 3), 128, np.uint8)
+    _write_png(str(tmp_path / "c.png"), img8)
+    m = _parse_text(hprt, tmp_path, TEX_SCENE % (str(tmp_path / "c.png"), ""), name="c.pbrt")
+    info, levels = m.texture(0)
+    assert levels[0].shape == (8, 16, 3) and info["levels"] == 5
+    c = _inverse_gamma(np.float32(128) / np.float32(255))
+    assert np.abs(levels[0] - c).max() < 2e-6
+    baked = str(tmp_path / "t.hprt"); m.save(baked)
+    assert open(baked, "rb").read()[8:12] == (3).to_bytes(4, "little")
+    m2 = hprt.Model.load(baked)
+    assert m2.counts() == m.counts()
+    for a, b in zip(m.texture(0)[1], m2.texture(0)[1]):
+        assert np.array_equal(a, b)
+    again = str(tmp_path / "t2.hprt"); m2.save(again)
+    assert open(baked, "rb").read() == open(again, "rb").read()

@@ -92,6 +92,8 @@ def _load():
         "hprt_model_set_options": (C.c_int, [vp, P(RenderOptions)]),
         "hprt_model_counts": (C.c_int, [vp, P(u64)]),
         "hprt_model_warnings": (cp, [vp]),
+        "hprt_model_texture_info": (C.c_int, [vp, C.c_uint32, P(C.c_int32), P(C.c_float)]),
+        "hprt_model_texture_level": (C.c_int, [vp, C.c_uint32, C.c_uint32, P(C.c_int32), vp]),
         "hprt_bvh_build": (C.c_int, [vp, P(vp)]),
         "hprt_bvh_build_from_bounds": (C.c_int, [sz, vp, vp, C.c_int, C.c_int, C.c_int, P(vp)]),
         "hprt_bvh_destroy": (None, [vp]),
@@ -175,9 +177,22 @@ class Model:
         _check(lib.hprt_model_set_options(self._h, C.byref(o)))
 
     def counts(self):
-        c = (C.c_uint64 * 6)()
+        c = (C.c_uint64 * 7)()
         _check(lib.hprt_model_counts(self._h, c))
-        return dict(zip(("shapes", "primitives", "triangles", "spheres", "materials", "lights"), [int(x) for x in c]))
+        return dict(zip(("shapes", "primitives", "triangles", "spheres", "materials", "lights", "textures"), [int(x) for x in c]))
+
+    def texture(self, index):
+        """Built MIPMap of image texture `index`: (info dict, [level arrays of shape (h, w, 3)], level 0 first, row 0 = t 0)."""
+        info = (C.c_int32 * 5)(); ma = C.c_float()
+        _check(lib.hprt_model_texture_info(self._h, index, info, C.byref(ma)))
+        levels = []
+        for k in range(info[0]):
+            wh = (C.c_int32 * 2)()
+            _check(lib.hprt_model_texture_level(self._h, index, k, wh, None))
+            a = np.zeros((wh[1], wh[0], 3), np.float32)
+            _check(lib.hprt_model_texture_level(self._h, index, k, wh, _ptr(a)))
+            levels.append(a)
+        return {"levels": info[0], "trilinear": bool(info[1]), "wrap": info[2], "max_anisotropy": ma.value}, levels
 
     def warnings(self):
         w = lib.hprt_model_warnings(self._h).decode()

@@ -380,6 +380,8 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
         const HprtMaterialDesc &in = d->materials[m];
         if (in.type != 0 && in.type != 1) return SetError(HPRT_E_UNSUPPORTED, "material type outside the hot-path scope (matte, plastic)");
         if (in.type == 0 && in.sigma != 0.f) return SetError(HPRT_E_UNSUPPORTED, "matte sigma != 0 (OrenNayar) is outside the hot-path scope");
+        if (in.kd_texture >= (int32_t)d->n_textures || in.ks_texture >= (int32_t)d->n_textures) return SetError(HPRT_E_INVALID, "material texture index out of range");
+        if (in.kd_texture >= 0 || in.ks_texture >= 0) return SetError(HPRT_E_UNSUPPORTED, "image textures are parsed and baked, the device lookup is not built yet");
         DevMaterial &o = mats[m];
         o.type = in.type; memcpy(o.Kd, in.Kd, 12); memcpy(o.Ks, in.Ks, 12);
         o.alpha = in.remap_roughness ? RoughnessToAlpha(in.roughness) : in.roughness;
@@ -512,6 +514,16 @@ int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int devic
         const MaterialDesc &s = sm.materials[i];
         mats[i].type = s.type; memcpy(mats[i].Kd, s.Kd, 12); mats[i].sigma = s.sigma; memcpy(mats[i].Ks, s.Ks, 12);
         mats[i].roughness = s.roughness; mats[i].remap_roughness = s.remapRoughness;
+        mats[i].kd_texture = s.KdTex; mats[i].ks_texture = s.KsTex;
+    }
+    std::vector<std::vector<HprtTextureLevel>> texLevels(sm.textures.size());
+    std::vector<HprtTextureDesc> textures(sm.textures.size());
+    for (size_t i = 0; i < textures.size(); ++i) {
+        const TextureDesc &t = sm.textures[i];
+        for (const MipLevel &l : t.levels) texLevels[i].push_back(HprtTextureLevel{l.w, l.h, l.rgb.data()});
+        textures[i].levels = texLevels[i].data(); textures[i].n_levels = (uint32_t)texLevels[i].size();
+        textures[i].trilinear = t.trilinear; textures[i].max_anisotropy = t.maxAniso; textures[i].wrap = t.wrap;
+        textures[i].su = t.su; textures[i].sv = t.sv; textures[i].du = t.du; textures[i].dv = t.dv; textures[i].weight_lut = t.weightLut;
     }
     std::vector<HprtLightDesc> lights(sm.lights.size());
     for (size_t i = 0; i < lights.size(); ++i) {
@@ -540,6 +552,7 @@ int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int devic
     for (size_t i = 0; i < top.size(); ++i) { top[i].kind = sm.top[i].kind; top[i].index = sm.top[i].index; }
     HprtSceneDesc d;
     memset(&d, 0, sizeof(d));
+    d.textures = textures.data(); d.n_textures = (uint32_t)textures.size();
     d.objects = objects.data(); d.n_objects = (uint32_t)objects.size();
     d.instances = instances.data(); d.n_instances = (uint32_t)instances.size();
     static const HprtTopItem kNoItems[1] = {{0, 0u}};

@@ -84,12 +84,27 @@ int hprt_model_set_options(HprtModel *m, const HprtRenderOptions *o) {
     p.maxNodePrims = o->max_node_prims; p.isectCost = o->isect_cost; p.travCost = o->trav_cost;
     return HPRT_OK;
 }
-int hprt_model_counts(const HprtModel *m, uint64_t c[6]) {
+int hprt_model_counts(const HprtModel *m, uint64_t c[7]) {
     if (!m || !c) return SetError(HPRT_E_INVALID, "hprt_model_counts: null argument");
     uint64_t tris = 0, spheres = 0;
     for (const ShapeDesc &s : m->sc.shapes) { if (s.kind == kTriangleMesh) tris += s.mesh.nTris(); else ++spheres; }
     c[0] = m->sc.shapes.size(); c[1] = tris + spheres; c[2] = tris; c[3] = spheres;
-    c[4] = m->sc.materials.size(); c[5] = m->sc.lights.size();
+    c[4] = m->sc.materials.size(); c[5] = m->sc.lights.size(); c[6] = m->sc.textures.size();
+    return HPRT_OK;
+}
+int hprt_model_texture_info(const HprtModel *m, uint32_t texture, int32_t info[5], float *max_anisotropy) {
+    if (!m || !info || texture >= m->sc.textures.size()) return SetError(HPRT_E_INVALID, "hprt_model_texture_info: bad argument");
+    const TextureDesc &t = m->sc.textures[texture];
+    info[0] = (int32_t)t.levels.size(); info[1] = t.trilinear; info[2] = t.wrap; info[3] = t.levels[0].w; info[4] = t.levels[0].h;
+    if (max_anisotropy) *max_anisotropy = t.maxAniso;
+    return HPRT_OK;
+}
+int hprt_model_texture_level(const HprtModel *m, uint32_t texture, uint32_t level, int32_t wh[2], float *rgb) {
+    if (!m || !wh || texture >= m->sc.textures.size() || level >= m->sc.textures[texture].levels.size())
+        return SetError(HPRT_E_INVALID, "hprt_model_texture_level: bad argument");
+    const MipLevel &l = m->sc.textures[texture].levels[level];
+    wh[0] = l.w; wh[1] = l.h;
+    if (rgb) memcpy(rgb, l.rgb.data(), 4 * l.rgb.size());
     return HPRT_OK;
 }
 const char *hprt_model_warnings(const HprtModel *m) {

@@ -6,6 +6,8 @@
 // to the accelerator (core/api.cpp:1883-1892).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <strings.h>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -81,7 +83,7 @@ struct Tokenizer {
     }
 };
 
-struct TexConst { bool isFloat; float v[3]; };
+struct TexConst { bool isFloat; float v[3]; int image = -1; };   // image >= 0: SceneModel::textures index (spectrum imagemap)
 
 struct GraphicsState {
     std::string materialName = "matte";
@@ -101,6 +103,7 @@ struct Frontend {
     std::map<std::string, Xform> namedCS;
     std::vector<GraphicsState> gsStack; GraphicsState gs;
     std::vector<Xform> xfStack;
+    std::map<std::string, int> imageCache;         // ImageTexture::textures (textures/imagemap.h:119)
     int currentObject = -1;                        // renderOptions->currentInstance
     std::map<std::string, int> objectByName;       // renderOptions->instances
     std::map<std::string, std::pair<std::string, ParamList>> namedMaterials;
@@ -204,13 +207,15 @@ struct Frontend {
     }
 
     // ---- materials (core/api.cpp MakeMaterial + TextureParams lookups) -----
-    bool spectrumParam(const ParamList &geom, const ParamList &mat, const std::string &name, const float def[3], float out[3]) {
+    bool spectrumParam(const ParamList &geom, const ParamList &mat, const std::string &name, const float def[3], float out[3], int32_t *image = nullptr) {
         // TextureParams::GetSpectrumTexture: geometry params first, then material params
+        if (image) *image = -1;
         for (const ParamList *pl : {&geom, &mat}) {
             std::string tex = pl->texture(name);
             if (!tex.empty()) {
                 auto it = gs.textures.find(tex);
-                if (it != gs.textures.end() && !it->second.isFloat) { memcpy(out, it->second.v, 12); return true; }
+                if (it != gs.textures.end() && !it->second.isFloat && it->second.image >= 0 && image) { *image = it->second.image; memcpy(out, def, 12); return true; }
+                if (it != gs.textures.end() && !it->second.isFloat && it->second.image < 0) { memcpy(out, it->second.v, 12); return true; }
                 warn("texture \"" + tex + "\" for \"" + name + "\" is not a constant spectrum texture; using the default");
                 memcpy(out, def, 12); return true;
             }
@@ -242,11 +247,12 @@ struct Frontend {
         }
         MaterialDesc m;
         memset(&m, 0, sizeof(m));
+        m.KdTex = m.KsTex = -1;
         if (name == "plastic") {
             const float dk[3] = {0.25f, 0.25f, 0.25f};
             m.type = kPlastic;
-            spectrumParam(geom, *mp, "Kd", dk, m.Kd);
-            spectrumParam(geom, *mp, "Ks", dk, m.Ks);
+            spectrumParam(geom, *mp, "Kd", dk, m.Kd, &m.KdTex);
+            spectrumParam(geom, *mp, "Ks", dk, m.Ks, &m.KsTex);
             m.roughness = floatParam(geom, *mp, "roughness", .1f);
             bool remap = true;
             const Param *rp = geom.find("remaproughness", "bool"); if (!rp) rp = mp->find("remaproughness", "bool");
@@ -257,7 +263,7 @@ struct Frontend {
                 warn("material \"" + name + "\" is outside the hot-path scope; rendered as matte (SURVEY.md §2)");
             const float dk[3] = {0.5f, 0.5f, 0.5f};
             m.type = kMatte;
-            spectrumParam(geom, *mp, "Kd", dk, m.Kd);
+            spectrumParam(geom, *mp, "Kd", dk, m.Kd, &m.KdTex);
             m.sigma = floatParam(geom, *mp, "sigma", 0.f);
             if (m.sigma != 0.f) warn("matte sigma != 0 (OrenNayar) is outside the hot-path scope; sigma forced to 0");
             m.sigma = 0.f;
@@ -543,7 +549,43 @@ struct Frontend {
                     if (tc.isFloat) tc.v[0] = tc.v[1] = tc.v[2] = pl.oneFloat("value", 1.f);
                     else pl.rgb3("value", tc.v);
                     gs.textures[name] = tc;
-                } else warn("texture class \"" + tclass + "\" is outside the hot-path scope (constant only)");
+                } else if (tclass == "imagemap" && (ttype == "spectrum" || ttype == "color")) {
+                    // CreateImageSpectrumTexture, textures/imagemap.cpp:140-186
+                    const std::string mapping = pl.oneString("mapping", "uv");
+                    if (mapping != "uv") { warn("2D texture mapping \"" + mapping + "\" is outside the hot-path scope (uv only)"); continue; }
+                    const std::string fn = pl.oneString("filename", "");
+                    TextureDesc td;
+                    td.su = pl.oneFloat("uscale", 1.f); td.sv = pl.oneFloat("vscale", 1.f);
+                    td.du = pl.oneFloat("udelta", 0.f); td.dv = pl.oneFloat("vdelta", 0.f);
+                    td.maxAniso = pl.oneFloat("maxanisotropy", 8.f);
+                    td.trilinear = pl.oneBool("trilinear", false) ? 1 : 0;
+                    const std::string wrap = pl.oneString("wrap", "repeat");
+                    td.wrap = wrap == "black" ? kWrapBlack : wrap == "clamp" ? kWrapClamp : kWrapRepeat;
+                    const float scale = pl.oneFloat("scale", 1.f);
+                    auto ext = [&](const char *e) { size_t n = strlen(e); return fn.size() >= n && strcasecmp(fn.c_str() + fn.size() - n, e) == 0; };
+                    const bool gamma = pl.oneBool("gamma", ext(".tga") || ext(".png"));
+                    // the texture cache of ImageTexture::GetTexture: same file and parameters, same MIPMap
+                    char keyBuf[512];
+                    snprintf(keyBuf, sizeof(keyBuf), "|%d|%a|%d|%a|%d|%a|%a|%a|%a", td.trilinear, td.maxAniso, td.wrap, scale, gamma ? 1 : 0, td.su, td.sv, td.du, td.dv);
+                    const std::string key = resolve(fn) + keyBuf;
+                    int id;
+                    auto hit = imageCache.find(key);
+                    if (hit != imageCache.end()) id = hit->second;
+                    else {
+                        int w = 0, h = 0; std::vector<float> rgb; std::string e;
+                        if (!ReadImageFile(resolve(fn), &w, &h, &rgb, &e)) {
+                            // "Creating a constant grey texture to replace ..." (imagemap.cpp:66-72)
+                            warn(e + "; a constant grey texture replaces it");
+                            w = h = 1; rgb.assign(3, 0.5f);
+                        }
+                        BuildMipMap(w, h, rgb, scale, gamma, &td);
+                        id = (int)sc->textures.size();
+                        sc->textures.push_back(std::move(td));
+                        imageCache[key] = id;
+                    }
+                    TexConst tc; tc.isFloat = false; tc.v[0] = tc.v[1] = tc.v[2] = 0.f; tc.image = id;
+                    gs.textures[name] = tc;
+                } else warn("texture class \"" + tclass + "\" is outside the hot-path scope (constant, spectrum imagemap)");
             } else if (tok == "AreaLightSource") { if (!readQuoted(&gs.areaLight) || !readParams(&gs.areaLightParams)) return false; }
             else if (tok == "LightSource") { if (!readQuoted(&name) || !readParams(&pl) || !doLight(name, pl)) return false; }
             else if (tok == "Shape") { if (!readQuoted(&name) || !readParams(&pl) || !doShape(name, pl)) return false; }

@@ -36,7 +36,9 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
     // version 1: every shape is a top-level primitive source.  Version 2 appends the instancing
     // section (objects, instances, top-level creation order) and is written only when needed.
     const bool instancing = sc.nObjects > 0 || !sc.instances.empty();
-    o.raw("HPRTSCN1", 8); o.u32(instancing ? 2u : 1u);
+    // version 3 = version 2's layout (instancing section always present) followed by the image textures
+    const bool textured = !sc.textures.empty();
+    o.raw("HPRTSCN1", 8); o.u32(textured ? 3u : instancing ? 2u : 1u);
     o.i32(p.xres); o.i32(p.yres);
     o.raw(p.crop, 16);
     o.raw(p.filterRadius, 8); o.i32(p.filterType);
@@ -70,13 +72,23 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
         }
     }
     for (const LightDesc &l : sc.lights) { o.i32(l.type); o.raw(l.pos, 12); o.raw(l.I, 12); o.i32(l.shape); o.i32(l.twoSided); }
-    if (instancing) {
+    if (instancing || textured) {
         o.u32(sc.nObjects);
         for (const ShapeDesc &s : sc.shapes) o.i32(s.object);
         o.u32((uint32_t)sc.instances.size());
         for (const InstanceDesc &in : sc.instances) { o.i32(in.object); o.raw(in.instanceToWorld.m, 64); o.raw(in.worldToInstance.m, 64); }
         o.u32((uint32_t)sc.top.size());
         for (const TopItem &t : sc.top) { o.i32(t.kind); o.u32(t.index); }
+    }
+    if (textured) {
+        for (const MaterialDesc &m : sc.materials) { o.i32(m.KdTex); o.i32(m.KsTex); }
+        o.u32((uint32_t)sc.textures.size());
+        for (const TextureDesc &t : sc.textures) {
+            o.i32(t.trilinear); o.f32(t.maxAniso); o.i32(t.wrap); o.f32(t.su); o.f32(t.sv); o.f32(t.du); o.f32(t.dv);
+            o.raw(t.weightLut, sizeof(t.weightLut));
+            o.u32((uint32_t)t.levels.size());
+            for (const MipLevel &l : t.levels) { o.i32(l.w); o.i32(l.h); o.raw(l.rgb.data(), 4 * l.rgb.size()); }
+        }
     }
     bool ok = o.ok;
     if (fclose(fp) != 0) ok = false;
@@ -92,7 +104,7 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
     char magic[8]; in.raw(magic, 8);
     if (!in.ok || memcmp(magic, "HPRTSCN1", 8) != 0) return fail("not a baked hprt scene");
     const uint32_t version = in.u32();
-    if (version != 1 && version != 2) return fail("unsupported version");
+    if (version < 1 || version > 3) return fail("unsupported version");
     RenderOptions &p = sc->opt;
     p.xres = in.i32(); p.yres = in.i32();
     in.raw(p.crop, 16);
@@ -137,7 +149,7 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
         if (l.type == kDiffuseAreaLight && (l.shape < 0 || (uint32_t)l.shape >= nShapes)) return fail("area light shape out of range");
     }
     sc->nObjects = 0; sc->instances.clear(); sc->top.clear();
-    if (version == 2) {
+    if (version >= 2) {
         sc->nObjects = in.u32();
         for (ShapeDesc &s : sc->shapes) { s.object = in.i32(); if (s.object < -1 || s.object >= (int32_t)sc->nObjects) return fail("object index out of range"); }
         const uint32_t nInst = in.u32();
@@ -156,6 +168,28 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
         }
     } else {
         for (uint32_t i = 0; i < nShapes; ++i) { sc->shapes[i].object = -1; sc->top.push_back(TopItem{0, i}); }
+    }
+    sc->textures.clear();
+    for (MaterialDesc &m : sc->materials) m.KdTex = m.KsTex = -1;
+    if (version >= 3) {
+        for (MaterialDesc &m : sc->materials) { m.KdTex = in.i32(); m.KsTex = in.i32(); }
+        const uint32_t nTex = in.u32();
+        if (!in.ok || nTex > (1u << 20)) return fail("corrupt texture count");
+        sc->textures.resize(nTex);
+        for (TextureDesc &t : sc->textures) {
+            t.trilinear = in.i32(); t.maxAniso = in.f32(); t.wrap = in.i32(); t.su = in.f32(); t.sv = in.f32(); t.du = in.f32(); t.dv = in.f32();
+            in.raw(t.weightLut, sizeof(t.weightLut));
+            const uint32_t nl = in.u32();
+            if (!in.ok || nl == 0 || nl > 32 || t.wrap < 0 || t.wrap > 2) return fail("corrupt texture header");
+            t.levels.resize(nl);
+            for (MipLevel &l : t.levels) {
+                l.w = in.i32(); l.h = in.i32();
+                if (!in.ok || l.w <= 0 || l.h <= 0 || l.w > 65536 || l.h > 65536) return fail("corrupt texture level");
+                l.rgb.resize(3 * (size_t)l.w * l.h); in.raw(l.rgb.data(), 4 * l.rgb.size());
+            }
+        }
+        for (const MaterialDesc &m : sc->materials)
+            if (m.KdTex >= (int32_t)nTex || m.KsTex >= (int32_t)nTex || m.KdTex < -1 || m.KsTex < -1) return fail("material texture index out of range");
     }
     if (!in.ok) return fail("truncated file");
     fclose(fp);

@@ -19,6 +19,18 @@ enum LightStrategy { kUniform = 0, kPower = 1, kSpatial = 2 };
 struct MaterialDesc {
     int32_t type;
     float Kd[3]; float sigma; float Ks[3]; float roughness; int32_t remapRoughness;
+    int32_t KdTex, KsTex;     // index into SceneModel::textures when the parameter is an image texture, else -1
+};
+
+// ImageTexture<RGBSpectrum, Spectrum> (textures/imagemap.h) with its finished MIPMap (core/mipmap.h): the pyramid
+// (level 0 = the power-of-two image, (0,0) = lower left), filter choice and the UVMapping2D parameters.
+enum ImageWrapMode { kWrapRepeat = 0, kWrapBlack = 1, kWrapClamp = 2 };
+struct MipLevel { int32_t w = 0, h = 0; std::vector<float> rgb; };
+struct TextureDesc {
+    std::vector<MipLevel> levels;
+    int32_t trilinear = 0; float maxAniso = 8.f; int32_t wrap = kWrapRepeat;
+    float su = 1.f, sv = 1.f, du = 0.f, dv = 0.f;       // UVMapping2D (core/texture.cpp:93-99)
+    float weightLut[128];                                // MIPMap::weightLut
 };
 
 struct MeshData {             // world space, as TriangleMesh holds it (shapes/triangle.cpp:54-92)
@@ -68,6 +80,7 @@ struct SceneModel {
     std::vector<MaterialDesc> materials;
     std::vector<ShapeDesc> shapes;
     std::vector<LightDesc> lights;
+    std::vector<TextureDesc> textures;
     uint32_t nObjects = 0;                // object ids are 0..nObjects-1 (ShapeDesc::object)
     std::vector<InstanceDesc> instances;
     std::vector<TopItem> top;             // what the top-level aggregate holds, in creation order
@@ -75,6 +88,11 @@ struct SceneModel {
     // primitives of the top-level aggregate
     uint64_t totalPrims() const { uint64_t n = 0; for (auto &t : top) n += t.kind == 0 ? shapes[t.index].nPrims() : 1u; return n; }
 };
+
+// texture_io.cpp: ReadImage (core/imageio.cpp:60-79; .tga .png .pfm), rows top to bottom, RGB floats; and
+// ImageTexture::GetTexture + MIPMap::MIPMap (textures/imagemap.cpp:52-97, core/mipmap.h:113-201)
+bool ReadImageFile(const std::string &path, int *w, int *h, std::vector<float> *rgb, std::string *err);
+void BuildMipMap(int w, int h, const std::vector<float> &rgb, float scale, bool gamma, TextureDesc *tex);
 
 bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *err);
 bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err);
