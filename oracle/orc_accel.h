@@ -37,6 +37,7 @@ struct SurfaceInteraction {
     struct { V3 n, dpdu, dpdv; } shading;
     int prim = -1;        // creation-order primitive number (within its aggregate)
     int shape = -1;
+    Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;      // ComputeDifferentials (core/interaction.cpp:103-149)
     int ordered = -1;     // ordered index of the hit primitive over all aggregates: top level first, then object 0, 1, ...
     int inst = -1;        // instance the hit went through (Scene::instances), -1: none
     // barycentrics (triangles) kept for the per-ray golden vectors

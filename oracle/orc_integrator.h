@@ -85,10 +85,54 @@ inline Xf XfPerspective(Float fov, Float n, Float f) {
 }
 
 // ---- Camera (core/camera.h:84-115, cameras/perspective.cpp:45-144) --------
+// RayDifferential's extra members (core/geometry.h:1205-1240)
+struct RayDiff {
+    bool has = false;
+    V3 rxOrigin, ryOrigin, rxDirection, ryDirection;
+    void Scale(const Ray &r, Float s) {      // ScaleDifferentials
+        rxOrigin = r.o + (rxOrigin - r.o) * s;
+        ryOrigin = r.o + (ryOrigin - r.o) * s;
+        rxDirection = r.d + (rxDirection - r.d) * s;
+        ryDirection = r.d + (ryDirection - r.d) * s;
+    }
+};
+// SurfaceInteraction::ComputeDifferentials, core/interaction.cpp:103-149 (the (u,v) part; dpdx/dpdy feed nothing here)
+inline bool SolveLinearSystem2x2(const Float A[2][2], const Float B[2], Float *x0, Float *x1) {   // core/transform.cpp:41-49
+    Float det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+    if (std::abs(det) < 1e-10f) return false;
+    *x0 = (A[1][1] * B[0] - A[0][1] * B[1]) / det;
+    *x1 = (A[0][0] * B[1] - A[1][0] * B[0]) / det;
+    if (std::isnan(*x0) || std::isnan(*x1)) return false;
+    return true;
+}
+inline void ComputeDifferentials(SurfaceInteraction *si, const Ray &ray, const RayDiff &rd) {
+    si->dudx = si->dvdx = si->dudy = si->dvdy = 0;
+    if (!rd.has) return;
+    const V3 &n = si->n, &p = si->p;
+    Float d = Dot(n, V3(p.x, p.y, p.z));
+    Float tx = -(Dot(n, rd.rxOrigin) - d) / Dot(n, rd.rxDirection);
+    if (std::isinf(tx) || std::isnan(tx)) return;
+    V3 px = rd.rxOrigin + tx * rd.rxDirection;
+    Float ty = -(Dot(n, rd.ryOrigin) - d) / Dot(n, rd.ryDirection);
+    if (std::isinf(ty) || std::isnan(ty)) return;
+    V3 py = rd.ryOrigin + ty * rd.ryDirection;
+    int dim[2];
+    if (std::abs(n.x) > std::abs(n.y) && std::abs(n.x) > std::abs(n.z)) { dim[0] = 1; dim[1] = 2; }
+    else if (std::abs(n.y) > std::abs(n.z)) { dim[0] = 0; dim[1] = 2; }
+    else { dim[0] = 0; dim[1] = 1; }
+    Float A[2][2] = {{si->dpdu[dim[0]], si->dpdv[dim[0]]}, {si->dpdu[dim[1]], si->dpdv[dim[1]]}};
+    Float Bx[2] = {px[dim[0]] - p[dim[0]], px[dim[1]] - p[dim[1]]};
+    Float By[2] = {py[dim[0]] - p[dim[0]], py[dim[1]] - p[dim[1]]};
+    if (!SolveLinearSystem2x2(A, Bx, &si->dudx, &si->dvdx)) si->dudx = si->dvdx = 0;
+    if (!SolveLinearSystem2x2(A, By, &si->dudy, &si->dvdy)) si->dudy = si->dvdy = 0;
+    (void)ray;
+}
+
 struct Camera {
     Xf rasterToCamera;
     M44 camToWorld;
     Float lensRadius, focalDistance;
+    V3 dxCamera, dyCamera;           // cameras/perspective.cpp:55-58
     void Init(const SceneParams &p) {
         Xf camToScreen = XfPerspective(p.fov, 1e-2f, 1000.f);
         const Float *sw = p.screenWindow;   // pMin.x pMax.x pMin.y pMax.y
@@ -99,10 +143,11 @@ struct Camera {
         rasterToCamera = XfMul(XfInverse(camToScreen), rasterToScreen);
         camToWorld = p.camToWorld;
         lensRadius = p.lensRadius; focalDistance = p.focalDistance;
+        dxCamera = XfPoint(rasterToCamera.m, V3(1, 0, 0)) - XfPoint(rasterToCamera.m, V3(0, 0, 0));
+        dyCamera = XfPoint(rasterToCamera.m, V3(0, 1, 0)) - XfPoint(rasterToCamera.m, V3(0, 0, 0));
     }
-    // GenerateRayDifferential :95-144; differentials themselves only feed
-    // texture filtering (constant textures here), so only the main ray is kept.
-    Float GenerateRay(const P2 &pFilmS, const P2 &pLensS, Ray *ray) const {
+    // GenerateRayDifferential :95-144.  The differentials only feed texture filtering; rd (may be null) receives them.
+    Float GenerateRay(const P2 &pFilmS, const P2 &pLensS, Ray *ray, RayDiff *rd = nullptr) const {
         V3 pFilm(pFilmS.x, pFilmS.y, 0);
         V3 pCamera = XfPoint(rasterToCamera.m, pFilm);
         V3 dir = Normalize(V3(pCamera.x, pCamera.y, pCamera.z));
@@ -127,6 +172,32 @@ struct Camera {
             tMax -= dt;
         }
         *ray = Ray(o, d, tMax);
+        if (rd) {
+            // offset rays (:117-138), then Transform::operator()(const RayDifferential &) (core/transform.h:266-275):
+            // points and vectors transformed plainly
+            V3 rxO, ryO, rxD, ryD;
+            if (lensRadius > 0) {
+                P2 c = ConcentricSampleDisk(pLensS);
+                P2 pLens(lensRadius * c.x, lensRadius * c.y);
+                V3 dx = Normalize(pCamera + dxCamera);
+                Float ft = focalDistance / dx.z;
+                V3 pFocus = V3(0, 0, 0) + (ft * dx);
+                rxO = V3(pLens.x, pLens.y, 0);
+                rxD = Normalize(pFocus - rxO);
+                V3 dy = Normalize(pCamera + dyCamera);
+                ft = focalDistance / dy.z;
+                pFocus = V3(0, 0, 0) + (ft * dy);
+                ryO = V3(pLens.x, pLens.y, 0);
+                ryD = Normalize(pFocus - ryO);
+            } else {
+                rxO = ryO = r.o;
+                rxD = Normalize(pCamera + dxCamera);
+                ryD = Normalize(pCamera + dyCamera);
+            }
+            rd->has = true;
+            rd->rxOrigin = XfPoint(camToWorld, rxO); rd->ryOrigin = XfPoint(camToWorld, ryO);
+            rd->rxDirection = XfVector(camToWorld, rxD); rd->ryDirection = XfVector(camToWorld, ryD);
+        }
         return 1;
     }
 };
@@ -431,7 +502,8 @@ struct Renderer {
         return EstimateDirect(isect, bsdf, uScattering, lightNum, uLight, ctr) / lightPdf;
     }
     // integrators/path.cpp:64-204 (no media, no BSSRDF; every material has a BSDF)
-    Spec Li(const Ray &r, HaltonSampler &sampler, Counters &ctr, int *pathLen = nullptr) const {
+    Spec Li(const Ray &r, HaltonSampler &sampler, Counters &ctr, int *pathLen = nullptr, const RayDiff *camDiff = nullptr) const {
+        RayDiff rdiff; if (camDiff) rdiff = *camDiff;     // only the camera ray has differentials: SpawnRay returns a plain Ray
         Spec L(0.f), beta(1.f);
         Ray ray(r);
         bool specularBounce = false;
@@ -447,7 +519,8 @@ struct Renderer {
             }
             if (!foundIntersection || bounces >= maxDepth) break;
             BSDF bsdf;
-            ComputeScatteringFunctions(scene.materials[scene.shapes[isect.shape].material], isect, &bsdf);
+            ComputeDifferentials(&isect, ray, rdiff);      // SurfaceInteraction::ComputeScatteringFunctions, core/interaction.cpp:93-101
+            ComputeScatteringFunctions(scene, scene.materials[scene.shapes[isect.shape].material], isect, &bsdf);
             if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
                 Spec Ld = beta * UniformSampleOneLight(isect, bsdf, sampler, ctr);
                 L += Ld;
@@ -460,6 +533,7 @@ struct Renderer {
             beta *= f * AbsDot(wi, isect.shading.n) / pdf;
             specularBounce = (flags & BSDF_SPECULAR) != 0;
             ray = SpawnRay(isect.p, isect.pError, isect.n, wi);
+            rdiff.has = false;
             Spec rrBeta = beta * etaScale;
             if (rrBeta.MaxComponentValue() < rrThreshold && bounces > 3) {
                 Float q = smax((Float).05, 1 - rrBeta.MaxComponentValue());
@@ -477,11 +551,13 @@ struct Renderer {
         P2 pFilm((Float)px + u.x, (Float)py + u.y);
         Float time = sampler.Get1D(); (void)time;
         P2 pLens = sampler.Get2D();
-        Ray ray;
-        Float rayWeight = camera.GenerateRay(pFilm, pLens, &ray);
+        Ray ray; RayDiff rd;
+        const bool textured = !scene.textures.empty();
+        Float rayWeight = camera.GenerateRay(pFilm, pLens, &ray, textured ? &rd : nullptr);
+        if (textured) rd.Scale(ray, 1 / std::sqrt((Float)sampler.samplesPerPixel));     // core/integrator.cpp:288-289
         ++ctr.cameraRays;
         Spec L(0.f);
-        if (rayWeight > 0) L = Li(ray, sampler, ctr);
+        if (rayWeight > 0) L = Li(ray, sampler, ctr, nullptr, textured ? &rd : nullptr);
         if (L.HasNaNs()) L = Spec(0.f);
         else if (L.y() < -1e-5) L = Spec(0.f);
         else if (std::isinf(L.y())) L = Spec(0.f);

@@ -185,6 +185,22 @@ inline double acos_d(double x) {
     if (x >= 1.0) return 0.0;
     return 2.0 * atan_pos(std::sqrt((1.0 - x) / (1.0 + x)));
 }
+// log(x) for finite x > 0: x = m * 2^e with m in [sqrt(1/2), sqrt(2)), log(m) = 2 atanh((m-1)/(m+1)) as a series
+inline double log_d(double x) {
+    if (!(x > 0.0)) return x == 0.0 ? -HUGE_VAL : (x - x) / (x - x);        // log(0) = -inf, log(<0) = nan
+    if (x > 1.7976931348623157e308) return x;                                // +inf
+    uint64_t bits; memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7ffu);
+    if (e == 0) { x *= 18014398509481984.0; memcpy(&bits, &x, 8); e = (int)((bits >> 52) & 0x7ffu) - 54; }   // subnormal: scale by 2^54
+    e -= 1023;
+    bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;           // m in [1, 2)
+    double m; memcpy(&m, &bits, 8);
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = 1.0 / 27.0;
+    for (int n = 12; n >= 0; --n) p = 1.0 / (double)(2 * n + 1) + z * p;
+    return (double)e * 6.93147180369123816490e-01 + ((double)e * 1.90821492927058770002e-10 + 2.0 * s * p);
+}
 }  // namespace det
 
 // float-argument versions, as std::sin(float) etc. in the reference.
@@ -192,6 +208,7 @@ inline float m_sinf(float x) { return g_use_libm ? std::sin(x) : (float)det::sin
 inline float m_cosf(float x) { return g_use_libm ? std::cos(x) : (float)det::cos_d((double)x); }
 inline float m_atan2f(float y, float x) { return g_use_libm ? std::atan2(y, x) : (float)det::atan2_d((double)y, (double)x); }
 inline float m_acosf(float x) { return g_use_libm ? std::acos(x) : (float)det::acos_d((double)x); }
+inline float m_logf(float x) { return g_use_libm ? std::log(x) : (float)det::log_d((double)x); }
 // double-argument versions: unqualified sin()/cos() in core/microfacet.cpp:241-246
 // resolve to ::sin(double)/::cos(double) under libstdc++ <cmath>.
 inline double m_sin(double x) { return g_use_libm ? ::sin(x) : det::sin_d(x); }

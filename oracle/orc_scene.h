@@ -19,6 +19,17 @@ enum { SHAPE_MESH = 0, SHAPE_SPHERE = 1 };
 struct Material {
     int type;
     Float Kd[3]; Float sigma; Float Ks[3]; Float roughness; int remap;
+    int KdTex = -1, KsTex = -1;       // Scene::textures index when the parameter is an ImageTexture
+};
+// ImageTexture<RGBSpectrum, Spectrum> with its built MIPMap (textures/imagemap.h, core/mipmap.h).  The pyramid is
+// built once by the product's host code (csrc/texture_io.cpp) and travels in the baked scene; lookups are restated here.
+enum { WRAP_REPEAT = 0, WRAP_BLACK = 1, WRAP_CLAMP = 2 };
+struct MipLevel { int w = 0, h = 0; std::vector<Float> rgb; };
+struct Texture {
+    std::vector<MipLevel> levels;
+    int trilinear = 0; Float maxAniso = 8; int wrap = WRAP_REPEAT;
+    Float su = 1, sv = 1, du = 0, dv = 0;
+    Float weightLut[128];
 };
 struct Mesh {
     uint32_t nTris, nVerts;
@@ -69,6 +80,7 @@ struct Scene {
     std::vector<Mesh> meshes;
     std::vector<Sphere> spheres;
     std::vector<Light> lights;
+    std::vector<Texture> textures;
     std::vector<PrimRef> prims;                          // top level
     std::vector<std::vector<PrimRef>> objectPrims;       // per object definition
     std::vector<Instance> instances;
@@ -90,7 +102,7 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
     char magic[8]; r.raw(magic, 8);
     if (!r.ok || memcmp(magic, "HPRTSCN1", 8) != 0) { *err = "bad magic"; return false; }
     uint32_t version = r.u32();
-    if (version != 1 && version != 2) { *err = "bad version"; return false; }
+    if (version < 1 || version > 3) { *err = "bad version"; return false; }
     SceneParams &p = sc->prm;
     p.xres = r.i32(); p.yres = r.i32();
     for (int i = 0; i < 4; ++i) p.crop[i] = r.f32();
@@ -151,7 +163,7 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
     auto addShapePrims = [&](std::vector<PrimRef> &dst, uint32_t si) {
         for (uint32_t k = 0; k < sc->shapes[si].nPrims; ++k) dst.push_back(PrimRef{(int)si, (int)k});
     };
-    if (version == 2) {
+    if (version >= 2) {
         uint32_t nObjects = r.u32();
         if (!r.ok || nObjects > (1u << 24)) { *err = "bad object count"; return false; }
         sc->objectPrims.resize(nObjects);
@@ -177,6 +189,26 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
         }
     } else {
         for (uint32_t si = 0; si < nShapes; ++si) addShapePrims(sc->prims, si);
+    }
+    if (version >= 3) {
+        for (auto &m : sc->materials) { m.KdTex = r.i32(); m.KsTex = r.i32(); }
+        uint32_t nTex = r.u32();
+        if (!r.ok || nTex > (1u << 20)) { *err = "bad texture count"; return false; }
+        sc->textures.resize(nTex);
+        for (auto &t : sc->textures) {
+            t.trilinear = r.i32(); t.maxAniso = r.f32(); t.wrap = r.i32(); t.su = r.f32(); t.sv = r.f32(); t.du = r.f32(); t.dv = r.f32();
+            r.raw(t.weightLut, sizeof(t.weightLut));
+            uint32_t nl = r.u32();
+            if (!r.ok || nl == 0 || nl > 32) { *err = "bad texture header"; return false; }
+            t.levels.resize(nl);
+            for (auto &l : t.levels) {
+                l.w = r.i32(); l.h = r.i32();
+                if (!r.ok || l.w <= 0 || l.h <= 0 || l.w > 65536 || l.h > 65536) { *err = "bad texture level"; return false; }
+                l.rgb.resize(3 * (size_t)l.w * l.h); r.raw(l.rgb.data(), 4 * l.rgb.size());
+            }
+        }
+        for (auto &m : sc->materials)
+            if (m.KdTex >= (int)nTex || m.KsTex >= (int)nTex) { *err = "bad material texture index"; return false; }
     }
     if (!r.ok) { *err = "truncated file"; return false; }
     return true;

@@ -269,23 +269,115 @@ struct BSDF {
     }
 };
 
-// materials/matte.cpp:45-62, materials/plastic.cpp:45-70 (constant textures;
+// ---- image textures: MIPMap lookups (core/mipmap.h:203-338) and UVMapping2D (core/texture.cpp:93-99) ----
+inline int ModI(int a, int b) { int r = a - (a / b) * b; return r < 0 ? r + b : r; }
+inline Spec MipTexel(const Texture &tx, int level, int s, int t) {
+    const MipLevel &l = tx.levels[level];
+    if (tx.wrap == WRAP_REPEAT) { s = ModI(s, l.w); t = ModI(t, l.h); }
+    else if (tx.wrap == WRAP_CLAMP) { s = Clamp(s, 0, l.w - 1); t = Clamp(t, 0, l.h - 1); }
+    else if (s < 0 || s >= l.w || t < 0 || t >= l.h) return Spec(0.f);
+    const Float *p = &l.rgb[3 * ((size_t)t * l.w + s)];
+    return Spec(p[0], p[1], p[2]);
+}
+inline Spec MipTriangle(const Texture &tx, int level, const P2 &st) {
+    const int nLevels = (int)tx.levels.size();
+    level = Clamp(level, 0, nLevels - 1);
+    Float s = st.x * tx.levels[level].w - 0.5f;
+    Float t = st.y * tx.levels[level].h - 0.5f;
+    int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
+    Float ds = s - s0, dt = t - t0;
+    return (1 - ds) * (1 - dt) * MipTexel(tx, level, s0, t0) + (1 - ds) * dt * MipTexel(tx, level, s0, t0 + 1) +
+           ds * (1 - dt) * MipTexel(tx, level, s0 + 1, t0) + ds * dt * MipTexel(tx, level, s0 + 1, t0 + 1);
+}
+inline Float Log2F(Float x) { const Float invLog2 = 1.442695040888963387004650940071; return m_logf(x) * invLog2; }   // core/pbrt.h:328-331
+inline Spec LerpS(Float t, const Spec &a, const Spec &b) { return (1 - t) * a + t * b; }
+inline Spec MipLookupWidth(const Texture &tx, const P2 &st, Float width) {
+    const int nLevels = (int)tx.levels.size();
+    Float level = nLevels - 1 + Log2F(smax(width, (Float)1e-8));
+    if (level < 0) return MipTriangle(tx, 0, st);
+    else if (level >= nLevels - 1) return MipTexel(tx, nLevels - 1, 0, 0);
+    int iLevel = (int)std::floor(level);
+    Float delta = level - iLevel;
+    return LerpS(delta, MipTriangle(tx, iLevel, st), MipTriangle(tx, iLevel + 1, st));
+}
+inline Spec MipEWA(const Texture &tx, int level, P2 st, P2 dst0, P2 dst1) {
+    const int nLevels = (int)tx.levels.size();
+    if (level >= nLevels) return MipTexel(tx, nLevels - 1, 0, 0);
+    const MipLevel &l = tx.levels[level];
+    st.x = st.x * l.w - 0.5f; st.y = st.y * l.h - 0.5f;
+    dst0.x *= l.w; dst0.y *= l.h; dst1.x *= l.w; dst1.y *= l.h;
+    Float A = dst0.y * dst0.y + dst1.y * dst1.y + 1;
+    Float B = -2 * (dst0.x * dst0.y + dst1.x * dst1.y);
+    Float C = dst0.x * dst0.x + dst1.x * dst1.x + 1;
+    Float invF = 1 / (A * C - B * B * 0.25f);
+    A *= invF; B *= invF; C *= invF;
+    Float det = -B * B + 4 * A * C;
+    Float invDet = 1 / det;
+    Float uSqrt = std::sqrt(det * C), vSqrt = std::sqrt(A * det);
+    int s0 = (int)std::ceil(st.x - 2 * invDet * uSqrt), s1 = (int)std::floor(st.x + 2 * invDet * uSqrt);
+    int t0 = (int)std::ceil(st.y - 2 * invDet * vSqrt), t1 = (int)std::floor(st.y + 2 * invDet * vSqrt);
+    Spec sum(0.f);
+    Float sumWts = 0;
+    for (int it = t0; it <= t1; ++it) {
+        Float tt = it - st.y;
+        for (int is = s0; is <= s1; ++is) {
+            Float ss = is - st.x;
+            Float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
+            if (r2 < 1) {
+                int index = smin((int)(r2 * 128), 128 - 1);
+                Float weight = tx.weightLut[index];
+                sum += MipTexel(tx, level, is, it) * weight;
+                sumWts += weight;
+            }
+        }
+    }
+    return sum / sumWts;
+}
+inline Spec MipLookup(const Texture &tx, const P2 &st, P2 dst0, P2 dst1) {
+    if (tx.trilinear) {
+        Float width = smax(smax(std::abs(dst0.x), std::abs(dst0.y)), smax(std::abs(dst1.x), std::abs(dst1.y)));
+        return MipLookupWidth(tx, st, 2 * width);
+    }
+    if (dst0.x * dst0.x + dst0.y * dst0.y < dst1.x * dst1.x + dst1.y * dst1.y) std::swap(dst0, dst1);
+    Float majorLength = std::sqrt(dst0.x * dst0.x + dst0.y * dst0.y);
+    Float minorLength = std::sqrt(dst1.x * dst1.x + dst1.y * dst1.y);
+    if (minorLength * tx.maxAniso < majorLength && minorLength > 0) {
+        Float scale = majorLength / (minorLength * tx.maxAniso);
+        dst1.x *= scale; dst1.y *= scale;
+        minorLength *= scale;
+    }
+    if (minorLength == 0) return MipTriangle(tx, 0, st);
+    const int nLevels = (int)tx.levels.size();
+    Float lod = smax((Float)0, nLevels - (Float)1 + Log2F(minorLength));
+    int ilod = (int)std::floor(lod);
+    return LerpS(lod - ilod, MipEWA(tx, ilod, st, dst0, dst1), MipEWA(tx, ilod + 1, st, dst0, dst1));
+}
+// ImageTexture::Evaluate (textures/imagemap.h:82-89) over UVMapping2D::Map
+inline Spec EvalImageTexture(const Texture &tx, const SurfaceInteraction &si) {
+    P2 dstdx(tx.su * si.dudx, tx.sv * si.dvdx), dstdy(tx.su * si.dudy, tx.sv * si.dvdy);
+    P2 st(tx.su * si.uv.x + tx.du, tx.sv * si.uv.y + tx.dv);
+    return MipLookup(tx, st, dstdx, dstdy);
+}
+
+// materials/matte.cpp:45-62, materials/plastic.cpp:45-70 (constant or image textures;
 // sigma != 0 (OrenNayar) is outside the hot-path scope)
-inline void ComputeScatteringFunctions(const Material &m, const SurfaceInteraction &si, BSDF *bsdf) {
+inline void ComputeScatteringFunctions(const Scene &scene, const Material &m, const SurfaceInteraction &si, BSDF *bsdf) {
     bsdf->Init(si);
+    const Spec Kd = m.KdTex >= 0 ? EvalImageTexture(scene.textures[m.KdTex], si) : Spec(m.Kd[0], m.Kd[1], m.Kd[2]);
+    const Spec Ks = m.KsTex >= 0 ? EvalImageTexture(scene.textures[m.KsTex], si) : Spec(m.Ks[0], m.Ks[1], m.Ks[2]);
     if (m.type == MAT_MATTE) {
-        Spec r = Spec(m.Kd[0], m.Kd[1], m.Kd[2]).Clamp();
+        Spec r = Kd.Clamp();
         if (!r.IsBlack()) {
             BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
             b.kind = BXDF_LAMBERT; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.R = r;
         }
     } else {
-        Spec kd = Spec(m.Kd[0], m.Kd[1], m.Kd[2]).Clamp();
+        Spec kd = Kd.Clamp();
         if (!kd.IsBlack()) {
             BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
             b.kind = BXDF_LAMBERT; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.R = kd;
         }
-        Spec ks = Spec(m.Ks[0], m.Ks[1], m.Ks[2]).Clamp();
+        Spec ks = Ks.Clamp();
         if (!ks.IsBlack()) {
             Float rough = m.roughness;
             if (m.remap) rough = RoughnessToAlpha(rough);

@@ -206,6 +206,24 @@ HPRT_HD double det_acos(double x) {
     if (x >= 1.0) return 0.0;
     return 2.0 * det_atan_pos(sqrt((1.0 - x) / (1.0 + x)));
 }
+// log(x) for finite x > 0: x = m * 2^e with m in [sqrt(1/2), sqrt(2)), log(m) = 2 atanh((m-1)/(m+1)) as a series
+// (stands in for logf of Log2(), core/pbrt.h:328-331, like the functions above do for sinf / cosf)
+HPRT_HD double det_log(double x) {
+    if (!(x > 0.0)) return x == 0.0 ? -HUGE_VAL : (x - x) / (x - x);
+    if (x > 1.7976931348623157e308) return x;
+    unsigned long long bits; memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7ffu);
+    if (e == 0) { x *= 18014398509481984.0; memcpy(&bits, &x, 8); e = (int)((bits >> 52) & 0x7ffu) - 54; }
+    e -= 1023;
+    bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m; memcpy(&m, &bits, 8);
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = 1.0 / 27.0;
+    for (int n = 12; n >= 0; --n) p = 1.0 / (double)(2 * n + 1) + z * p;
+    return (double)e * 6.93147180369123816490e-01 + ((double)e * 1.90821492927058770002e-10 + 2.0 * s * p);
+}
+HPRT_HD float det_logf(float x) { return (float)det_log((double)x); }
 HPRT_HD float det_sinf(float x) { return (float)det_sin((double)x); }
 HPRT_HD float det_cosf(float x) { return (float)det_cos((double)x); }
 HPRT_HD float det_atan2f(float y, float x) { return (float)det_atan2((double)y, (double)x); }
