@@ -1,0 +1,114 @@
+"""GPU parity for image textures: ImageTexture<RGBSpectrum, Spectrum> on matte / plastic Kd and Ks
+(textures/imagemap.h:82-89), UVMapping2D (core/texture.cpp:93-99), camera ray differentials scaled by 1/sqrt(spp)
+(core/integrator.cpp:288-289), SurfaceInteraction::ComputeDifferentials (core/interaction.cpp:103-149) and the MIPMap
+lookups, EWA and trilinear, with the three wrap modes (core/mipmap.h:203-338).
+
+Each scene is .pbrt text plus image files written here (PNG / TGA / PFM), parsed and baked by the product front-end
+(which also builds the pyramids), then rendered by the HIP path through the C ABI and by the oracle: films must be
+bit-identical.  No scene of the reference that is in the hot-path scope uses an image whose file is in the repository,
+so these lookups are not pinned against a reference image ("parity unpinned"): the oracle restates
+core/mipmap.h and the device must agree with it exactly."""
+import numpy as np
+import pytest
+
+from test_gpu_scenes import BUMPY, FLOOR, MATTE, SPHERE_LIGHT, _grid_mesh, _scene
+from test_host_side import _write_pfm, _write_png, _write_tga
+
+pytestmark = pytest.mark.gpu
+
+
+def _checker(n=64, cells=8, seed=3):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:n, 0:n]
+    c = ((x * cells // n) + (y * cells // n)) % 2
+    img = np.where(c[..., None] == 1, np.array([230, 220, 200]), np.array([40, 60, 160])).astype(np.int32)
+    img = img + rng.integers(-25, 25, size=img.shape)          # per-texel noise: every filter footprint matters
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _write_images(d):
+    _write_png(str(d / "chk.png"), _checker())
+    _write_tga(str(d / "stripes.tga"), np.repeat(_checker(48, 6, 5)[:, :1], 20, axis=1), rle=True)   # 20 x 48: non power of two
+    rng = np.random.default_rng(11)
+    _write_pfm(str(d / "hdr.pfm"), (rng.random((33, 57, 3)) * 1.5).astype(np.float32))                # resampled to 64 x 64
+
+
+BUMPY_UV = _grid_mesh(24, 24, lambda x, y: 0.25 * np.sin(2.3 * x) * np.cos(1.7 * y), uv=True)
+
+
+def _tex(name, fn, extra=""):
+    return 'Texture "%s" "spectrum" "imagemap" "string filename" "%%(dir)s/%s" %s\n' % (name, fn, extra)
+
+
+CASES = {
+    # EWA (the default), repeat wrap, magnified and minified across the floor; the bumpy mesh keeps constant parameters
+    "floor_ewa_repeat": _scene(SPHERE_LIGHT + _tex("chk", "chk.png", '"float uscale" [3] "float vscale" [3]') +
+                               'Material "matte" "texture Kd" "chk"\nShape "trianglemesh" ' + FLOOR + "\n" + MATTE +
+                               'Shape "trianglemesh" ' + BUMPY + "\n", xres=128, yres=96, spp=4),
+    # trilinear, clamp wrap, offset mapping; textured plastic Kd and Ks on a mesh with uv
+    "plastic_trilinear_clamp": _scene(SPHERE_LIGHT + _tex("a", "stripes.tga", '"bool trilinear" ["true"] "string wrap" ["clamp"] "float udelta" [-.2] "float uscale" [1.4]') +
+                                      _tex("b", "hdr.pfm", '"float scale" [.5]') + MATTE + 'Shape "trianglemesh" ' + FLOOR + "\n" +
+                                      'Material "plastic" "texture Kd" "a" "texture Ks" "b" "float roughness" [.1]\nShape "trianglemesh" ' + BUMPY_UV + "\n", spp=4),
+    # black wrap; a mesh without uv (default parameterisation, shapes/triangle.h:114-118); strong anisotropy limit
+    "black_wrap_no_uv": _scene('LightSource "point" "point from" [1 -2 4] "color I" [30 30 30]\n' +
+                               _tex("chk", "chk.png", '"string wrap" ["black"] "float uscale" [2.5] "float vscale" [.7] "float maxanisotropy" [2]') +
+                               'Material "matte" "texture Kd" "chk"\nShape "trianglemesh" ' + BUMPY + "\nShape \"trianglemesh\" " + FLOOR + "\n", spp=2),
+    # spheres (u = phi / phiMax, v from theta) directly and inside instances, a textured instanced mesh, depth of field
+    "spheres_instances_dof": _scene(SPHERE_LIGHT + _tex("chk", "chk.png", '"float uscale" [4] "float vscale" [2]') + _tex("h", "hdr.pfm") +
+                                    'Material "matte" "texture Kd" "h"\nShape "trianglemesh" ' + FLOOR + "\n"
+                                    'AttributeBegin\nMaterial "plastic" "texture Kd" "chk" "color Ks" [.3 .3 .3]\nTranslate -1.2 0 .4\nRotate 35 0 1 0\n'
+                                    'Shape "sphere" "float radius" [.6] "float zmax" [.45] "float phimax" [300]\nAttributeEnd\n'
+                                    'ObjectBegin "o"\nMaterial "matte" "texture Kd" "chk"\nScale .35 .35 .8\nShape "trianglemesh" ' + BUMPY_UV +
+                                    '\nTranslate 0 0 1.2\nShape "sphere" "float radius" [.8]\nObjectEnd\n'
+                                    'AttributeBegin\nTranslate 1.1 -.3 .1\nRotate -40 .2 .1 1\nScale 1.2 .8 1\nObjectInstance "o"\nAttributeEnd\n'
+                                    'AttributeBegin\nTranslate 0 1.4 .3\nScale 1 -1 1\nObjectInstance "o"\nAttributeEnd\n',
+                                    cam='"float lensradius" [0.08] "float focaldistance" [6.5]', spp=4, maxdepth=4),
+    # one sample per pixel (differential scale 1), and far minification (grazing floor up to the horizon)
+    "spp1_grazing": """LookAt 0 -3.9 -0.25  0 4 -0.45  0 0 1
+Camera "perspective" "float fov" [55]
+Film "image" "integer xresolution" [120] "integer yresolution" [60]
+Sampler "halton" "integer pixelsamples" [1]
+Integrator "path" "integer maxdepth" [2]
+WorldBegin
+LightSource "distant" "point from" [1 -1 3] "point to" [0 0 0] "color L" [2 2 1.5]
+""" + _tex("chk", "chk.png", '"float uscale" [16] "float vscale" [16]') + 'Material "matte" "texture Kd" "chk"\nShape "trianglemesh" ' + FLOOR + "\nWorldEnd\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_textured_film_parity(hprt, orc, tmp_path, name):
+    _write_images(tmp_path)
+    p = tmp_path / (name + ".pbrt")
+    p.write_text(CASES[name] % {"dir": str(tmp_path)})
+    model = hprt.Model.parse(str(p))
+    assert model.warnings() == [], model.warnings()
+    assert model.counts()["textures"] >= 1
+    baked = str(tmp_path / (name + ".hprt"))
+    model.save(baked)
+    bvh = hprt.Bvh(model)
+    oracle = orc.OracleScene(baked)
+    scene = hprt.Scene(model, bvh)
+    rgb0, film0, c0, _, _ = oracle.render(threads=8)
+    film1, st = scene.render(count_work=True)
+    assert film1.shape == film0.shape
+    bad = np.any(film0.view(np.uint32) != film1.view(np.uint32), axis=2)
+    assert not bad.any(), "%s: %d pixels differ, max |d| = %g" % (name, int(bad.sum()), float(np.abs(film0 - film1).max()))
+    for k in ("camera_rays", "rays", "shadow_rays", "nodes_fetched", "nodes_fetched_p", "tri_tests", "tri_tests_p", "sphere_tests", "sphere_tests_p"):
+        assert st[k] == c0[k], (name, k, st[k], c0[k])
+    # the texture is visible: neighbouring pixels of the textured surface differ in chromaticity
+    assert film0[..., :3].max() > 0 and np.unique(np.round(film0[..., :3] / (film0[..., 3:4] + 1e-9), 3).reshape(-1, 3), axis=0).shape[0] > 50
+
+
+def test_textured_render_matches_constant_when_texture_is_flat(hprt, orc, tmp_path):
+    """A one-colour image must give the film of the same scene with that colour as a constant
+    (every lookup is a convex combination of equal texels, up to the weights' rounding)."""
+    _write_pfm(str(tmp_path / "flat.pfm"), np.full((8, 8, 3), 0.5, np.float32))
+    body = SPHERE_LIGHT + '%s\nShape "trianglemesh" ' + FLOOR + "\n" + MATTE + 'Shape "trianglemesh" ' + BUMPY + "\n"
+    films = []
+    for i, mat in enumerate(('Texture "t" "spectrum" "imagemap" "string filename" "%s/flat.pfm" "bool trilinear" ["true"]\nMaterial "matte" "texture Kd" "t"' % tmp_path,
+                             'Material "matte" "color Kd" [.5 .5 .5]')):
+        p = tmp_path / ("flat%d.pbrt" % i)
+        p.write_text(_scene(body % mat, spp=2))
+        model = hprt.Model.parse(str(p))
+        films.append(hprt.Scene(model, hprt.Bvh(model)).render()[0])
+    assert np.allclose(films[0], films[1], rtol=2e-6, atol=1e-7)

@@ -53,6 +53,7 @@ template <typename T> hipError_t upload(DevBuf &b, const std::vector<T> &v) {
 struct HprtScene {
     int device = 0;
     DevScene dev;
+    DevBuf textures, mipLevels, texels, weightLut;
     DevBuf nodes, tris, primVtx, primN, vUV, vS, shapes, materials, lights, spheres, instances, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
     DevBuf counters, workCounter;
     DevBuf rayStats, pixelStatsLocal, pixelStatsFilm; bool pixelStatsValid = false;   // HPRT_RENDER_PIXEL_STATS
@@ -161,6 +162,9 @@ void MakeCamera(const HprtRenderOptions &o, DevCamera *cam) {
     cam->rasterToCamera = rasterToCamera.m;
     memcpy(cam->cameraToWorld.m, o.camera_to_world, 64);
     cam->lensRadius = o.lens_radius; cam->focalDistance = o.focal_distance;
+    // cameras/perspective.cpp:55-58
+    cam->dxCamera = xf_point(cam->rasterToCamera, vec3(1, 0, 0)) - xf_point(cam->rasterToCamera, vec3(0, 0, 0));
+    cam->dyCamera = xf_point(cam->rasterToCamera, vec3(0, 1, 0)) - xf_point(cam->rasterToCamera, vec3(0, 0, 0));
 }
 
 struct FrameSetup {
@@ -362,7 +366,8 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
                     bool bogus = TriangleIsBogus(vec3(a[0], a[1], a[2]), vec3(b[0], b[1], b[2]), vec3(c[0], c[1], c[2]),
                                                  sh.UV ? &sh.UV[2 * (size_t)v[0]] : nullptr, sh.UV ? &sh.UV[2 * (size_t)v[1]] : nullptr,
                                                  sh.UV ? &sh.UV[2 * (size_t)v[2]] : nullptr);
-                    uint32_t tag = (bogus ? TAG_BOGUS : 0u) | (d->materials[sh.material].type == 1 ? TAG_PLASTIC : 0u);
+                    const HprtMaterialDesc &md = d->materials[sh.material];
+                    uint32_t tag = (bogus ? TAG_BOGUS : 0u) | (md.type == 1 ? TAG_PLASTIC : 0u) | (md.kd_texture >= 0 || md.ks_texture >= 0 ? TAG_GENERIC : 0u);
                     r0 = make_float4(a[0], a[1], a[2], u2f(tag)); r1 = make_float4(b[0], b[1], b[2], u2f(s)); r2 = make_float4(c[0], c[1], c[2], u2f(0u));
                     for (int k = 0; k < 3; ++k) {
                         primVtx[3 * i + k] = (uint32_t)(vtxBase[s] + (uint32_t)v[k]);
@@ -381,10 +386,33 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
         if (in.type != 0 && in.type != 1) return SetError(HPRT_E_UNSUPPORTED, "material type outside the hot-path scope (matte, plastic)");
         if (in.type == 0 && in.sigma != 0.f) return SetError(HPRT_E_UNSUPPORTED, "matte sigma != 0 (OrenNayar) is outside the hot-path scope");
         if (in.kd_texture >= (int32_t)d->n_textures || in.ks_texture >= (int32_t)d->n_textures) return SetError(HPRT_E_INVALID, "material texture index out of range");
-        if (in.kd_texture >= 0 || in.ks_texture >= 0) return SetError(HPRT_E_UNSUPPORTED, "image textures are parsed and baked, the device lookup is not built yet");
         DevMaterial &o = mats[m];
+        o.KdTex = in.kd_texture >= 0 ? in.kd_texture : -1; o.KsTex = in.ks_texture >= 0 ? in.ks_texture : -1;
         o.type = in.type; memcpy(o.Kd, in.Kd, 12); memcpy(o.Ks, in.Ks, 12);
         o.alpha = in.remap_roughness ? RoughnessToAlpha(in.roughness) : in.roughness;
+    }
+    // image textures: every pyramid level of every texture in one texel array (3 floats per texel)
+    std::vector<DevTexture> textures(d->n_textures);
+    std::vector<DevMipLevel> mipLevels;
+    std::vector<float> texels, weightLut;
+    for (uint32_t t = 0; t < d->n_textures; ++t) {
+        const HprtTextureDesc &in = d->textures[t];
+        if (!in.levels || in.n_levels == 0 || in.n_levels > 32 || !in.weight_lut) return SetError(HPRT_E_INVALID, "texture without levels or weight table");
+        if (in.wrap < 0 || in.wrap > 2) return SetError(HPRT_E_INVALID, "texture wrap mode out of range");
+        DevTexture &o = textures[t];
+        o.firstLevel = (uint32_t)mipLevels.size(); o.nLevels = in.n_levels; o.trilinear = in.trilinear ? 1 : 0; o.wrap = in.wrap;
+        o.maxAniso = in.max_anisotropy; o.su = in.su; o.sv = in.sv; o.du = in.du; o.dv = in.dv;
+        for (uint32_t l = 0; l < in.n_levels; ++l) {
+            const HprtTextureLevel &lv = in.levels[l];
+            if (lv.w <= 0 || lv.h <= 0 || !lv.rgb) return SetError(HPRT_E_INVALID, "empty texture level");
+            const size_t n = 3 * (size_t)lv.w * (size_t)lv.h;
+            if (texels.size() + n > 0xffffffffull) return SetError(HPRT_E_UNSUPPORTED, "more than 2^32 texture floats");
+            mipLevels.push_back(DevMipLevel{(uint32_t)texels.size(), lv.w, lv.h});
+            texels.insert(texels.end(), lv.rgb, lv.rgb + n);
+        }
+        // MIPMap::weightLut is a static table (core/mipmap.h:107, 153-161): identical for every texture
+        if (t == 0) weightLut.assign(in.weight_lut, in.weight_lut + 128);
+        else if (memcmp(weightLut.data(), in.weight_lut, 128 * sizeof(float)) != 0) return SetError(HPRT_E_INVALID, "textures disagree on the EWA weight table");
     }
     std::vector<DevLight> lights(d->n_lights);
     for (uint32_t l = 0; l < d->n_lights; ++l) {
@@ -457,6 +485,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     HIP_TRY(upload(sc->spheres, spheres)); HIP_TRY(upload(sc->instances, instances)); HIP_TRY(upload(sc->lightFunc, func)); HIP_TRY(upload(sc->lightCdf, cdf));
     HIP_TRY(upload(sc->perms, perms)); HIP_TRY(upload(sc->primes, primes)); HIP_TRY(upload(sc->primeSums, primeSums));
     HIP_TRY(upload(sc->primeMagic, magic));
+    HIP_TRY(upload(sc->textures, textures)); HIP_TRY(upload(sc->mipLevels, mipLevels)); HIP_TRY(upload(sc->texels, texels)); HIP_TRY(upload(sc->weightLut, weightLut));
     HIP_TRY(sc->counters.alloc(sizeof(DevCounters)));
     HIP_TRY(hipMemset(sc->counters.p, 0, sizeof(DevCounters)));
     HIP_TRY(sc->workCounter.alloc(64));
@@ -469,6 +498,8 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     dv.materials = sc->materials.as<DevMaterial>();
     dv.lights = sc->lights.as<DevLight>(); dv.nLights = d->n_lights;
     dv.spheres = sc->spheres.as<DevSphere>();
+    dv.textures = d->n_textures ? sc->textures.as<DevTexture>() : nullptr; dv.mipLevels = sc->mipLevels.as<DevMipLevel>();
+    dv.texels = sc->texels.as<float>(); dv.weightLut = sc->weightLut.as<float>();
     dv.instances = sc->instances.as<DevInstance>(); dv.nInstances = d->n_instances;
     dv.lightFunc = sc->lightFunc.as<float>(); dv.lightCdf = sc->lightCdf.as<float>(); dv.lightFuncInt = funcInt;
     dv.perms = sc->perms.as<uint16_t>(); dv.primes = sc->primes.as<int32_t>(); dv.primeSums = sc->primeSums.as<int32_t>();
@@ -813,6 +844,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     rp.hal.samplePixelCenter = o.sample_pixel_center;
     rp.pixelXY = s->pixelXY.as<uint32_t>(); rp.pixelOffset = s->pixelOffset.as<uint64_t>(); rp.nPix = nPix;
     rp.maxDepth = o.max_depth; rp.rrThreshold = o.rr_threshold;
+    rp.invSqrtSpp = 1 / std::sqrt((float)spp);      // ScaleDifferentials' factor, core/integrator.cpp:288-289
     const bool wantPixelStats = (desc->flags & HPRT_RENDER_PIXEL_STATS) != 0;
     const bool count = (desc->flags & HPRT_RENDER_COUNT_WORK) != 0 || wantPixelStats;
     uint32_t *pixelStats = nullptr;

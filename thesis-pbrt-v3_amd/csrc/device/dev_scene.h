@@ -51,11 +51,16 @@ __host__ __device__ inline int32_t hit_prim(int32_t word) { return word < 0 ? wo
 enum : int32_t { REF_NONE = (int32_t)0x80000000, REF_EXIT = (int32_t)0x80000001 };
 
 enum : uint32_t { TAG_KIND_MASK = 3u, TAG_SPHERE = 1u, TAG_INSTANCE = 2u, TAG_BOGUS = 4u, TAG_LAST = 8u,
-                  TAG_PLASTIC = 16u };   // triangle of a plastic material: the shading bin without chasing shape -> material
+                  TAG_PLASTIC = 16u,     // triangle of a plastic material: the shading bin without chasing shape -> material
+                  TAG_GENERIC = 32u };   // triangle whose material has an image texture: shaded by the generic variant
+// (TAG_PLASTIC | TAG_GENERIC) << 24 are the hit word's HIT_PLASTIC | HIT_GENERIC
 enum : uint32_t { SHAPE_FLIP = 1u, SHAPE_HAS_N = 2u, SHAPE_HAS_UV = 4u, SHAPE_HAS_S = 8u, SHAPE_REVERSE = 16u };
 
 struct DevShape { int32_t material, areaLight; uint32_t flags; int32_t sphere; };
-struct DevMaterial { int32_t type; float Kd[3]; float Ks[3]; float alpha; };   // alpha: RoughnessToAlpha applied on the host
+struct DevMaterial { int32_t type; float Kd[3]; float Ks[3]; float alpha; int32_t KdTex, KsTex; };   // alpha: RoughnessToAlpha applied on the host; *Tex: image texture or -1
+// ImageTexture + MIPMap (textures/imagemap.h, core/mipmap.h): levels are consecutive in mipLevels, texels hold 3 floats each
+struct DevMipLevel { uint32_t offset; int32_t w, h; };
+struct DevTexture { uint32_t firstLevel, nLevels; int32_t trilinear, wrap; float maxAniso, su, sv, du, dv; };
 struct DevLight { int32_t type; float pos[3]; float I[3]; int32_t shape; int32_t twoSided; int32_t sphere; uint32_t shapeFlags; };
 struct DevSphere { mat4 o2w, w2o; float radius, zMin, zMax, thetaMin, thetaMax, phiMax; };
 // ObjectInstance: the wrapped aggregate's entry (pair index, or ~primitive when the object holds a
@@ -71,6 +76,7 @@ struct DevScene {
     const DevShape *shapes; uint32_t nShapes;
     const DevMaterial *materials;
     const DevLight *lights; uint32_t nLights;
+    const DevTexture *textures; const DevMipLevel *mipLevels; const float *texels; const float *weightLut;   // image textures; weightLut: MIPMap::weightLut[128]
     const DevSphere *spheres;
     const DevInstance *instances; uint32_t nInstances;
     const float *lightFunc, *lightCdf; float lightFuncInt;      // Distribution1D (core/sampling.h:55-109)

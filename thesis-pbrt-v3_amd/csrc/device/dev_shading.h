@@ -107,7 +107,7 @@ __device__ __forceinline__ float halton_dim(const DevScene &sc, const DevHalton 
 // ---------------------------------------------------------------------------
 // Camera
 // ---------------------------------------------------------------------------
-struct DevCamera { mat4 rasterToCamera, cameraToWorld; float lensRadius, focalDistance; };
+struct DevCamera { mat4 rasterToCamera, cameraToWorld; float lensRadius, focalDistance; vec3 dxCamera, dyCamera; };   // d*Camera: cameras/perspective.cpp:55-58
 
 // core/sampling.cpp:113-130
 __device__ __forceinline__ void concentric_disk(float ux, float uy, float *dx, float *dy) {
@@ -139,10 +139,39 @@ __device__ __forceinline__ void camera_ray(const DevCamera &cam, float fx, float
     out->o = o; out->d = d; out->tMax = tMax;
 }
 
+// The offset rays of GenerateRayDifferential (cameras/perspective.cpp:117-143), in world space
+// (Transform::operator()(const RayDifferential &), core/transform.h:266-275); image textures only.
+struct DevRayDiff { vec3 rxO, ryO, rxD, ryD; };
+__device__ __forceinline__ void camera_ray_diff(const DevCamera &cam, float fx, float fy, float lu, float lv, DevRayDiff *rd) {
+    const vec3 pCamera = xf_point(cam.rasterToCamera, vec3(fx, fy, 0));
+    vec3 rxO(0, 0, 0), ryO(0, 0, 0), rxD, ryD;
+    if (cam.lensRadius > 0) {
+        float cx, cy; concentric_disk(lu, lv, &cx, &cy);
+        const float lx = cam.lensRadius * cx, ly = cam.lensRadius * cy;
+        const vec3 dx = normalize(pCamera + cam.dxCamera);
+        float ft = cam.focalDistance / dx.z;
+        vec3 pFocus = vec3(0, 0, 0) + (ft * dx);
+        rxO = vec3(lx, ly, 0);
+        rxD = normalize(pFocus - rxO);
+        const vec3 dy = normalize(pCamera + cam.dyCamera);
+        ft = cam.focalDistance / dy.z;
+        pFocus = vec3(0, 0, 0) + (ft * dy);
+        ryO = vec3(lx, ly, 0);
+        ryD = normalize(pFocus - ryO);
+    } else {
+        rxD = normalize(pCamera + cam.dxCamera);
+        ryD = normalize(pCamera + cam.dyCamera);
+    }
+    rd->rxO = xf_point(cam.cameraToWorld, rxO); rd->ryO = xf_point(cam.cameraToWorld, ryO);
+    rd->rxD = xf_vector(cam.cameraToWorld, rxD); rd->ryD = xf_vector(cam.cameraToWorld, ryD);
+}
+
 // ---------------------------------------------------------------------------
 // Surface interaction
 // ---------------------------------------------------------------------------
 struct DevSI { vec3 p, pErr, wo, n, ns, sdpdu; int32_t shape; };   // ns = shading.n, sdpdu = shading.dpdu
+// what image textures additionally need of the interaction: (u,v) and the parametric derivatives
+struct DevTexGeom { vec3 dpdu, dpdv; float u, v; };
 
 // SurfaceInteraction::SetShadingGeometry with orientationIsAuthoritative (core/interaction.cpp:72-91)
 __device__ __forceinline__ void set_shading(DevSI *si, vec3 dpdus, vec3 dpdvs, bool flip) {
@@ -153,7 +182,8 @@ __device__ __forceinline__ void set_shading(DevSI *si, vec3 dpdus, vec3 dpdvs, b
 }
 // Triangle::Intersect fill part, shapes/triangle.cpp:294-425.  The degenerate
 // (bogus) case was rejected during traversal via TAG_BOGUS.
-__device__ __forceinline__ void fill_triangle(const DevScene &sc, uint32_t prim, float b0, float b1, float b2, vec3 rayD, DevSI *si) {
+__device__ __forceinline__ void fill_triangle(const DevScene &sc, uint32_t prim, float b0, float b1, float b2, vec3 rayD, DevSI *si,
+                                              DevTexGeom *tg = nullptr) {
     const float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
     const vec3 p0(v0.x, v0.y, v0.z), p1(v1.x, v1.y, v1.z), p2(v2.x, v2.y, v2.z);
     const int shapeId = (int)__float_as_uint(v1.w);
@@ -190,6 +220,10 @@ __device__ __forceinline__ void fill_triangle(const DevScene &sc, uint32_t prim,
     si->n = normalize(cross(dp02, dp12));
     si->ns = si->n;
     si->sdpdu = dpdu;
+    if (tg) {      // uvHit = b0 * uv[0] + b1 * uv[1] + b2 * uv[2] (shapes/triangle.cpp:328)
+        tg->dpdu = dpdu; tg->dpdv = dpdv;
+        tg->u = b0 * uv0x + b1 * uv1x + b2 * uv2x; tg->v = b0 * uv0y + b1 * uv1y + b2 * uv2y;
+    }
     if (sh.flags & (SHAPE_HAS_N | SHAPE_HAS_S)) {
         vec3 ns;
         if (sh.flags & SHAPE_HAS_N) {
@@ -216,7 +250,7 @@ __device__ __forceinline__ void fill_triangle(const DevScene &sc, uint32_t prim,
 // Sphere::Intersect fill part + (*ObjectToWorld)(SurfaceInteraction)
 // (shapes/sphere.cpp:106-157, core/transform.cpp:262-297).  Returns false if the
 // quadric test fails (cannot happen for a primitive the traversal reported).
-__device__ __noinline__ bool fill_sphere(const DevScene &sc, int shapeId, const DRay &r, DevSI *si, float *tOut) {
+__device__ __noinline__ bool fill_sphere(const DevScene &sc, int shapeId, const DRay &r, DevSI *si, float *tOut, DevTexGeom *tg = nullptr) {
     const DevShape sh = sc.shapes[shapeId];
     const DevSphere &s = sc.spheres[sh.sphere];
     DRay ray; vec3 pHit; float phi, t;
@@ -241,6 +275,12 @@ __device__ __noinline__ bool fill_sphere(const DevScene &sc, int shapeId, const 
     si->sdpdu = xf_vector(s.o2w, dpdu);
     si->ns = face_forward(si->ns, si->n);
     si->shape = shapeId;
+    if (tg) {      // u = phi / phiMax, v = (theta - thetaMin) / (thetaMax - thetaMin) (shapes/sphere.cpp:108-110)
+        phi = det_atan2f(pHit.y, pHit.x);      // sphere_test skips phi where the clipping test does not need it
+        if (phi < 0) phi += 2 * HPRT_PI;
+        tg->u = phi / s.phiMax; tg->v = (theta - s.thetaMin) / (s.thetaMax - s.thetaMin);
+        tg->dpdu = xf_vector(s.o2w, dpdu); tg->dpdv = xf_vector(s.o2w, dpdv);
+    }
     *tOut = t;
     return true;
 }
@@ -367,16 +407,128 @@ __device__ __forceinline__ float mf_pdf(const DevBsdf &b, vec3 wo, vec3 wi) {
 
 // materials/matte.cpp:45-62, materials/plastic.cpp:45-70: lobes are added in the order
 // diffuse, specular; a black reflectance adds no lobe.
-__device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, DevBsdf *b) {
+// ---- image textures: SurfaceInteraction::ComputeDifferentials (core/interaction.cpp:103-149, the (u,v) part),
+// UVMapping2D::Map (core/texture.cpp:93-99), MIPMap lookups (core/mipmap.h:203-338) -------------------------------
+struct DevUvDiff { float dudx, dvdx, dudy, dvdy; };
+__device__ __forceinline__ bool solve2x2(float a00, float a01, float a10, float a11, float b0, float b1, float *x0, float *x1) {   // core/transform.cpp:41-49
+    const float det = a00 * a11 - a01 * a10;
+    if (fabsf(det) < 1e-10f) return false;
+    *x0 = (a11 * b0 - a01 * b1) / det;
+    *x1 = (a00 * b1 - a10 * b0) / det;
+    if (is_nan(*x0) || is_nan(*x1)) return false;
+    return true;
+}
+__device__ __forceinline__ void compute_differentials(const DevSI &si, const DevTexGeom &tg, const DevRayDiff &rd, DevUvDiff *o) {
+    o->dudx = o->dvdx = o->dudy = o->dvdy = 0.f;
+    const vec3 n = si.n, p = si.p;
+    const float d = dot(n, vec3(p.x, p.y, p.z));
+    const float tx = -(dot(n, rd.rxO) - d) / dot(n, rd.rxD);
+    if (is_inf(tx) || is_nan(tx)) return;
+    const vec3 px = rd.rxO + tx * rd.rxD;
+    const float ty = -(dot(n, rd.ryO) - d) / dot(n, rd.ryD);
+    if (is_inf(ty) || is_nan(ty)) return;
+    const vec3 py = rd.ryO + ty * rd.ryD;
+    int d0, d1;
+    if (fabsf(n.x) > fabsf(n.y) && fabsf(n.x) > fabsf(n.z)) { d0 = 1; d1 = 2; }
+    else if (fabsf(n.y) > fabsf(n.z)) { d0 = 0; d1 = 2; }
+    else { d0 = 0; d1 = 1; }
+    const float a00 = tg.dpdu.get(d0), a01 = tg.dpdv.get(d0), a10 = tg.dpdu.get(d1), a11 = tg.dpdv.get(d1);
+    if (!solve2x2(a00, a01, a10, a11, px.get(d0) - p.get(d0), px.get(d1) - p.get(d1), &o->dudx, &o->dvdx)) o->dudx = o->dvdx = 0.f;
+    if (!solve2x2(a00, a01, a10, a11, py.get(d0) - p.get(d0), py.get(d1) - p.get(d1), &o->dudy, &o->dvdy)) o->dudy = o->dvdy = 0.f;
+}
+__device__ __forceinline__ int mod_i(int a, int b) { const int r = a - (a / b) * b; return r < 0 ? r + b : r; }
+__device__ __forceinline__ rgb mip_texel(const DevScene &sc, const DevTexture &tx, int level, int s, int t) {
+    const DevMipLevel l = sc.mipLevels[tx.firstLevel + level];
+    if (tx.wrap == 0) { s = mod_i(s, l.w); t = mod_i(t, l.h); }
+    else if (tx.wrap == 2) { s = s < 0 ? 0 : (s > l.w - 1 ? l.w - 1 : s); t = t < 0 ? 0 : (t > l.h - 1 ? l.h - 1 : t); }
+    else if (s < 0 || s >= l.w || t < 0 || t >= l.h) return rgb(0.f);
+    const float *p = sc.texels + l.offset + 3 * ((size_t)t * l.w + s);
+    return rgb(p[0], p[1], p[2]);
+}
+__device__ __forceinline__ rgb mip_triangle(const DevScene &sc, const DevTexture &tx, int level, float su, float sv) {
+    level = level < 0 ? 0 : (level > (int)tx.nLevels - 1 ? (int)tx.nLevels - 1 : level);
+    const DevMipLevel l = sc.mipLevels[tx.firstLevel + level];
+    const float s = su * l.w - 0.5f, t = sv * l.h - 0.5f;
+    const int s0 = (int)floorf(s), t0 = (int)floorf(t);
+    const float ds = s - s0, dt = t - t0;
+    return (1 - ds) * (1 - dt) * mip_texel(sc, tx, level, s0, t0) + (1 - ds) * dt * mip_texel(sc, tx, level, s0, t0 + 1) +
+           ds * (1 - dt) * mip_texel(sc, tx, level, s0 + 1, t0) + ds * dt * mip_texel(sc, tx, level, s0 + 1, t0 + 1);
+}
+__device__ __forceinline__ float log2_f(float x) { const float invLog2 = 1.442695040888963387004650940071; return det_logf(x) * invLog2; }   // core/pbrt.h:328-331
+__device__ __forceinline__ rgb lerp_rgb(float t, rgb a, rgb b) { return (1 - t) * a + t * b; }
+__device__ __noinline__ rgb mip_ewa(const DevScene &sc, const DevTexture &tx, int level, float su, float sv, float d0x, float d0y, float d1x, float d1y) {
+    if (level >= (int)tx.nLevels) return mip_texel(sc, tx, (int)tx.nLevels - 1, 0, 0);
+    const DevMipLevel l = sc.mipLevels[tx.firstLevel + level];
+    su = su * l.w - 0.5f; sv = sv * l.h - 0.5f;
+    d0x *= l.w; d0y *= l.h; d1x *= l.w; d1y *= l.h;
+    float A = d0y * d0y + d1y * d1y + 1;
+    float B = -2 * (d0x * d0y + d1x * d1y);
+    float C = d0x * d0x + d1x * d1x + 1;
+    const float invF = 1 / (A * C - B * B * 0.25f);
+    A *= invF; B *= invF; C *= invF;
+    const float det = -B * B + 4 * A * C;
+    const float invDet = 1 / det;
+    const float uSqrt = sqrtf(det * C), vSqrt = sqrtf(A * det);
+    const int s0 = (int)ceilf(su - 2 * invDet * uSqrt), s1 = (int)floorf(su + 2 * invDet * uSqrt);
+    const int t0 = (int)ceilf(sv - 2 * invDet * vSqrt), t1 = (int)floorf(sv + 2 * invDet * vSqrt);
+    rgb sum(0.f);
+    float sumWts = 0;
+    for (int it = t0; it <= t1; ++it) {
+        const float tt = it - sv;
+        for (int is = s0; is <= s1; ++is) {
+            const float ss = is - su;
+            const float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
+            if (r2 < 1) {
+                int index = (int)(r2 * 128); if (index > 127) index = 127;
+                const float weight = sc.weightLut[index];
+                sum = sum + mip_texel(sc, tx, level, is, it) * weight;
+                sumWts += weight;
+            }
+        }
+    }
+    return sum / sumWts;
+}
+// ImageTexture::Evaluate (textures/imagemap.h:82-89): UVMapping2D::Map, then MIPMap::Lookup(st, dstdx, dstdy)
+__device__ __noinline__ rgb eval_image_texture(const DevScene &sc, int texId, const DevTexGeom &tg, const DevUvDiff &uv) {
+    const DevTexture tx = sc.textures[texId];
+    float d0x = tx.su * uv.dudx, d0y = tx.sv * uv.dvdx, d1x = tx.su * uv.dudy, d1y = tx.sv * uv.dvdy;
+    const float su = tx.su * tg.u + tx.du, sv = tx.sv * tg.v + tx.dv;
+    if (tx.trilinear) {
+        const float width = 2 * sel_max(sel_max(fabsf(d0x), fabsf(d0y)), sel_max(fabsf(d1x), fabsf(d1y)));
+        const float level = (int)tx.nLevels - 1 + log2_f(sel_max(width, (float)1e-8));
+        if (level < 0) return mip_triangle(sc, tx, 0, su, sv);
+        else if (level >= (int)tx.nLevels - 1) return mip_texel(sc, tx, (int)tx.nLevels - 1, 0, 0);
+        const int iLevel = (int)floorf(level);
+        const float delta = level - iLevel;
+        return lerp_rgb(delta, mip_triangle(sc, tx, iLevel, su, sv), mip_triangle(sc, tx, iLevel + 1, su, sv));
+    }
+    if (d0x * d0x + d0y * d0y < d1x * d1x + d1y * d1y) { float t; t = d0x; d0x = d1x; d1x = t; t = d0y; d0y = d1y; d1y = t; }
+    const float majorLength = sqrtf(d0x * d0x + d0y * d0y);
+    float minorLength = sqrtf(d1x * d1x + d1y * d1y);
+    if (minorLength * tx.maxAniso < majorLength && minorLength > 0) {
+        const float scale = majorLength / (minorLength * tx.maxAniso);
+        d1x *= scale; d1y *= scale;
+        minorLength *= scale;
+    }
+    if (minorLength == 0) return mip_triangle(sc, tx, 0, su, sv);
+    const float lod = sel_max((float)0, (int)tx.nLevels - (float)1 + log2_f(minorLength));
+    const int ilod = (int)floorf(lod);
+    const rgb a = mip_ewa(sc, tx, ilod, su, sv, d0x, d0y, d1x, d1y), b = mip_ewa(sc, tx, ilod + 1, su, sv, d0x, d0y, d1x, d1y);
+    return lerp_rgb(lod - ilod, a, b);
+}
+
+// kdOverride / ksOverride: evaluated image textures of the material's Kd / Ks (null: the constants)
+__device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, DevBsdf *b, const rgb *kdOverride = nullptr,
+                                          const rgb *ksOverride = nullptr) {
     b->ns = si.ns; b->ng = si.n;
     b->ss = normalize(si.sdpdu);
     b->ts = cross(b->ns, b->ss);
     b->alpha = 0; b->hasD = false; b->hasS = false; b->Rd = rgb(0.f); b->Rs = rgb(0.f);
     const DevMaterial m = sc.materials[sc.shapes[si.shape].material];
-    rgb kd = clamp0(rgb(m.Kd[0], m.Kd[1], m.Kd[2]));
+    rgb kd = clamp0(kdOverride ? *kdOverride : rgb(m.Kd[0], m.Kd[1], m.Kd[2]));
     if (!is_black(kd)) { b->hasD = true; b->Rd = kd; }
     if (m.type == 1) {
-        rgb ks = clamp0(rgb(m.Ks[0], m.Ks[1], m.Ks[2]));
+        rgb ks = clamp0(ksOverride ? *ksOverride : rgb(m.Ks[0], m.Ks[1], m.Ks[2]));
         if (!is_black(ks)) { b->hasS = true; b->Rs = ks; b->alpha = m.alpha; }
     }
 }

@@ -43,6 +43,7 @@ struct RenderParams {
     uint32_t nPix;
     int32_t maxDepth;
     float rrThreshold;
+    float invSqrtSpp;               // 1 / sqrt(samplesPerPixel): ray differential scale (image textures only)
 };
 struct FilmGeom {
     int32_t cx0, cy0, cx1, cy1;     // croppedPixelBounds

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                                          vec3(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
                                          vec3(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z)), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
                                 if (ANY_HIT) { hit = true; done = true; }
-                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)(pi | ((tag & TAG_PLASTIC) ? HIT_PLASTIC : 0u) | (INST && inst >= 0 ? HIT_GENERIC : 0u)); hb0 = b0; hb1 = b1; hb2 = b2; if (INST) { hitInst = inst; instHit = inst >= 0; } }
+                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)(pi | ((tag & (TAG_PLASTIC | TAG_GENERIC)) << 24) | (INST && inst >= 0 ? HIT_GENERIC : 0u)); hb0 = b0; hb1 = b1; hb2 = b2; if (INST) { hitInst = inst; instHit = inst >= 0; } }
                             }
                             if (done) cur = REF_NONE;
                             else if (tag & TAG_LAST) cur = pop();
@@ -534,7 +534,9 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
 // Specialised variants (MODE 0/1) run 512-thread workgroups (BS) so that queue appends cost one
 // atomic per queue and workgroup; the rare generic variant keeps 256 threads (it needs more
 // registers than a larger workgroup can have).
-template <int MODE, int BS>
+// TEX: scenes with image textures get their own instance of the generic variant (the lookups cost registers and a
+// call stack that every other scene would pay for in occupancy).
+template <int MODE, int BS, bool TEX = false>
 __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, PathStream in, HitStream hit, uint32_t s0,
                                                PathStream out, VertexStreams vs, QueueSet q, BinSet bins, float4 *Lfinal) {
     __shared__ HaltonLds hl;
@@ -564,6 +566,8 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
         rgb L(L4.x, L4.y, L4.z);
         const bool found = prim >= 0;
         DevSI si;
+        DevTexGeom tg;
+        constexpr bool texScene = MODE == 2 && TEX;      // image textures: the generic variant only
         if (found) {
             const float4 v0 = sc.tris[3 * prim];
             const float2 hitB = hit.b[slot];
@@ -584,10 +588,10 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                 }
             }
             if (MODE != 2 || (__float_as_uint(v0.w) & TAG_KIND_MASK) == 0u)
-                fill_triangle(sc, (uint32_t)prim, hitA.z, hitA.w, hitB.x, r0.d, &si);
+                fill_triangle(sc, (uint32_t)prim, hitA.z, hitA.w, hitB.x, r0.d, &si, texScene ? &tg : nullptr);
             else {
                 float tt;
-                fill_sphere(sc, (int)__float_as_uint(sc.tris[3 * prim + 1].w), r0, &si, &tt);
+                fill_sphere(sc, (int)__float_as_uint(sc.tris[3 * prim + 1].w), r0, &si, &tt, texScene ? &tg : nullptr);
             }
             if (MODE == 2 && inst >= 0 && !sc.instances[inst].identity) {
                 // Transform::operator()(const SurfaceInteraction &), core/transform.cpp:262-297
@@ -599,6 +603,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                 si.ns = normalize(xf_normal(in.w2i, si.ns));
                 si.sdpdu = xf_vector(in.i2w, si.sdpdu);
                 si.ns = face_forward(si.ns, si.n);
+                if (texScene) { tg.dpdu = xf_vector(in.i2w, tg.dpdu); tg.dpdv = xf_vector(in.i2w, tg.dpdv); }
             }
             // emitted radiance at the first vertex (path.cpp:97-107; no specular lobes exist here).
             // Triangle meshes carry no area lights in this build, so only the generic variant looks.
@@ -615,7 +620,32 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
         }
         if (found && bounces < rp.maxDepth) {
             DevBsdf bsdf;
-            bsdf_init(sc, si, &bsdf);
+            bool useKd = false, useKs = false;
+            rgb kdTex, ksTex;
+            if (texScene) {
+                const DevMaterial m = sc.materials[sc.shapes[si.shape].material];
+                if (m.KdTex >= 0 || m.KsTex >= 0) {
+                    // SurfaceInteraction::ComputeDifferentials (core/interaction.cpp:103-149): only the camera ray carries
+                    // differentials (RayDifferential(const Ray &) clears them for every spawned ray, core/geometry.h:1213-1216)
+                    DevUvDiff uvd; uvd.dudx = uvd.dvdx = uvd.dudy = uvd.dvdy = 0.f;
+                    if (bounces == 0) {
+                        const float u0 = halton_dim(sc, rp.hal, index, 0, &hl), u1 = halton_dim(sc, rp.hal, index, 1, &hl);
+                        const uint32_t pxy = rp.pixelXY[pix];
+                        const float fx = (float)(int)(pxy & 0xffffu) + u0, fy = (float)(int)(pxy >> 16) + u1;
+                        float lu = 0.f, lv = 0.f;
+                        if (rp.cam.lensRadius > 0) { lu = halton_dim(sc, rp.hal, index, 3, &hl); lv = halton_dim(sc, rp.hal, index, 4, &hl); }
+                        DevRayDiff rd;
+                        camera_ray_diff(rp.cam, fx, fy, lu, lv, &rd);
+                        const float s = rp.invSqrtSpp;      // RayDifferential::ScaleDifferentials, core/geometry.h:1222-1227
+                        rd.rxO = rayO + (rd.rxO - rayO) * s; rd.ryO = rayO + (rd.ryO - rayO) * s;
+                        rd.rxD = rayD + (rd.rxD - rayD) * s; rd.ryD = rayD + (rd.ryD - rayD) * s;
+                        compute_differentials(si, tg, rd, &uvd);
+                    }
+                    if (m.KdTex >= 0) { kdTex = eval_image_texture(sc, m.KdTex, tg, uvd); useKd = true; }
+                    if (m.KsTex >= 0) { ksTex = eval_image_texture(sc, m.KsTex, tg, uvd); useKs = true; }
+                }
+            }
+            bsdf_init(sc, si, &bsdf, useKd ? &kdTex : nullptr, useKs ? &ksTex : nullptr);
             if (MODE == 0) { bsdf.hasS = false; bsdf.Rs = rgb(0.f); bsdf.alpha = 0.f; }   // matte: no microfacet lobe (matte.cpp:45-62)
             // ---- direct lighting (UniformSampleOneLight + EstimateDirect) ----
             if (bsdf_num(bsdf) > 0 && sc.nLights > 0) {
@@ -953,7 +983,7 @@ void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParam
     dim3 grid(blocks_for(gridItems, bs)), block(bs);
 #define HPRT_SHADE_LAUNCH(M, B) hipLaunchKernelGGL((k_shade<M, B>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal)
 #define HPRT_SHADE_PICK(M) switch (shadeCfg) { case 0: HPRT_SHADE_LAUNCH(M, 1024); break; case 1: HPRT_SHADE_LAUNCH(M, 512); break; default: HPRT_SHADE_LAUNCH(M, 256); break; }
-    if (mode == 2) HPRT_SHADE_LAUNCH(2, 256);
+    if (mode == 2) { if (sc.textures) hipLaunchKernelGGL((k_shade<2, 256, true>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal); else HPRT_SHADE_LAUNCH(2, 256); }
     else if (mode == 0) { HPRT_SHADE_PICK(0) }
     else { HPRT_SHADE_PICK(1) }
 #undef HPRT_SHADE_PICK

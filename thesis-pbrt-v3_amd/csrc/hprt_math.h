@@ -239,6 +239,7 @@ struct rgb {
 HPRT_HD rgb operator+(rgb a, rgb b) { return rgb(a.r + b.r, a.g + b.g, a.b + b.b); }
 HPRT_HD rgb operator*(rgb a, rgb b) { return rgb(a.r * b.r, a.g * b.g, a.b * b.b); }
 HPRT_HD rgb operator*(rgb a, float s) { return rgb(a.r * s, a.g * s, a.b * s); }
+HPRT_HD rgb operator*(float s, rgb a) { return rgb(a.r * s, a.g * s, a.b * s); }
 HPRT_HD rgb operator/(rgb a, float s) { return rgb(a.r / s, a.g / s, a.b / s); }   // spectrum.h:181-187: true divide
 HPRT_HD bool is_black(rgb a) { return a.r == 0.f && a.g == 0.f && a.b == 0.f; }
 HPRT_HD float max_value(rgb a) { float m = a.r; m = sel_max(m, a.g); m = sel_max(m, a.b); return m; }
