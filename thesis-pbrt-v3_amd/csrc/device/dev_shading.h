@@ -35,17 +35,33 @@ __device__ __forceinline__ uint64_t reverse_bits64(uint64_t n) {
 // LDS variant of the scrambled form: invBase = 1/(float)base and the infinite-tail term
 // invBase*perm[0]/(1-invBase) depend on the dimension only, so they are evaluated once per
 // block by halton_lds_load (same float operations, same values) instead of once per sample.
-__device__ __forceinline__ float scrambled_radical_inverse_lds(uint32_t base, uint64_t M, uint64_t a, const uint16_t *perm, float invBase, float tail) {
+__device__ __forceinline__ float scrambled_radical_inverse_lds(uint32_t base, uint64_t M, uint32_t m32, uint64_t a, const uint16_t *perm, float invBase, float tail) {
     uint64_t reversedDigits = 0;
     float invBaseN = 1;
-    while (a) {
-        uint64_t next;
-        if (a <= 0xffffffffull) next = div_magic32((uint32_t)a, M);
-        else next = a / base;
-        uint32_t digit = (uint32_t)(a - next * base);
-        reversedDigits = reversedDigits * base + (uint32_t)perm[digit];
-        invBaseN *= invBase;
-        a = next;
+    if (a <= 0xffffffffull) {
+        // 32-bit digit loop (every index below 2^32: e.g. up to 138,000 spp at the 128x128 Halton period).
+        // q = mulhi(a, floor(2^32 / base)) is floor(a / base) or one less, fixed by one compare; the remainder is the
+        // digit.  reversedDigits stays below 2^32 until the last digit is appended (it has one digit less than a
+        // had, and a < 2^32), so each step is one 32 x 32 + 64 multiply-add.
+        uint32_t a32 = (uint32_t)a;
+        while (a32) {
+            uint32_t q = __umulhi(a32, m32);
+            uint32_t digit = a32 - q * base;
+            if (digit >= base) { digit -= base; q += 1u; }
+            reversedDigits = (uint64_t)(uint32_t)reversedDigits * (uint64_t)base + (uint64_t)perm[digit];
+            invBaseN *= invBase;
+            a32 = q;
+        }
+    } else {
+        while (a) {
+            uint64_t next;
+            if (a <= 0xffffffffull) next = div_magic32((uint32_t)a, M);
+            else next = a / base;
+            uint32_t digit = (uint32_t)(a - next * base);
+            reversedDigits = reversedDigits * base + (uint32_t)perm[digit];
+            invBaseN *= invBase;
+            a = next;
+        }
     }
     // (float)uint64: a value below 2^32 converts identically through the 32-bit instruction
     const float rd = (reversedDigits >> 32) == 0ull ? (float)(uint32_t)reversedDigits : (float)reversedDigits;
@@ -78,6 +94,7 @@ __device__ __forceinline__ float radical_inverse_base(uint32_t base, uint64_t M,
 #define HPRT_HALTON_LDS_PERMS 8893
 struct HaltonLds {
     uint64_t magic[HPRT_HALTON_LDS_DIMS];
+    uint32_t magic32[HPRT_HALTON_LDS_DIMS];      // floor(2^32 / prime)
     int32_t prime[HPRT_HALTON_LDS_DIMS];
     int32_t primeSum[HPRT_HALTON_LDS_DIMS];
     float invBase[HPRT_HALTON_LDS_DIMS];
@@ -86,7 +103,7 @@ struct HaltonLds {
 };
 __device__ __forceinline__ void halton_lds_load(const DevScene &sc, HaltonLds *h) {
     for (int i = threadIdx.x; i < HPRT_HALTON_LDS_DIMS; i += blockDim.x) {
-        h->magic[i] = sc.primeMagic[i]; h->prime[i] = sc.primes[i]; h->primeSum[i] = sc.primeSums[i];
+        h->magic[i] = sc.primeMagic[i]; h->magic32[i] = (uint32_t)(0x100000000ull / (uint64_t)(uint32_t)sc.primes[i]); h->prime[i] = sc.primes[i]; h->primeSum[i] = sc.primeSums[i];
         const float invBase = 1.0f / (float)sc.primes[i];
         h->invBase[i] = invBase;
         h->tail[i] = invBase * (float)sc.perms[sc.primeSums[i]] / (1 - invBase);   // invBase * perm[0] / (1 - invBase)
@@ -100,7 +117,7 @@ __device__ __forceinline__ float halton_dim(const DevScene &sc, const DevHalton 
     if (dim == 0) return (float)((double)reverse_bits64(index >> h.baseExp0) * 0x1p-64);
     if (dim == 1) return radical_inverse_base<const uint16_t *>(3u, sc.primeMagic[1], index / (uint64_t)h.baseScale1, nullptr, false);
     if (lds && dim < HPRT_HALTON_LDS_DIMS)
-        return scrambled_radical_inverse_lds((uint32_t)lds->prime[dim], lds->magic[dim], index, lds->perm + lds->primeSum[dim], lds->invBase[dim], lds->tail[dim]);
+        return scrambled_radical_inverse_lds((uint32_t)lds->prime[dim], lds->magic[dim], lds->magic32[dim], index, lds->perm + lds->primeSum[dim], lds->invBase[dim], lds->tail[dim]);
     return radical_inverse_base<const uint16_t *>((uint32_t)sc.primes[dim], sc.primeMagic[dim], index, sc.perms + sc.primeSums[dim], true);
 }
 
