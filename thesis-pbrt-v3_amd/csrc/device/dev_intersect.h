@@ -186,5 +186,7 @@ struct TraceCount { unsigned int fetched, entered, tri, sphere, leaf; };   // le
 
 // `cur` of a lane: >= 0 interior pair, REF_NONE finished, REF_EXIT leaving an instance, otherwise ~(parked primitive index)
 __device__ __forceinline__ bool is_parked(int cur) { return (uint32_t)cur > (uint32_t)REF_EXIT; }
+// with object instances: parked primitives and the REF_EXIT sentinel are both handled by the primitive phase
+__device__ __forceinline__ bool wants_prim_phase(int cur) { return (uint32_t)cur >= (uint32_t)REF_EXIT; }
 
 }  // namespace hprt

@@ -173,6 +173,9 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
     const unsigned long long pfStart = PROF ? clock64() : 0ull;
     __shared__ uint2 stackMem[HPRT_LDS_STACK * HPRT_TRACE_BLOCK];     // [entry][thread]: {ref, tMin}
     uint2 *const ldsStack = &stackMem[threadIdx.x];
+    // INST: the world-space ray stays in LDS ([component][thread]) while the lane walks an instance with the transformed one
+    __shared__ float worldRayMem[INST ? 6 * HPRT_TRACE_BLOCK : 1];
+    float *const worldRay = &worldRayMem[INST ? threadIdx.x : 0];
     const uint32_t n = countPtr ? *countPtr : countImm;
     const uint32_t lane = __lane_id();
     // Pairs and primitives are fetched with buffer loads: a 32-bit per-lane byte offset against a
@@ -193,9 +196,9 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
     bool negX = false, negY = false, negZ = false;
     int sp = 0, cur = REF_NONE;
     int32_t prim = -1; float hb0 = 0.f, hb1 = 0.f, hb2 = 0.f;
-    // A parked primitive that is not a triangle waits for the batched slow phase: wait 1 = quadric test,
-    // 2 = entering an object instance (TransformedPrimitive, core/primitive.cpp:77-102); waitInfo = sphere /
-    // instance index | bit 31 "last primitive of its leaf".  cur == REF_EXIT waits there too (leaving one).
+    // A parked quadric waits for the batched slow phase (wait = 1; waitInfo = sphere index | bit 31 "last primitive
+    // of its leaf").  Object instances (TransformedPrimitive, core/primitive.cpp:77-102) are entered in the primitive
+    // phase itself, and left there when the walk pops the REF_EXIT sentinel: both cost about as much as a triangle test.
     uint32_t wait = 0u, waitInfo = 0u;
     int inst = -1, hitInst = -1;          // instance being walked / instance of the closest hit so far
     bool instHit = false;                 // a hit was recorded inside the instance being walked
@@ -270,6 +273,10 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                         shear = ray_shear(rd);
                         sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
                         wait = 0u; inst = -1; hitInst = -1; instHit = false;
+                        if (INST) {
+                            worldRay[0] = ra.x; worldRay[HPRT_TRACE_BLOCK] = ra.y; worldRay[2 * HPRT_TRACE_BLOCK] = ra.z;
+                            worldRay[3 * HPRT_TRACE_BLOCK] = rb.x; worldRay[4 * HPRT_TRACE_BLOCK] = rb.y; worldRay[5 * HPRT_TRACE_BLOCK] = rb.z;
+                        }
                         if (COUNT) { snapEntered = cnt.entered; snapLeaf = cnt.leaf; snapPrim = cnt.tri + cnt.sphere; }
                         active = true;
                     }
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                     }
                 }
                 ++steps;
-                if (steps >= tune.stepLimit || __popcll(__ballot(active && is_parked(cur) && wait == 0u)) >= tune.parkLimit) break;
+                if (steps >= tune.stepLimit || __popcll(__ballot(active && (INST ? wants_prim_phase(cur) : is_parked(cur)) && wait == 0u)) >= tune.parkLimit) break;
             }
             const unsigned long long pfT2 = PROF ? clock64() : 0ull;
             if (PROF) pf[2] += pfT2 - pfT1;
@@ -333,12 +340,27 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
             // different times, so a lane that meets one waits (wait = 1) until `sphereLimit`
             // lanes wait or nothing else can run, and the test runs once for all of them.
             while (true) {
-                const bool pending = active && is_parked(cur) && wait == 0u;
-                const int nPending = __popcll(__ballot(pending));
+                const bool todo = active && (INST ? wants_prim_phase(cur) : is_parked(cur)) && wait == 0u;
+                const int nPending = __popcll(__ballot(todo));
                 // too few parked lanes for a primitive test to pay: let the others walk first
                 if (nPending != 0 && nPending < tune.primMin && __ballot(active && cur >= 0) != 0ull) break;
                 if (nPending != 0) {
-                    if (PROF) { pf[7] += 1; pf[8] += __popcll(__ballot(pending)); }
+                    if (PROF) { pf[7] += 1; pf[8] += nPending; }
+                    if (INST && todo && cur == REF_EXIT) {
+                        // the instance's walk is over, back to world space: r.tMax = ray.tMax only if the instance was
+                        // hit (core/primitive.cpp:85-86); continue with the top-level leaf the instance belongs to
+                        const float worldT = instHit ? rayTMax : savedTMax;
+                        ro = vec3(worldRay[0], worldRay[HPRT_TRACE_BLOCK], worldRay[2 * HPRT_TRACE_BLOCK]);
+                        const vec3 rd(worldRay[3 * HPRT_TRACE_BLOCK], worldRay[4 * HPRT_TRACE_BLOCK], worldRay[5 * HPRT_TRACE_BLOCK]);
+                        invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
+                        negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
+                        shear = ray_shear(rd);
+                        rayTMax = worldT;
+                        inst = -1; instHit = false;
+                        if (instPrim & 0x80000000u) cur = pop();
+                        else cur = ~(int)((instPrim & 0x7fffffffu) + 1u);
+                    }
+                    const bool pending = todo && is_parked(cur);      // (a lane that just left an instance may be at its next primitive)
                     if (pending) {
                         const uint32_t pi = (uint32_t)~cur;
                         u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48, 0, 0);
@@ -361,11 +383,37 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                             if (done) cur = REF_NONE;
                             else if (tag & TAG_LAST) cur = pop();
                             else --cur;                                  // ~(pi + 1)
-                        } else { wait = tag & TAG_KIND_MASK; waitInfo = v2.w | ((tag & TAG_LAST) ? 0x80000000u : 0u); }
+                        } else if (INST && (tag & TAG_KIND_MASK) == TAG_INSTANCE) {
+                            // TransformedPrimitive::Intersect: Ray ray = Inverse(InterpolatedPrimToWorld)(r), i.e.
+                            // Transform::operator()(const Ray &) (core/transform.h:251-264); then walk the object's aggregate
+                            inst = (int)v2.w;
+                            instPrim = pi | ((tag & TAG_LAST) ? 0x80000000u : 0u);
+                            instHit = false;
+                            const DevInstance &in = sc.instances[inst];
+                            vec3 oErr;
+                            vec3 o2 = xf_point_err(in.w2i, ro, &oErr);
+                            const vec3 d2 = xf_vector(in.w2i, vec3(worldRay[3 * HPRT_TRACE_BLOCK], worldRay[4 * HPRT_TRACE_BLOCK], worldRay[5 * HPRT_TRACE_BLOCK]));
+                            const float lengthSquared = d2.x * d2.x + d2.y * d2.y + d2.z * d2.z;
+                            float tm = rayTMax;
+                            if (lengthSquared > 0) {
+                                const float dt = dot(vabs(d2), oErr) / lengthSquared;
+                                o2 = o2 + d2 * dt;
+                                tm -= dt;
+                            }
+                            const uint2 e = make_uint2((uint32_t)REF_EXIT, __float_as_uint(rayTMax));
+                            if (sp < HPRT_LDS_STACK) ldsStack[sp * HPRT_TRACE_BLOCK] = e;
+                            else if (sp < HPRT_LDS_STACK + HPRT_SPILL_STACK) { spillRef[sp - HPRT_LDS_STACK] = e.x; spillT[sp - HPRT_LDS_STACK] = e.y; }
+                            ++sp;       // a full stack cannot take the sentinel: such depths are outside what the reference supports either (64 entries)
+                            ro = o2; rayTMax = tm;
+                            invDir = vec3(1 / d2.x, 1 / d2.y, 1 / d2.z);
+                            negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
+                            shear = ray_shear(d2);
+                            cur = in.root;
+                        } else { wait = 1u; waitInfo = v2.w | ((tag & TAG_LAST) ? 0x80000000u : 0u); }
                     }
                     continue;
                 }
-                const bool slow = active && (wait != 0u || (INST && cur == REF_EXIT));
+                const bool slow = active && wait != 0u;
                 const int nWait = __popcll(__ballot(slow));
                 if (nWait == 0) break;
                 const bool canWalk = __ballot(active && cur >= 0) != 0ull;
@@ -377,7 +425,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                     wait = 0u;
                     if (COUNT) ++cnt.sphere;
                     DRay rr; rr.o = ro; rr.tMax = rayTMax;
-                    { const float4 rb = rays.b[slot]; rr.d = vec3(rb.x, rb.y, rb.z); }
+                    if (INST) rr.d = vec3(worldRay[3 * HPRT_TRACE_BLOCK], worldRay[4 * HPRT_TRACE_BLOCK], worldRay[5 * HPRT_TRACE_BLOCK]);
+                    else { const float4 rb = rays.b[slot]; rr.d = vec3(rb.x, rb.y, rb.z); }
                     if (INST && inst >= 0) rr.d = xf_vector(sc.instances[inst].w2i, rr.d);      // the instance-space direction, recomputed
                     DRay robj; vec3 ph; float phi, t;
                     bool done = false;
@@ -388,50 +437,6 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                     if (done) cur = REF_NONE;
                     else if (waitInfo & 0x80000000u) cur = pop();
                     else --cur;
-                }
-                if (INST && wait == 2u) {
-                    // TransformedPrimitive::Intersect: Ray ray = Inverse(InterpolatedPrimToWorld)(r), i.e.
-                    // Transform::operator()(const Ray &) (core/transform.h:251-264); then walk the object's aggregate
-                    const uint32_t pi = (uint32_t)~cur;
-                    wait = 0u;
-                    inst = (int)(waitInfo & 0x7fffffffu);
-                    instPrim = pi | (waitInfo & 0x80000000u);
-                    instHit = false;
-                    const DevInstance &in = sc.instances[inst];
-                    const float4 rb = rays.b[slot];
-                    vec3 oErr;
-                    vec3 o2 = xf_point_err(in.w2i, ro, &oErr);
-                    const vec3 d2 = xf_vector(in.w2i, vec3(rb.x, rb.y, rb.z));
-                    const float lengthSquared = d2.x * d2.x + d2.y * d2.y + d2.z * d2.z;
-                    float tm = rayTMax;
-                    if (lengthSquared > 0) {
-                        const float dt = dot(vabs(d2), oErr) / lengthSquared;
-                        o2 = o2 + d2 * dt;
-                        tm -= dt;
-                    }
-                    const uint2 e = make_uint2((uint32_t)REF_EXIT, __float_as_uint(rayTMax));
-                    if (sp < HPRT_LDS_STACK) ldsStack[sp * HPRT_TRACE_BLOCK] = e;
-                    else if (sp < HPRT_LDS_STACK + HPRT_SPILL_STACK) { spillRef[sp - HPRT_LDS_STACK] = e.x; spillT[sp - HPRT_LDS_STACK] = e.y; }
-                    ++sp;       // a full stack cannot take the sentinel: such depths are outside what the reference supports either (64 entries)
-                    ro = o2; rayTMax = tm;
-                    invDir = vec3(1 / d2.x, 1 / d2.y, 1 / d2.z);
-                    negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
-                    shear = ray_shear(d2);
-                    cur = in.root;
-                }
-                if (INST && cur == REF_EXIT) {
-                    // back in world space: r.tMax = ray.tMax only if the instance was hit (core/primitive.cpp:85-86)
-                    const float worldT = instHit ? rayTMax : savedTMax;
-                    const float4 ra = rays.a[slot], rb = rays.b[slot];
-                    ro = vec3(ra.x, ra.y, ra.z);
-                    const vec3 rd(rb.x, rb.y, rb.z);
-                    invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
-                    negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
-                    shear = ray_shear(rd);
-                    rayTMax = worldT;
-                    inst = -1; instHit = false;
-                    if (instPrim & 0x80000000u) cur = pop();
-                    else cur = ~(int)((instPrim & 0x7fffffffu) + 1u);
                 }
                 if (PROF) pfSphere += clock64() - pfT3;
             }

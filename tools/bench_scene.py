@@ -1,5 +1,5 @@
 """Frame throughput of an arbitrary scene (not the contract bench: bench.py stays on BASELINE.json's config[1]).
-usage: python tools/bench_scene.py <scene.pbrt | scene.hprt | atrium[:detail]> [--spp N] [--steps K] [--cpu-spp M]
+usage: python tools/bench_scene.py <scene.pbrt | scene.hprt | atrium[:detail] | instanced> [--spp N] [--steps K] [--cpu-spp M]
 Prints one JSON line: ms/frame, Mrays/s, Msamples/s, kernel rates, and the oracle's rate on a sample of the frame."""
 import argparse, importlib, json, os, sys, tempfile, time
 import torch
@@ -16,6 +16,11 @@ if args.scene.startswith("atrium"):
     detail = float(args.scene.split(":")[1]) if ":" in args.scene else 1.0
     text, ntri = scene_gen.atrium(detail)
     path = os.path.join(tmp, "atrium.pbrt"); open(path, "w").write(text)
+    model = hprt.Model.parse(path)
+elif args.scene == "instanced":
+    import scene_gen
+    text, ntri = scene_gen.instanced()
+    path = os.path.join(tmp, "instanced.pbrt"); open(path, "w").write(text)
     model = hprt.Model.parse(path)
 elif args.scene.endswith(".hprt"):
     model = hprt.Model.load(args.scene)

@@ -2,8 +2,9 @@
 assets are not part of its repository: scenes/sponza includes files under scenes/geometry/sponza that do not exist).
 `atrium(n)` writes .pbrt text of a Sponza-class interior: two storeys of arcades around a courtyard — flat walls and
 floors (few large triangles), tessellated round columns and arches (many small ones), wavy curtains — lit by a point
-light as scenes/sponza is, with constant-colour matte/plastic materials (image textures are not built).
-~262 k triangles at the default detail."""
+light as scenes/sponza is, with constant-colour matte/plastic materials.  ~262 k triangles at the default detail.
+`instanced()` writes BASELINE.json config 5's shape: one 10,082-triangle mesh instanced 1,024 times (10.3 M instanced
+triangles, every instance rotated and scaled differently) over a floor, lit by a sphere light."""
 import numpy as np
 
 
@@ -82,3 +83,27 @@ if __name__ == "__main__":
     text, n = atrium(float(sys.argv[2]) if len(sys.argv) > 2 else 1.0)
     open(sys.argv[1], "w").write(text)
     print(n, "triangles")
+
+
+def instanced(xres=700, yres=700, spp=64, maxdepth=5, n_side=32, grid=72):
+    rng = np.random.default_rng(12)
+    xs = np.linspace(-1, 1, grid)
+    P = np.array([[x, y, 0.35 * np.sin(3.1 * x) * np.cos(2.3 * y) + 0.1 * np.sin(7 * x * y)] for y in xs for x in xs], np.float32)
+    idx = []
+    for j in range(grid - 1):
+        for i in range(grid - 1):
+            a = j * grid + i
+            idx += [a, a + 1, a + grid + 1, a, a + grid + 1, a + grid]
+    body = ['AttributeBegin\nMaterial "matte" "color Kd" [0 0 0]\nTranslate 2 -3 6\nAreaLightSource "area" "color L" [40 38 30]\n'
+            'Shape "sphere" "float radius" [0.6]\nAttributeEnd\n',
+            'Material "matte" "color Kd" [.6 .5 .3]\n' + _mesh([[-4, -4, -.4], [4, -4, -.4], [4, 4, -.4], [-4, 4, -.4]], [0, 1, 2, 0, 2, 3]),
+            'Material "plastic" "color Kd" [.2 .3 .5] "color Ks" [.6 .6 .6] "float roughness" [.08]\nObjectBegin "patch"\n' + _mesh(P, idx) + "ObjectEnd\n"]
+    for i in range(n_side * n_side):
+        gx, gy = i % n_side, i // n_side
+        body.append('AttributeBegin\nTranslate %r %r %r\nRotate %r 0 0 1\nScale %r %r %r\nObjectInstance "patch"\nAttributeEnd\n' % (
+            -3.5 + 7.0 * gx / (n_side - 1), -3.5 + 7.0 * gy / (n_side - 1), float(rng.uniform(-0.3, 0.6)), float(rng.uniform(0, 360)),
+            float(rng.uniform(0.08, 0.14)), float(rng.uniform(0.08, 0.14)), float(rng.uniform(0.1, 0.5))))
+    text = ('LookAt 0 -6 3.5  0 0 0.3  0 0 1\nCamera "perspective" "float fov" [40]\n'
+            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]\nSampler "halton" "integer pixelsamples" [%d]\n'
+            'Integrator "path" "integer maxdepth" [%d]\nWorldBegin\n%sWorldEnd\n' % (xres, yres, spp, maxdepth, "".join(body)))
+    return text, n_side * n_side * 2 * (grid - 1) ** 2 + 2

@@ -1,5 +1,6 @@
-"""Phase profile of k_trace (diagnostics): renders killeroo-simple with HPRT_TRACE_PROFILE=1 and prints,
-per kernel variant, where the wave cycles go and how many of the 64 lanes each phase keeps busy."""
+"""Phase profile of k_trace (diagnostics): renders killeroo-simple (or `atrium` / `instanced` of tools/scene_gen.py, 2nd
+argument) with HPRT_TRACE_PROFILE=1 and prints, per kernel variant, where the wave cycles go and how many of the 64 lanes
+each phase keeps busy.  usage: python tools/trace_profile.py [spp] [killeroo|atrium|instanced]"""
 import ctypes as C, importlib, os, sys
 os.environ["HPRT_TRACE_PROFILE"] = "1"
 import torch
@@ -8,7 +9,17 @@ sys.path.insert(0, ROOT)
 hprt = importlib.import_module("thesis-pbrt-v3_amd")
 FIX = os.path.join(ROOT, "tests", "golden", "killeroo_simple.hprt")
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-model = hprt.Model.load(FIX); bvh = hprt.Bvh(model); scene = hprt.Scene(model, bvh, device=0)
+which = sys.argv[2] if len(sys.argv) > 2 else "killeroo"
+if which == "killeroo":
+    model = hprt.Model.load(FIX)
+else:
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scene_gen
+    text, _ = getattr(scene_gen, which)()
+    path = os.path.join(tempfile.mkdtemp(), which + ".pbrt"); open(path, "w").write(text)
+    model = hprt.Model.parse(path)
+bvh = hprt.Bvh(model); scene = hprt.Scene(model, bvh, device=0)
 opt = model.options; opt.spp = spp
 lib = C.CDLL(os.path.join(ROOT, "thesis-pbrt-v3_amd", "lib", "libhprt.so"))
 out = (C.c_ulonglong * 32)()
@@ -16,6 +27,7 @@ scene.render(opt); torch.cuda.synchronize()
 lib.hprt_debug_trace_profile(out, 1)
 film, stats = scene.render(opt); torch.cuda.synchronize()
 lib.hprt_debug_trace_profile(out, 1)
+print("rays %d shadow %d" % (stats["rays"], stats["shadow_rays"]))
 for name, b in (("closest", 0), ("any-hit", 16)):
     v = [int(out[b + k]) for k in range(16)]
     tot = max(1, v[0])
