@@ -199,7 +199,7 @@ class Model:
         return [x for x in w.split("\n") if x]
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:      # (module globals are cleared at interpreter exit)
             lib.hprt_model_destroy(self._h)
             self._h = None
 
@@ -243,7 +243,7 @@ class Bvh:
         return nodes, order
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:      # (module globals are cleared at interpreter exit)
             lib.hprt_bvh_destroy(self._h)
             self._h = None
 
@@ -328,7 +328,7 @@ class Scene:
         return L
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:      # (module globals are cleared at interpreter exit)
             lib.hprt_scene_destroy(self._h)
             self._h = None
 

@@ -828,7 +828,20 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     // ---- sizes ----
     const size_t lallBytes = 3ull * spp * nPix * sizeof(float);
     if (lallBytes > (96ull << 30)) return SetError(HPRT_E_UNSUPPORTED, "per-sample radiance store would exceed 96 GiB; render in several tile ranges");
-    uint32_t chunk = desc->spp_chunk > 0 ? (uint32_t)desc->spp_chunk : std::max<uint32_t>(1u, (uint32_t)((64u << 20) / std::max<uint32_t>(nPix, 1u)));   // ~64 M paths per wavefront batch (22 GB of path streams and queues)
+    // Paths per wavefront batch.  Every launch ends with a tail of half-empty waves and every bounce with a host
+    // read-back, so batches are as large as memory allows: up to 128 M paths (345 B per path of streams and
+    // queues = 46 GB of the 288 GB), less if the device has less free (a third of what is free now).  killeroo-simple
+    // at 256 spp is one batch of 125 M paths: 6.5 % faster than two batches of 64 M.
+    uint32_t chunk;
+    if (desc->spp_chunk > 0) chunk = (uint32_t)desc->spp_chunk;
+    else {
+        size_t freeB = 0, totalB = 0;
+        HIP_TRY(hipMemGetInfo(&freeB, &totalB));
+        freeB += s->planes.bytes + s->queues.bytes;                 // this scene's previous workspace is reused or released
+        const size_t perPath = kPlaneBytesPerSlot + 12 * sizeof(uint32_t);
+        const size_t budget = std::min<size_t>(128ull << 20, std::max<size_t>(freeB / 3 / perPath, 1ull << 20));
+        chunk = std::max<uint32_t>(1u, (uint32_t)(budget / std::max<uint32_t>(nPix, 1u)));
+    }
     chunk = std::min(chunk, spp);
     if ((uint64_t)chunk * nPix > 0x7fffffffull) chunk = (uint32_t)(0x7fffffffull / nPix);
     const size_t maxSlots = (size_t)chunk * nPix;
