@@ -942,8 +942,10 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     dim3 grid(std::min(blocks_for(gridItems, HPRT_TRACE_BLOCK), maxBlocks)), block(HPRT_TRACE_BLOCK);
     // rays per queue-head atomic: large launches take 512 at a time, small ones keep every wave busy
     const uint32_t nWaves = grid.x * (HPRT_TRACE_BLOCK / 64);
-    uint32_t chunk = gridItems / (nWaves * 4u);
-    chunk = std::max(64u, std::min(512u, chunk)) & ~63u;
+    static const uint32_t chunkMax = [] { const char *e = getenv("HPRT_TRACE_CHUNK_MAX"); return e ? (uint32_t)atoi(e) : 512u; }();
+    static const uint32_t chunkDiv = [] { const char *e = getenv("HPRT_TRACE_CHUNK_DIV"); return e ? (uint32_t)atoi(e) : 4u; }();
+    uint32_t chunk = gridItems / (nWaves * chunkDiv);
+    chunk = std::max(64u, std::min(chunkMax, chunk)) & ~63u;
     static const TraceTune tuneClosest = DefaultTraceTune(false), tuneAny = DefaultTraceTune(true);
     const TraceTune tune = anyHit ? tuneAny : tuneClosest;
     static const bool profile = getenv("HPRT_TRACE_PROFILE") != nullptr;
