@@ -170,7 +170,7 @@ class OracleScene:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.orc_scene_free(self._h)
             self._h = None
 

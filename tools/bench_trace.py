@@ -52,3 +52,15 @@ light = np.array([150.0, 120.0, 20.0], np.float32); to_o = p - light
 target = light + to_o / np.linalg.norm(to_o, axis=1, keepdims=True) * np.float32(3.01)
 s7 = to7(p, (target - p).astype(np.float32), np.full(m, np.float32(1) - np.float32(1e-4), np.float32))
 run("shadow any-hit", s7, m, anyhit=True)
+# ---- would reordering bounce rays by direction octant inside blocks of B consecutive rays pay? (diagnostics) ----
+octant = ((v[:, 0] < 0).astype(np.int64) | ((v[:, 1] < 0).astype(np.int64) << 1) | ((v[:, 2] < 0).astype(np.int64) << 2))
+for B in (512, 4096, 65536, m):
+    block = np.arange(m, dtype=np.int64) // B
+    order = np.lexsort((np.arange(m), octant, block))
+    run("bounce octant/%d" % B, to7(p[order], v[order], np.full(m, np.inf, np.float32)), m)
+# 6-bit key: octant + dominant axis
+ax = np.argmax(np.abs(v), axis=1).astype(np.int64)
+for B in (4096, 65536):
+    block = np.arange(m, dtype=np.int64) // B
+    order = np.lexsort((np.arange(m), octant * 3 + ax, block))
+    run("bounce oct+axis/%d" % B, to7(p[order], v[order], np.full(m, np.inf, np.float32)), m)
