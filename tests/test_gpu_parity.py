@@ -115,6 +115,35 @@ def test_render_crop_film_and_counters(hprt, killeroo_model, killeroo_scene, kil
     killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
 
 
+def test_full_size_frame_is_independent_of_batching_and_sharding(killeroo_model, killeroo_scene):
+    """BASELINE.json's config[1] at its full size (700x700, 256 spp, 125 M paths, 737 M rays) is too large for the oracle
+    in test time, so the whole frame is held to size-independent properties: the film and every work counter must not
+    depend on how the samples are cut into wavefront batches (one batch of 125 M paths, or batches of 100 and of 37
+    samples per pixel) nor on how the tiles are cut into shards (three interleaved shards summed, as MergeFilmTile
+    does); the sampled per-sample parity against the oracle is test_per_sample_radiance."""
+    opt = killeroo_model.options.copy()
+    opt.spp = 256                      # the baked fixture carries the 8 spp of the reference's regression image
+    assert (opt.xres, opt.yres) == (700, 700)
+    film_a, st_a = killeroo_scene.render(opt, count_work=True)                       # automatic: one batch
+    film_b, st_b = killeroo_scene.render(opt, count_work=True, spp_chunk=100)         # 100 + 100 + 56
+    film_c, st_c = killeroo_scene.render(opt, count_work=True, spp_chunk=37)
+    keys = ("camera_rays", "rays", "shadow_rays", "nodes_fetched", "nodes_fetched_p", "nodes_entered", "nodes_entered_p",
+            "tri_tests", "tri_tests_p", "sphere_tests", "sphere_tests_p")
+    assert st_a["camera_rays"] == 700 * 700 * 256 and st_a["rays"] + st_a["shadow_rays"] > 7 * 10 ** 8
+    for st in (st_b, st_c):
+        assert [st[k] for k in keys] == [st_a[k] for k in keys]
+    assert np.array_equal(film_a.view(np.uint32), film_b.view(np.uint32)) and np.array_equal(film_a.view(np.uint32), film_c.view(np.uint32))
+    # filterWeightSum (box filter, every weight 1): 256 except where a sample with an exactly-zero or rounded-up offset
+    # also lands in a neighbour (SURVEY.md appendix A.2)
+    w = film_a[..., 3]
+    assert np.isfinite(film_a).all() and (np.abs(w - 256) <= 2).all() and (w == 256).mean() > 0.97, (float(w.min()), float(w.max()), float((w == 256).mean()))
+    total = np.zeros_like(film_a)
+    for r in range(3):
+        part, _ = killeroo_scene.render(opt, tile_begin=r, tile_stride=3)
+        total += part
+    assert np.array_equal(total.view(np.uint32), film_a.view(np.uint32))
+
+
 def _two_rank_worker(rank, world, port, out_path, crop, spp):
     import importlib, os, sys
     import numpy as np
