@@ -379,3 +379,95 @@ def test_image_texture_resampling_and_bake(hprt, tmp_path):
         assert np.array_equal(a, b)
     again = str(tmp_path / "t2.hprt"); m2.save(again)
     assert open(baked, "rb").read() == open(again, "rb").read()
+
+
+# ---- front-end: plymesh, Include, named materials and coordinate systems ----
+def _baked_bytes(hprt, tmp_path, text, name):
+    m = _parse_text(hprt, tmp_path, text, name=name + ".pbrt")
+    assert m.warnings() == [], m.warnings()
+    out = tmp_path / (name + ".hprt")
+    m.save(str(out))
+    return out.read_bytes(), m
+
+
+def _write_ply(path, P, N, UV, faces, fmt):
+    """fmt: ascii | binary_little_endian | binary_big_endian; faces: lists of 3 or 4 vertex ids"""
+    import struct
+    hdr = "ply\nformat %s 1.0\ncomment made by the test\nelement vertex %d\n" % (fmt, len(P))
+    hdr += "property float x\nproperty float y\nproperty float z\n"
+    if N is not None: hdr += "property float nx\nproperty float ny\nproperty float nz\n"
+    if UV is not None: hdr += "property float u\nproperty float v\n"
+    hdr += "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % len(faces)
+    rows = [list(P[i]) + (list(N[i]) if N is not None else []) + (list(UV[i]) if UV is not None else []) for i in range(len(P))]
+    if fmt == "ascii":
+        body = "".join(" ".join("%r" % float(np.float32(v)) for v in r) + "\n" for r in rows)
+        body += "".join("%d %s\n" % (len(f), " ".join(map(str, f))) for f in faces)
+        open(path, "w").write(hdr + body)
+    else:
+        e = "<" if fmt == "binary_little_endian" else ">"
+        body = b"".join(struct.pack(e + "%df" % len(r), *r) for r in rows)
+        body += b"".join(struct.pack(e + "B%di" % len(f), len(f), *f) for f in faces)
+        open(path, "wb").write(hdr.encode() + body)
+
+
+def test_plymesh_equals_inline_trianglemesh(hprt, tmp_path):
+    """shapes/plymesh.cpp:50-152: x y z [nx ny nz] [u v], triangles and quads (a quad becomes (0,1,2) and (3,0,2));
+    the three PLY encodings must bake to the same bytes as the equivalent inline trianglemesh."""
+    rng = np.random.default_rng(4)
+    P = rng.uniform(-1, 1, (7, 3)).astype(np.float32)
+    N = rng.normal(size=(7, 3)).astype(np.float32)
+    UV = rng.uniform(0, 1, (7, 2)).astype(np.float32)
+    faces = [[0, 1, 2], [2, 3, 4, 5], [4, 5, 6], [6, 0, 3, 1]]
+    tri = []
+    for f in faces:
+        tri += f[:3]
+        if len(f) == 4: tri += [f[3], f[0], f[2]]
+    fl = lambda a: " ".join("%r" % float(v) for v in np.asarray(a).ravel())
+    body = 'AttributeBegin\nTranslate 0.5 0 0\nRotate 20 0 1 0\n%s\nAttributeEnd\nWorldEnd\n'
+    inline = 'Shape "trianglemesh" "integer indices" [%s] "point P" [%s] "normal N" [%s] "float uv" [%s]' % (" ".join(map(str, tri)), fl(P), fl(N), fl(UV))
+    ref, m0 = _baked_bytes(hprt, tmp_path, HEADER + body % inline, "inline")
+    assert m0.counts()["triangles"] == 6
+    for fmt in ("ascii", "binary_little_endian", "binary_big_endian"):
+        _write_ply(str(tmp_path / (fmt + ".ply")), P, N, UV, faces, fmt)
+        got, _ = _baked_bytes(hprt, tmp_path, HEADER + body % ('Shape "plymesh" "string filename" "%s.ply"' % fmt), fmt)   # relative to the scene file
+        assert got == ref, fmt
+    # positions only
+    _write_ply(str(tmp_path / "bare.ply"), P, None, None, faces, "binary_little_endian")
+    bare, _ = _baked_bytes(hprt, tmp_path, HEADER + body % 'Shape "plymesh" "string filename" "bare.ply"', "bare")
+    ref_bare, _ = _baked_bytes(hprt, tmp_path, HEADER + body % ('Shape "trianglemesh" "integer indices" [%s] "point P" [%s]' % (" ".join(map(str, tri)), fl(P))), "inline_bare")
+    assert bare == ref_bare
+    # errors: missing file, vertex reference out of range (plymesh.cpp:123-131), no faces
+    for bad, text in (("missing", 'Shape "plymesh" "string filename" "nope.ply"'),):
+        with pytest.raises(hprt.HprtError):
+            _parse_text(hprt, tmp_path, HEADER + body % text, name=bad + ".pbrt")
+    _write_ply(str(tmp_path / "oob.ply"), P, None, None, [[0, 1, 9]], "ascii")
+    with pytest.raises(hprt.HprtError) as e:
+        _parse_text(hprt, tmp_path, HEADER + body % 'Shape "plymesh" "string filename" "oob.ply"', name="oob.pbrt")
+    assert "out of bounds" in str(e.value)
+
+
+def test_include_named_materials_and_coordinate_systems(hprt, tmp_path):
+    """Include (core/parser.cpp:961-975: relative to the including file), MakeNamedMaterial / NamedMaterial
+    (core/api.cpp:1283-1330), CoordinateSystem / CoordSysTransform (:1022-1039), TransformBegin/End, Identity,
+    Transform / ConcatTransform (:985-1020): each must bake to the bytes of the spelled-out equivalent."""
+    quad = 'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [0 0 0 1 0 0 1 1 0 0 1 0]\n'
+    (tmp_path / "geo").mkdir()
+    (tmp_path / "geo" / "part.pbrt").write_text('Material "plastic" "color Kd" [.1 .2 .3] "color Ks" [.4 .4 .4] "float roughness" [.2]\n' + quad)
+    with_include, _ = _baked_bytes(hprt, tmp_path, HEADER + 'AttributeBegin\nTranslate 0 0 1\nInclude "geo/part.pbrt"\nAttributeEnd\n' + 'Material "matte" "color Kd" [.5 .5 .5]\n' + quad + "WorldEnd\n", "inc")
+    spelled, _ = _baked_bytes(hprt, tmp_path, HEADER + 'AttributeBegin\nTranslate 0 0 1\nMaterial "plastic" "color Kd" [.1 .2 .3] "color Ks" [.4 .4 .4] "float roughness" [.2]\n' + quad +
+                              'AttributeEnd\nMaterial "matte" "color Kd" [.5 .5 .5]\n' + quad + "WorldEnd\n", "inc_ref")
+    assert with_include == spelled
+    named, _ = _baked_bytes(hprt, tmp_path, HEADER + 'MakeNamedMaterial "shiny" "string type" "plastic" "color Kd" [.1 .2 .3] "color Ks" [.4 .4 .4] "float roughness" [.2]\n'
+                            'MakeNamedMaterial "dull" "string type" "matte" "color Kd" [.5 .5 .5]\n'
+                            'AttributeBegin\nTranslate 0 0 1\nNamedMaterial "shiny"\n' + quad + 'AttributeEnd\nNamedMaterial "dull"\n' + quad + "WorldEnd\n", "named")
+    assert named == spelled
+    # coordinate systems and explicit matrices: column-major 4x4 as pbrt's Transform directive takes it
+    cs, _ = _baked_bytes(hprt, tmp_path, HEADER + 'TransformBegin\nTranslate 0 0 1\nCoordinateSystem "up"\nTransformEnd\n'
+                         'Material "plastic" "color Kd" [.1 .2 .3] "color Ks" [.4 .4 .4] "float roughness" [.2]\n'
+                         'AttributeBegin\nScale 3 3 3\nCoordSysTransform "up"\n' + quad + 'AttributeEnd\nMaterial "matte" "color Kd" [.5 .5 .5]\n'
+                         'AttributeBegin\nRotate 45 1 0 0\nIdentity\n' + quad + "AttributeEnd\nWorldEnd\n", "cs")
+    assert cs == spelled
+    mat, _ = _baked_bytes(hprt, tmp_path, HEADER + 'Material "plastic" "color Kd" [.1 .2 .3] "color Ks" [.4 .4 .4] "float roughness" [.2]\n'
+                          'AttributeBegin\nTransform [1 0 0 0  0 1 0 0  0 0 1 0  0 0 1 1]\n' + quad + 'AttributeEnd\nMaterial "matte" "color Kd" [.5 .5 .5]\n'
+                          'AttributeBegin\nTranslate 0 0 -2\nConcatTransform [1 0 0 0  0 1 0 0  0 0 1 0  0 0 2 1]\n' + quad + "AttributeEnd\nWorldEnd\n", "mat")
+    assert mat == spelled

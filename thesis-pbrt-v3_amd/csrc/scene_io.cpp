@@ -4,6 +4,7 @@
 // as at shapes/plymesh.cpp:143-152).
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <fstream>
 #include <sstream>
 #include "scene_model.h"
@@ -203,7 +204,7 @@ bool ReadPlyMesh(const std::string &path, std::vector<int> *idx, std::vector<flo
     std::string line;
     std::getline(in, line);
     if (line.substr(0, 3) != "ply") { *err = path + ": not a PLY file"; return false; }
-    bool binary = false;
+    bool binary = false, bigEndian = false;
     struct Prop { std::string name, type, countType; bool list = false; };
     struct Elem { std::string name; long count = 0; std::vector<Prop> props; };
     std::vector<Elem> elems;
@@ -211,7 +212,7 @@ bool ReadPlyMesh(const std::string &path, std::vector<int> *idx, std::vector<flo
         if (!line.empty() && line.back() == '\r') line.pop_back();
         std::istringstream ls(line);
         std::string w; ls >> w;
-        if (w == "format") { std::string f; ls >> f; if (f == "binary_little_endian") binary = true; else if (f != "ascii") { *err = path + ": unsupported PLY format " + f; return false; } }
+        if (w == "format") { std::string f; ls >> f; if (f == "binary_little_endian") binary = true; else if (f == "binary_big_endian") { binary = true; bigEndian = true; } else if (f != "ascii") { *err = path + ": unsupported PLY format " + f; return false; } }
         else if (w == "element") { Elem e; ls >> e.name >> e.count; elems.push_back(e); }
         else if (w == "property" && !elems.empty()) {
             Prop p; std::string t; ls >> t;
@@ -230,6 +231,7 @@ bool ReadPlyMesh(const std::string &path, std::vector<int> *idx, std::vector<flo
         if (!binary) { return (bool)(in >> *out); }
         unsigned char b[8]; int n = tsize(t);
         if (n == 0 || !in.read((char *)b, n)) return false;
+        if (bigEndian) std::reverse(b, b + n);
         if (t == "float" || t == "float32") { float f; memcpy(&f, b, 4); *out = f; }
         else if (t == "double" || t == "float64") { double d; memcpy(&d, b, 8); *out = d; }
         else if (t == "uchar" || t == "uint8") *out = b[0];
