@@ -23,6 +23,16 @@ gets the resulting files with the repository snapshot.
   simple_8spp_srgb8.npz  scenes/simple.png (8 spp, 8-bit sRGB) as a uint8 array.  With the two
                          values above the oracle reproduces it bit for bit; with the current
                          scenes/simple text (eye (-5,-5,0)) it shows a different view.
+  living_room.hprt       the GEOMETRY of scenes/livingroom (65 PLY meshes under scenes/living-room/models, 143,163
+                         triangles with normals and uv; "The Grey & White Room" by Wig42, CC BY 3.0, converted by Benedikt
+                         Bitterli — scenes/living-room/LICENSE.txt) as the reference's only asset-backed interior: a
+                         real stand-in for BASELINE.json's conference-room configuration.  Everything outside the hot
+                         path's scope is replaced here, in the text, before parsing: the environment light (its map is
+                         not in the repository) by a point light under the ceiling, sobol by halton, the triangle filter
+                         by the box filter, maxdepth 65 by 5, image-mapped parameters by constants (the float pyramids
+                         would add 37 MB); substrate / metal / glass / mirror / uber materials become matte with their Kd
+                         (front-end substitution, recorded as warnings).  No reference render exists for it (the
+                         checked-in TungstenRender.png is another renderer's): it pins nothing, it is a workload.
 """
 import importlib
 import os
@@ -64,6 +74,28 @@ def main():
     m.save(os.path.join(HERE, "simple_instanced.hprt"))
     png = np.asarray(Image.open(os.path.join(REF, "simple.png")).convert("RGB"))
     np.savez_compressed(os.path.join(HERE, "simple_8spp_srgb8.npz"), srgb8=png)
+    living_room(hprt)
+
+
+def living_room(hprt):
+    import re, tempfile
+    text = open(os.path.join(REF, "livingroom")).read()
+    text = text.replace("/Programming/Thesis/pbrt-v3/scenes/", REF + "/")
+    text = re.sub(r'Accelerator \$acc[^\n]*', 'Accelerator "bvh"', text)
+    text = re.sub(r'Integrator "path"[^\n]*', 'Integrator "path" "integer maxdepth" [ 5 ]', text)
+    text = re.sub(r'Sampler "sobol"', 'Sampler "halton"', text)
+    text = re.sub(r'PixelFilter "triangle"[^\n]*', 'PixelFilter "box" "float xwidth" [ 0.5 ] "float ywidth" [ 0.5 ]', text)
+    text = re.sub(r'[ \t]*Texture "Texture0\d"[^\n]*\n', '', text)
+    text = re.sub(r'"texture Kd" \[ "Texture0\d" \]', '"rgb Kd" [ 0.45 0.33 0.22 ]', text)
+    text = re.sub(r'"texture opacity" \[ "Texture0\d" \]', '', text)
+    text, n = re.subn(r'LightSource "infinite"[^\n]*', 'LightSource "point" "point from" [ 2.3 2.6 -1.5 ] "color I" [ 9 9 8.5 ]', text)
+    assert n == 1
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "livingroom.pbrt")
+        open(p, "w").write(text)
+        m = hprt.Model.parse(p, {})
+    print("living room:", m.counts(), len(m.warnings()), "warnings:", sorted(set(w[:60] for w in m.warnings())))
+    m.save(os.path.join(HERE, "living_room.hprt"))
 
 
 if __name__ == "__main__":
