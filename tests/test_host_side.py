@@ -471,3 +471,43 @@ def test_include_named_materials_and_coordinate_systems(hprt, tmp_path):
                           'AttributeBegin\nTransform [1 0 0 0  0 1 0 0  0 0 1 0  0 0 1 1]\n' + quad + 'AttributeEnd\nMaterial "matte" "color Kd" [.5 .5 .5]\n'
                           'AttributeBegin\nTranslate 0 0 -2\nConcatTransform [1 0 0 0  0 1 0 0  0 0 1 0  0 0 2 1]\n' + quad + "AttributeEnd\nWorldEnd\n", "mat")
     assert mat == spelled
+
+
+def test_image_readers_against_an_independent_encoder(hprt, tmp_path):
+    """Files written by Pillow instead of this module's own writers: PNG with adaptive row filters (Sub / Up / Average /
+    Paeth, which the hand-written writer never emits), grey, grey+alpha, palette and RGBA PNGs, RLE and raw TGA.  Level 0
+    must be the decoded pixels, flipped and inverse-gamma corrected (textures/imagemap.cpp:52-64)."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(9)
+    y, x = np.mgrid[0:32, 0:64]
+    smooth = np.stack([(x * 4) % 256, (y * 8) % 256, (x * 3 + y * 5) % 256], axis=2).astype(np.uint8)      # gradients: every PNG filter type pays somewhere
+    noisy = rng.integers(0, 256, (32, 64, 3), dtype=np.uint8)
+    img8 = np.where((x[..., None] // 16) % 2 == 0, smooth, noisy).astype(np.uint8)
+    def level0(path):
+        m = _parse_text(hprt, tmp_path, TEX_SCENE % (path, ""), name=os.path.basename(path) + ".pbrt")
+        assert m.warnings() == [], m.warnings()
+        return m.texture(0)[1][0]
+    def want(rgb8):
+        return _inverse_gamma(rgb8[::-1].astype(np.float32) / np.float32(255))
+    cases = {}
+    Image.fromarray(img8, "RGB").save(str(tmp_path / "p_rgb.png"), optimize=True); cases["p_rgb.png"] = img8
+    rgba = np.concatenate([img8, rng.integers(0, 256, (32, 64, 1), dtype=np.uint8)], axis=2)
+    Image.fromarray(rgba, "RGBA").save(str(tmp_path / "p_rgba.png")); cases["p_rgba.png"] = img8               # alpha is dropped
+    grey = img8[..., 0]
+    Image.fromarray(grey, "L").save(str(tmp_path / "p_grey.png")); cases["p_grey.png"] = np.repeat(grey[..., None], 3, axis=2)
+    la = np.stack([grey, 255 - grey], axis=2)
+    Image.fromarray(la, "LA").save(str(tmp_path / "p_la.png")); cases["p_la.png"] = np.repeat(grey[..., None], 3, axis=2)
+    pal = Image.fromarray(img8, "RGB").quantize(colors=64)
+    pal.save(str(tmp_path / "p_pal.png")); cases["p_pal.png"] = np.asarray(pal.convert("RGB"))
+    Image.fromarray(img8, "RGB").save(str(tmp_path / "t_raw.tga")); cases["t_raw.tga"] = img8
+    Image.fromarray(img8, "RGB").save(str(tmp_path / "t_rle.tga"), compression="tga_rle"); cases["t_rle.tga"] = img8
+    Image.fromarray(rgba, "RGBA").save(str(tmp_path / "t_rgba.tga")); cases["t_rgba.tga"] = img8
+    Image.fromarray(grey, "L").save(str(tmp_path / "t_grey.tga")); cases["t_grey.tga"] = np.repeat(grey[..., None], 3, axis=2)
+    for name, rgb8 in cases.items():
+        got = level0(str(tmp_path / name))
+        assert got.shape == (32, 64, 3), name
+        assert np.abs(got - want(rgb8)).max() <= 1e-7, name
+    # the decoder agrees with Pillow's on the files it reads back itself
+    for name in cases:
+        back = np.asarray(Image.open(str(tmp_path / name)).convert("RGB"))
+        assert np.array_equal(back, cases[name]), name
