@@ -490,19 +490,19 @@ def test_image_readers_against_an_independent_encoder(hprt, tmp_path):
     def want(rgb8):
         return _inverse_gamma(rgb8[::-1].astype(np.float32) / np.float32(255))
     cases = {}
-    Image.fromarray(img8, "RGB").save(str(tmp_path / "p_rgb.png"), optimize=True); cases["p_rgb.png"] = img8
+    Image.fromarray(img8).save(str(tmp_path / "p_rgb.png"), optimize=True); cases["p_rgb.png"] = img8
     rgba = np.concatenate([img8, rng.integers(0, 256, (32, 64, 1), dtype=np.uint8)], axis=2)
-    Image.fromarray(rgba, "RGBA").save(str(tmp_path / "p_rgba.png")); cases["p_rgba.png"] = img8               # alpha is dropped
+    Image.fromarray(rgba).save(str(tmp_path / "p_rgba.png")); cases["p_rgba.png"] = img8               # alpha is dropped
     grey = img8[..., 0]
-    Image.fromarray(grey, "L").save(str(tmp_path / "p_grey.png")); cases["p_grey.png"] = np.repeat(grey[..., None], 3, axis=2)
+    Image.fromarray(grey).save(str(tmp_path / "p_grey.png")); cases["p_grey.png"] = np.repeat(grey[..., None], 3, axis=2)
     la = np.stack([grey, 255 - grey], axis=2)
-    Image.fromarray(la, "LA").save(str(tmp_path / "p_la.png")); cases["p_la.png"] = np.repeat(grey[..., None], 3, axis=2)
-    pal = Image.fromarray(img8, "RGB").quantize(colors=64)
+    Image.fromarray(la).save(str(tmp_path / "p_la.png")); cases["p_la.png"] = np.repeat(grey[..., None], 3, axis=2)
+    pal = Image.fromarray(img8).quantize(colors=64)
     pal.save(str(tmp_path / "p_pal.png")); cases["p_pal.png"] = np.asarray(pal.convert("RGB"))
-    Image.fromarray(img8, "RGB").save(str(tmp_path / "t_raw.tga")); cases["t_raw.tga"] = img8
-    Image.fromarray(img8, "RGB").save(str(tmp_path / "t_rle.tga"), compression="tga_rle"); cases["t_rle.tga"] = img8
-    Image.fromarray(rgba, "RGBA").save(str(tmp_path / "t_rgba.tga")); cases["t_rgba.tga"] = img8
-    Image.fromarray(grey, "L").save(str(tmp_path / "t_grey.tga")); cases["t_grey.tga"] = np.repeat(grey[..., None], 3, axis=2)
+    Image.fromarray(img8).save(str(tmp_path / "t_raw.tga")); cases["t_raw.tga"] = img8
+    Image.fromarray(img8).save(str(tmp_path / "t_rle.tga"), compression="tga_rle"); cases["t_rle.tga"] = img8
+    Image.fromarray(rgba).save(str(tmp_path / "t_rgba.tga")); cases["t_rgba.tga"] = img8
+    Image.fromarray(grey).save(str(tmp_path / "t_grey.tga")); cases["t_grey.tga"] = np.repeat(grey[..., None], 3, axis=2)
     for name, rgb8 in cases.items():
         got = level0(str(tmp_path / name))
         assert got.shape == (32, 64, 3), name
