@@ -125,7 +125,8 @@ struct TraceTune { int refillBelow, parkLimit, stepLimit, sphereLimit, primMin; 
 static TraceTune DefaultTraceTune(bool anyHit) {
     // closest-hit and any-hit rays want different schedules: shadow rays mostly cross the scene unoccluded, with
     // few primitive tests each, so their tests should not wait for company (full-frame sweeps, tools/sweep_bench.sh)
-    TraceTune t = anyHit ? TraceTune{52, 24, 10, 16, 3} : TraceTune{52, 24, 6, 16, 8};
+    // (stepLimit 10 for closest hits: flat on killeroo-simple, +2-3 % on the deep interiors: living room, atrium)
+    TraceTune t = anyHit ? TraceTune{52, 24, 10, 16, 3} : TraceTune{52, 24, 10, 16, 8};
     if (const char *e = getenv(anyHit ? "HPRT_TRACE_TUNE_ANY" : "HPRT_TRACE_TUNE"))
         sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin);
     return t;
