@@ -436,10 +436,28 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     const std::vector<uint16_t> &perms = HaltonPermutations();
     // ---- child-pair layout of the BVHs (device/dev_scene.h): one run of pairs per aggregate ----
     std::vector<DevPair> pairs((size_t)pairBase[aggs.size()]);
+    // The ordered walk keeps at most one pending sibling per level, plus the sentinel of an instance: the kernel's
+    // stack has HPRT_LDS_STACK + HPRT_SPILL_STACK = 64 entries, as the reference's nodesToVisit[64]
+    // (accelerators/bvh.cpp:365).  Deeper trees are refused here rather than walked wrongly.
+    int topDepth = 0, objectDepth = 0;
     for (size_t ai = 0; ai < aggs.size(); ++ai) {
         const Agg &g = aggs[ai];
         if (g.nNodes == 0) continue;
         const BvhNode *nd = g.nodes;
+        {   // depth of this aggregate's tree (depth-first layout: first child at i + 1, second child at offset)
+            std::vector<std::pair<uint32_t, int>> todo; todo.push_back({0u, 1});
+            int depth = 0;
+            while (!todo.empty()) {
+                auto [i, dpt] = todo.back(); todo.pop_back();
+                if (i >= g.nNodes) return SetError(HPRT_E_INVALID, "BVH node index out of range");
+                depth = std::max(depth, dpt);
+                if ((nd[i].countAxis & 3u) != 3u) {
+                    if ((uint32_t)nd[i].offset <= i || (uint32_t)nd[i].offset >= g.nNodes) return SetError(HPRT_E_INVALID, "BVH second-child offset out of range");
+                    todo.push_back({(uint32_t)nd[i].offset, dpt + 1}); todo.push_back({i + 1u, dpt + 1});
+                }
+            }
+            if (ai == 0) topDepth = depth; else objectDepth = std::max(objectDepth, depth);
+        }
         std::vector<int32_t> ref(g.nNodes);
         int32_t nextPair = (int32_t)pairBase[ai] + 1;
         for (uint32_t i = 0; i < g.nNodes; ++i) {
@@ -463,6 +481,8 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
             fill(pairs[(size_t)ref[i]], c[0], c[1], nd[i].countAxis & 3u);
         }
     }
+    if (topDepth + (d->n_instances ? 1 + objectDepth : 0) > HPRT_LDS_STACK + HPRT_SPILL_STACK)
+        return SetError(HPRT_E_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack (accelerators/bvh.cpp:365 reserves the same)");
     std::vector<DevInstance> instances(d->n_instances);
     for (uint32_t i = 0; i < d->n_instances; ++i) {
         const HprtInstanceDesc &in = d->instances[i];

@@ -159,7 +159,7 @@ __device__ __forceinline__ bool slab_test(float lox, float hix, float loy, float
 // Diagnostics (HPRT_TRACE_PROFILE=1, tools/trace_profile.py): per-phase cycles and lane occupancy,
 // summed over all waves.  [0] total [1] refill [2] pair phase [3] primitive phase [4] quadric
 // batches [5] pair iterations [6] pair lanes [7] primitive iterations [8] primitive lanes
-// [9] refills [10] refilled lanes [11] quadric batches [12] quadric lanes [13] waves.
+// [9] refills [10] refilled lanes [11] quadric batches [12] quadric lanes [13] waves [14] stack pushes [15] pushes beyond the LDS entries.
 __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31] any hit
 
 // MODE 0: plain; 1: work counters (HprtRenderStats); 2: phase profile (diagnostics only).
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                                                             TraceTune tune) {
     constexpr bool COUNT = MODE == 1, PROF = MODE == 2;
     unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned int pfPush = 0u, pfSpill = 0u;      // PROF: stack pushes, and those beyond the LDS entries (scratch)
     const unsigned long long pfStart = PROF ? clock64() : 0ull;
     __shared__ uint2 stackMem[HPRT_LDS_STACK * HPRT_TRACE_BLOCK];     // [entry][thread]: {ref, tMin}
     uint2 *const ldsStack = &stackMem[threadIdx.x];
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
                         cur = refN;
                         if (COUNT ? !single : (slabF && tF < rayTMax)) {
                             const uint2 e = make_uint2((uint32_t)refF, __float_as_uint(slabF ? tF : HPRT_INF));
+                            if (PROF) { ++pfPush; if (sp >= HPRT_LDS_STACK) ++pfSpill; }
                             if (sp < HPRT_LDS_STACK) { ldsStack[sp * HPRT_TRACE_BLOCK] = e; ++sp; }
                             else if (sp < HPRT_LDS_STACK + HPRT_SPILL_STACK) { spillRef[sp - HPRT_LDS_STACK] = e.x; spillT[sp - HPRT_LDS_STACK] = e.y; ++sp; }
                         }
@@ -459,6 +461,10 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, cons
         }
     }
     if (COUNT) wave_count_add(counters, ANY_HIT, cnt);
+    if (PROF) {
+        for (int off = 32; off > 0; off >>= 1) { pfPush += __shfl_down(pfPush, off); pfSpill += __shfl_down(pfSpill, off); }
+        if (lane == 0) { atomicAdd(&g_traceProf[(ANY_HIT ? 16 : 0) + 14], (unsigned long long)pfPush); atomicAdd(&g_traceProf[(ANY_HIT ? 16 : 0) + 15], (unsigned long long)pfSpill); }
+    }
     if (PROF && lane == 0) {
         pf[0] = clock64() - pfStart;
         for (int k = 0; k < 13; ++k) atomicAdd(&g_traceProf[(ANY_HIT ? 16 : 0) + k], pf[k]);

@@ -12,6 +12,8 @@ spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 which = sys.argv[2] if len(sys.argv) > 2 else "killeroo"
 if which == "killeroo":
     model = hprt.Model.load(FIX)
+elif which.endswith(".hprt"):
+    model = hprt.Model.load(which)
 else:
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -38,4 +40,5 @@ for name, b in (("closest", 0), ("any-hit", 16)):
     print("   pair steps: %d iterations, %.1f lanes avg   | cycles/iteration %.0f" % (v[5], v[6] / max(1, v[5]), v[2] / max(1, v[5])))
     print("   prim tests: %d iterations, %.1f lanes avg   | cycles/iteration %.0f" % (v[7], v[8] / max(1, v[7]), v[3] / max(1, v[7])))
     print("   refills   : %d, %.1f lanes avg               | cycles/refill %.0f" % (v[9], v[10] / max(1, v[9]), v[1] / max(1, v[9])))
+    print("   stack     : %d pushes, %.3f %% beyond the LDS entries (scratch)" % (v[14], 100.0 * v[15] / max(1, v[14])))
     print("   quadric   : %d batches, %.1f lanes avg       | cycles/batch %.0f" % (v[11], v[12] / max(1, v[11]), v[4] / max(1, v[11])))
