@@ -125,8 +125,7 @@ struct TraceTune { int refillBelow, parkLimit, stepLimit, sphereLimit, primMin; 
 static TraceTune DefaultTraceTune(bool anyHit) {
     // closest-hit and any-hit rays want different schedules: shadow rays mostly cross the scene unoccluded, with
     // few primitive tests each, so their tests should not wait for company (full-frame sweeps, tools/sweep_bench.sh)
-    // (stepLimit 10 for closest hits: flat on killeroo-simple, +2-3 % on the deep interiors: living room, atrium)
-    TraceTune t = anyHit ? TraceTune{52, 24, 10, 16, 3} : TraceTune{52, 24, 10, 16, 8};
+    TraceTune t = anyHit ? TraceTune{52, 24, 10, 16, 3} : TraceTune{52, 24, 6, 16, 8};
     if (const char *e = getenv(anyHit ? "HPRT_TRACE_TUNE_ANY" : "HPRT_TRACE_TUNE"))
         sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin);
     return t;
@@ -954,7 +953,11 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     uint32_t chunk = gridItems / (nWaves * chunkDiv);
     chunk = std::max(64u, std::min(chunkMax, chunk)) & ~63u;
     static const TraceTune tuneClosest = DefaultTraceTune(false), tuneAny = DefaultTraceTune(true);
-    const TraceTune tune = anyHit ? tuneAny : tuneClosest;
+    TraceTune tune = anyHit ? tuneAny : tuneClosest;
+    // closest hits in large scenes run longer interior stretches between leaves (57 nodes per ray in the living room,
+    // 20 in killeroo-simple): a longer pair phase pays there (+2-3 % on the living room and the atrium, -1 % on killeroo)
+    static const bool tuneFromEnv = getenv("HPRT_TRACE_TUNE") != nullptr;
+    if (!anyHit && !tuneFromEnv && sc.nPairs > 100000u) tune.stepLimit = 10;
     static const bool profile = getenv("HPRT_TRACE_PROFILE") != nullptr;
     const bool inst = sc.nInstances != 0u;
 #define HPRT_TRACE_LAUNCH(A, M, I) hipLaunchKernelGGL((k_trace<A, M, I>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, rayStats, workCounter, chunk, tune)
