@@ -180,7 +180,9 @@ __device__ __noinline__ bool sphere_test(const DevSphere &s, const DRay &r, DRay
 // use stays well below the tree depth.
 #define HPRT_LDS_STACK 16
 #define HPRT_SPILL_STACK 48
+#ifndef HPRT_TRACE_BLOCK
 #define HPRT_TRACE_BLOCK 256
+#endif
 
 struct TraceCount { unsigned int fetched, entered, tri, sphere, leaf; };   // leaf: of the entered nodes, leaves
 

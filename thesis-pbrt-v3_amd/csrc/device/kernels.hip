@@ -164,7 +164,7 @@ __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31
 // MODE 0: plain; 1: work counters (HprtRenderStats); 2: phase profile (diagnostics only).
 // INST: the scene has object instances (two-level walk); without them that code and its registers are compiled out.
 template <bool ANY_HIT, int MODE, bool INST>
-__global__ __launch_bounds__(HPRT_TRACE_BLOCK, 4) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
+__global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ,
                                                             DevCounters *counters, uint4 *rayStats, uint32_t *workCounter, uint32_t chunk,
                                                             TraceTune tune) {
@@ -944,7 +944,7 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     if (gridItems == 0) return;
     (void)hipMemsetAsync(workCounter, 0, sizeof(uint32_t), st);
     // persistent waves: enough blocks to fill 256 CUs at this kernel's occupancy, never more than the rays need
-    const uint32_t maxBlocks = 256u * 5u;
+    const uint32_t maxBlocks = 256u * 5u * (256u / HPRT_TRACE_BLOCK);
     dim3 grid(std::min(blocks_for(gridItems, HPRT_TRACE_BLOCK), maxBlocks)), block(HPRT_TRACE_BLOCK);
     // rays per queue-head atomic: large launches take 512 at a time, small ones keep every wave busy
     const uint32_t nWaves = grid.x * (HPRT_TRACE_BLOCK / 64);
