@@ -511,3 +511,18 @@ def test_image_readers_against_an_independent_encoder(hprt, tmp_path):
     for name in cases:
         back = np.asarray(Image.open(str(tmp_path / name)).convert("RGB"))
         assert np.array_equal(back, cases[name]), name
+
+
+def test_living_room_fixture_builds_the_same_bvh_on_both_sides(hprt, orc):
+    """tests/golden/living_room.hprt (the reference's scenes/livingroom geometry, see ATTRIBUTION.md): the product's
+    builder and the oracle's must produce the same 233,709 nodes from its 143,163 triangles."""
+    path = os.path.join(GOLDEN, "living_room.hprt")
+    model = hprt.Model.load(path)
+    c = model.counts()
+    assert (c["triangles"], c["shapes"], c["lights"], c["textures"]) == (143163, 65, 1, 0)
+    bvh = hprt.Bvh(model)
+    o = orc.OracleScene(path)
+    n1, o1 = o.bvh_arrays(); n2, o2 = bvh.arrays()
+    assert np.array_equal(n1, n2) and np.array_equal(o1, o2)
+    info = bvh.info()
+    assert (info["nodes"], info["leaves"], info["max_depth"]) == (233709, 116855, 26)
