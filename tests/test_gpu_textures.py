@@ -112,3 +112,24 @@ def test_textured_render_matches_constant_when_texture_is_flat(hprt, orc, tmp_pa
         model = hprt.Model.parse(str(p))
         films.append(hprt.Scene(model, hprt.Bvh(model)).render()[0])
     assert np.allclose(films[0], films[1], rtol=2e-6, atol=1e-7)
+
+
+def test_pixel_statistics_with_instances_and_textures(hprt, orc, tmp_path):
+    """The fork's per-pixel traversal statistics (Pixel::stats, core/film.h:91) on a scene that goes through the other
+    optional paths at once: object instances (the two-level walk counts the instance's aggregate nodes as the reference's
+    TransformedPrimitive::Intersect does), quadrics inside instances, image textures, depth of field."""
+    name = "spheres_instances_dof"
+    _write_images(tmp_path)
+    p = tmp_path / (name + ".pbrt")
+    p.write_text(CASES[name] % {"dir": str(tmp_path)})
+    model = hprt.Model.parse(str(p))
+    baked = str(tmp_path / (name + ".hprt")); model.save(baked)
+    oracle = orc.OracleScene(baked)
+    oracle.render(threads=8)
+    ref = oracle.pixel_stats()
+    scene = hprt.Scene(model, hprt.Bvh(model))
+    film, st = scene.render(pixel_stats=True)
+    got = scene.pixel_stats()
+    assert got.shape == ref.shape and ref[..., 1].sum() > 0 and ref[..., 4].sum() > 0
+    assert np.array_equal(got, ref)
+    assert int(got[..., 1].sum()) == st["tri_tests"] + st["sphere_tests"]
