@@ -169,6 +169,13 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                                                             DevCounters *counters, uint4 *rayStats, uint32_t *workCounter, uint32_t chunk,
                                                             TraceTune tune) {
     constexpr bool COUNT = MODE == 1, PROF = MODE == 2;
+    // An any-hit ray's answer does not depend on the order of the walk (its tMax never shrinks, every primitive test is
+    // independent of the others), so the plain any-hit kernel visits children in storage order and skips the re-test of
+    // popped entries: 8-11 % more rays per second than the reference's front-to-back order (bvh.cpp:381-388), which the
+    // counting and profiling variants keep so that their node counts are the reference's.  Nearest-entry-first was
+    // measured too: 2 % slower than storage order.  Closest-hit rays keep the reference's order: ties in t (shared edges)
+    // are resolved by it.
+    constexpr bool FREE_ORDER = ANY_HIT && MODE == 0;
     unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned int pfPush = 0u, pfSpill = 0u;      // PROF: stack pushes, and those beyond the LDS entries (scratch)
     const unsigned long long pfStart = PROF ? clock64() : 0ull;
@@ -216,7 +223,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
             if (sp < HPRT_LDS_STACK) e = ldsStack[sp * HPRT_TRACE_BLOCK]; else e = make_uint2(spillRef[sp - HPRT_LDS_STACK], spillT[sp - HPRT_LDS_STACK]);
             if (INST && (int)e.x == REF_EXIT) { savedTMax = __uint_as_float(e.y); return REF_EXIT; }     // the instance's walk is over
             if (COUNT) ++cnt.fetched;
-            if (__uint_as_float(e.y) < rayTMax) { if (COUNT) { ++cnt.entered; if ((int)e.x < 0) ++cnt.leaf; } return (int)e.x; }
+            // (an any-hit ray's tMax never shrinks: what was pushed with tMin < tMax still passes)
+            if (FREE_ORDER || __uint_as_float(e.y) < rayTMax) { if (COUNT) { ++cnt.entered; if ((int)e.x < 0) ++cnt.leaf; } return (int)e.x; }
         }
         return REF_NONE;
     };
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                     const uint32_t axis = meta & 3u;
                     const bool single = (meta & PAIR_SINGLE) != 0u;
                     // second child first when the ray is negative along the split axis (bvh.cpp:381-388)
-                    const bool isNeg = axis == 0 ? negX : (axis == 1 ? negY : negZ);
+                    const bool isNeg = FREE_ORDER ? false : (axis == 0 ? negX : (axis == 1 ? negY : negZ));
                     const int refN = (int)(isNeg ? q3.y : q3.x), refF = (int)(isNeg ? q3.x : q3.y);
                     const float tN = isNeg ? t1 : t0, tF = isNeg ? t0 : t1;
                     const bool hitN = (isNeg ? s1 : s0) && tN < rayTMax;
