@@ -79,6 +79,9 @@ __device__ __forceinline__ bool tri_test(vec3 p0, vec3 p1, vec3 p2, vec3 rayO, f
 }
 
 // ---- EFloat interval arithmetic (core/efloat.h, NDEBUG layout) --------------
+// The operations are real functions (not inlined) on purpose: inlined, the quadric test needs 99 VGPRs, and a kernel that
+// calls it must keep its own live values ABOVE the callee's registers — k_trace was at 122 VGPRs (four waves per SIMD)
+// because of this rarely executed test.  As calls the test needs 56, k_trace 96: five waves per SIMD.
 struct efloat { float v, lo, hi; };
 __device__ __forceinline__ efloat ef(float v) { efloat r; r.v = v; r.lo = v; r.hi = v; return r; }
 __device__ __forceinline__ efloat ef(float v, float err) {
@@ -86,16 +89,16 @@ __device__ __forceinline__ efloat ef(float v, float err) {
     if (err == 0.f) { r.lo = v; r.hi = v; } else { r.lo = next_down(v - err); r.hi = next_up(v + err); }
     return r;
 }
-__device__ __forceinline__ efloat ef_add(efloat a, efloat b) { efloat r; r.v = a.v + b.v; r.lo = next_down(a.lo + b.lo); r.hi = next_up(a.hi + b.hi); return r; }
-__device__ __forceinline__ efloat ef_sub(efloat a, efloat b) { efloat r; r.v = a.v - b.v; r.lo = next_down(a.lo - b.hi); r.hi = next_up(a.hi - b.lo); return r; }
-__device__ __forceinline__ efloat ef_mul(efloat a, efloat b) {
+__device__ __noinline__ efloat ef_add(efloat a, efloat b) { efloat r; r.v = a.v + b.v; r.lo = next_down(a.lo + b.lo); r.hi = next_up(a.hi + b.hi); return r; }
+__device__ __noinline__ efloat ef_sub(efloat a, efloat b) { efloat r; r.v = a.v - b.v; r.lo = next_down(a.lo - b.hi); r.hi = next_up(a.hi - b.lo); return r; }
+__device__ __noinline__ efloat ef_mul(efloat a, efloat b) {
     efloat r; r.v = a.v * b.v;
     float p0 = a.lo * b.lo, p1 = a.hi * b.lo, p2 = a.lo * b.hi, p3 = a.hi * b.hi;
     r.lo = next_down(sel_min(sel_min(p0, p1), sel_min(p2, p3)));
     r.hi = next_up(sel_max(sel_max(p0, p1), sel_max(p2, p3)));
     return r;
 }
-__device__ __forceinline__ efloat ef_div(efloat a, efloat b) {
+__device__ __noinline__ efloat ef_div(efloat a, efloat b) {
     efloat r; r.v = a.v / b.v;
     if (b.lo < 0 && b.hi > 0) { r.lo = -HPRT_INF; r.hi = HPRT_INF; }
     else {
@@ -106,7 +109,7 @@ __device__ __forceinline__ efloat ef_div(efloat a, efloat b) {
     return r;
 }
 // core/efloat.h:267-288
-__device__ __forceinline__ bool ef_quadratic(efloat A, efloat B, efloat C, efloat *t0, efloat *t1) {
+__device__ __noinline__ bool ef_quadratic(efloat A, efloat B, efloat C, efloat *t0, efloat *t1) {
     double discrim = (double)B.v * (double)B.v - 4. * (double)A.v * (double)C.v;
     if (discrim < 0.) return false;
     double rootDiscrim = sqrt(discrim);
@@ -134,6 +137,30 @@ __device__ __forceinline__ bool sphere_phi_exceeds(const DevSphere &s, vec3 pHit
     float phi = det_atan2f(pHit.y, pHit.x);
     if (phi < 0) phi += 2 * HPRT_PI;
     return phi > s.phiMax;
+}
+
+// The values (".v" lanes) of the quadric test's EFloat arithmetic up to its first rejection tests (shapes/sphere.cpp:55-75),
+// in plain float.  An EFloat's bounds enclose its value (every operation keeps lo <= v <= hi), so t0.v > tMax implies the
+// reference's t0.UpperBound() > tMax and t1.v <= 0 implies t1.LowerBound() <= 0; the discriminant test only reads values.
+// false: the full test would return false; true: it has to run.  Most rays that reach the emitter's leaf end here: a shadow
+// ray stops short of the sampled point (t0 ~ 1 > tMax = 1 - eps), most other rays miss the sphere or have it behind them.
+__device__ __forceinline__ bool sphere_may_hit(const DevSphere &s, const DRay &r) {
+    vec3 oErr;
+    vec3 o = xf_point_err(s.w2o, r.o, &oErr);
+    const vec3 d = xf_vector(s.w2o, r.d);
+    const float len2 = length2(d);
+    if (len2 > 0) { const float dt = dot(vabs(d), oErr) / len2; o = o + d * dt; }
+    const float a = (d.x * d.x + d.y * d.y) + d.z * d.z;
+    const float b = 2.f * ((d.x * o.x + d.y * o.y) + d.z * o.z);
+    const float c = ((o.x * o.x + o.y * o.y) + o.z * o.z) - s.radius * s.radius;
+    const double discrim = (double)b * (double)b - 4. * (double)a * (double)c;
+    if (discrim < 0.) return false;
+    const float fr = (float)sqrt(discrim);
+    const float q = b < 0 ? -.5f * (b - fr) : -.5f * (b + fr);
+    float t0 = q / a, t1 = c / q;
+    if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+    if (t0 > r.tMax || t1 <= 0) return false;
+    return true;
 }
 
 // Quadric test shared by Sphere::Intersect and IntersectP (shapes/sphere.cpp:49-104 == :159-213).

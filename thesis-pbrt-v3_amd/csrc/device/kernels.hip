@@ -164,7 +164,7 @@ __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31
 // MODE 0: plain; 1: work counters (HprtRenderStats); 2: phase profile (diagnostics only).
 // INST: the scene has object instances (two-level walk); without them that code and its registers are compiled out.
 template <bool ANY_HIT, int MODE, bool INST>
-__global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
+__global__ __launch_bounds__(HPRT_TRACE_BLOCK, (ANY_HIT ? 1280 : 1024) / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ,
                                                             DevCounters *counters, uint4 *rayStats, uint32_t *workCounter, uint32_t chunk,
                                                             TraceTune tune) {
@@ -176,6 +176,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
     // measured too: 2 % slower than storage order.  Closest-hit rays keep the reference's order: ties in t (shared edges)
     // are resolved by it.
     constexpr bool FREE_ORDER = ANY_HIT && MODE == 0;
+    constexpr bool HPRT_INLINE_PRETEST = true;
     unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned int pfPush = 0u, pfSpill = 0u;      // PROF: stack pushes, and those beyond the LDS entries (scratch)
     const unsigned long long pfStart = PROF ? clock64() : 0ull;
@@ -419,7 +420,20 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                             negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
                             shear = ray_shear(d2);
                             cur = in.root;
-                        } else { wait = 1u; waitInfo = v2.w | ((tag & TAG_LAST) ? 0x80000000u : 0u); }
+                        } else {
+                            // a quadric: the cheap exact pre-test (dev_intersect.h) settles most of them here; the rest wait for
+                            // the batched interval-arithmetic test
+                            bool maybe = true;
+                            if (HPRT_INLINE_PRETEST) {
+                                DRay rr; rr.o = ro; rr.tMax = rayTMax;
+                                if (INST) rr.d = vec3(worldRay[3 * HPRT_TRACE_BLOCK], worldRay[4 * HPRT_TRACE_BLOCK], worldRay[5 * HPRT_TRACE_BLOCK]);
+                                else { const float4 rb = rays.b[slot]; rr.d = vec3(rb.x, rb.y, rb.z); }
+                                if (INST && inst >= 0) rr.d = xf_vector(sc.instances[inst].w2i, rr.d);
+                                maybe = sphere_may_hit(sc.spheres[v2.w], rr);
+                            }
+                            if (maybe) { wait = 1u; waitInfo = v2.w | ((tag & TAG_LAST) ? 0x80000000u : 0u); }
+                            else { if (COUNT) ++cnt.sphere; if (tag & TAG_LAST) cur = pop(); else --cur; }
+                        }
                     }
                     continue;
                 }
@@ -440,7 +454,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                     if (INST && inst >= 0) rr.d = xf_vector(sc.instances[inst].w2i, rr.d);      // the instance-space direction, recomputed
                     DRay robj; vec3 ph; float phi, t;
                     bool done = false;
-                    if (sphere_test(sc.spheres[waitInfo & 0x7fffffffu], rr, &robj, &ph, &phi, &t)) {
+                    // the cheap exact pre-test (dev_intersect.h) settles most quadrics; the interval arithmetic runs for the rest
+                    if ((HPRT_INLINE_PRETEST || sphere_may_hit(sc.spheres[waitInfo & 0x7fffffffu], rr)) && sphere_test(sc.spheres[waitInfo & 0x7fffffffu], rr, &robj, &ph, &phi, &t)) {
                         if (ANY_HIT) { hit = true; done = true; }
                         else { hit = true; rayTMax = t; prim = (int32_t)(pi | HIT_GENERIC); hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; if (INST) { hitInst = inst; instHit = inst >= 0; } }
                     }
