@@ -125,7 +125,7 @@ struct TraceTune { int refillBelow, parkLimit, stepLimit, sphereLimit, primMin; 
 static TraceTune DefaultTraceTune(bool anyHit) {
     // closest-hit and any-hit rays want different schedules: shadow rays mostly cross the scene unoccluded, with
     // few primitive tests each, so their tests should not wait for company (full-frame sweeps, tools/sweep_bench.sh)
-    TraceTune t = anyHit ? TraceTune{52, 24, 10, 16, 3} : TraceTune{52, 24, 6, 16, 8};
+    TraceTune t = anyHit ? TraceTune{52, 24, 10, 4, 3} : TraceTune{52, 24, 6, 4, 8};      // (sphereLimit: flat between 1 and 16 since the pre-test)
     if (const char *e = getenv(anyHit ? "HPRT_TRACE_TUNE_ANY" : "HPRT_TRACE_TUNE"))
         sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin);
     return t;
@@ -164,7 +164,7 @@ __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31
 // MODE 0: plain; 1: work counters (HprtRenderStats); 2: phase profile (diagnostics only).
 // INST: the scene has object instances (two-level walk); without them that code and its registers are compiled out.
 template <bool ANY_HIT, int MODE, bool INST>
-__global__ __launch_bounds__(HPRT_TRACE_BLOCK, (ANY_HIT ? 1280 : 1024) / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
+__global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ,
                                                             DevCounters *counters, uint4 *rayStats, uint32_t *workCounter, uint32_t chunk,
                                                             TraceTune tune) {
