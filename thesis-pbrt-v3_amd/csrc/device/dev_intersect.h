@@ -79,9 +79,6 @@ __device__ __forceinline__ bool tri_test(vec3 p0, vec3 p1, vec3 p2, vec3 rayO, f
 }
 
 // ---- EFloat interval arithmetic (core/efloat.h, NDEBUG layout) --------------
-// The operations are real functions (not inlined) on purpose: inlined, the quadric test needs 99 VGPRs, and a kernel that
-// calls it must keep its own live values ABOVE the callee's registers — k_trace was at 122 VGPRs (four waves per SIMD)
-// because of this rarely executed test.  As calls the test needs 56, k_trace 96: five waves per SIMD.
 struct efloat { float v, lo, hi; };
 __device__ __forceinline__ efloat ef(float v) { efloat r; r.v = v; r.lo = v; r.hi = v; return r; }
 __device__ __forceinline__ efloat ef(float v, float err) {
@@ -89,16 +86,16 @@ __device__ __forceinline__ efloat ef(float v, float err) {
     if (err == 0.f) { r.lo = v; r.hi = v; } else { r.lo = next_down(v - err); r.hi = next_up(v + err); }
     return r;
 }
-__device__ __noinline__ efloat ef_add(efloat a, efloat b) { efloat r; r.v = a.v + b.v; r.lo = next_down(a.lo + b.lo); r.hi = next_up(a.hi + b.hi); return r; }
-__device__ __noinline__ efloat ef_sub(efloat a, efloat b) { efloat r; r.v = a.v - b.v; r.lo = next_down(a.lo - b.hi); r.hi = next_up(a.hi - b.lo); return r; }
-__device__ __noinline__ efloat ef_mul(efloat a, efloat b) {
+__device__ __forceinline__ efloat ef_add(efloat a, efloat b) { efloat r; r.v = a.v + b.v; r.lo = next_down(a.lo + b.lo); r.hi = next_up(a.hi + b.hi); return r; }
+__device__ __forceinline__ efloat ef_sub(efloat a, efloat b) { efloat r; r.v = a.v - b.v; r.lo = next_down(a.lo - b.hi); r.hi = next_up(a.hi - b.lo); return r; }
+__device__ __forceinline__ efloat ef_mul(efloat a, efloat b) {
     efloat r; r.v = a.v * b.v;
     float p0 = a.lo * b.lo, p1 = a.hi * b.lo, p2 = a.lo * b.hi, p3 = a.hi * b.hi;
     r.lo = next_down(sel_min(sel_min(p0, p1), sel_min(p2, p3)));
     r.hi = next_up(sel_max(sel_max(p0, p1), sel_max(p2, p3)));
     return r;
 }
-__device__ __noinline__ efloat ef_div(efloat a, efloat b) {
+__device__ __forceinline__ efloat ef_div(efloat a, efloat b) {
     efloat r; r.v = a.v / b.v;
     if (b.lo < 0 && b.hi > 0) { r.lo = -HPRT_INF; r.hi = HPRT_INF; }
     else {
@@ -109,7 +106,7 @@ __device__ __noinline__ efloat ef_div(efloat a, efloat b) {
     return r;
 }
 // core/efloat.h:267-288
-__device__ __noinline__ bool ef_quadratic(efloat A, efloat B, efloat C, efloat *t0, efloat *t1) {
+__device__ __forceinline__ bool ef_quadratic(efloat A, efloat B, efloat C, efloat *t0, efloat *t1) {
     double discrim = (double)B.v * (double)B.v - 4. * (double)A.v * (double)C.v;
     if (discrim < 0.) return false;
     double rootDiscrim = sqrt(discrim);
