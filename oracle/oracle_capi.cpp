@@ -265,6 +265,7 @@ int orc_triangle_intersect(const float *p9, const float *o, const float *d, floa
 int orc_selftest_watertight(int nRays) { return SelfTestWatertight(nRays); }
 int orc_selftest_reintersect(int nTriangles, int nRaysPerTriangle, int *nTested) { return SelfTestReintersect(nTriangles, nRaysPerTriangle, nTested); }
 int orc_selftest_radical_inverse() { return SelfTestRadicalInverse(); }
+int orc_selftest_sphere_pretest(int nRays, int *nFull, int *nMaybe) { return SelfTestSpherePretest(nRays, nFull, nMaybe); }
 int orc_selftest_scrambled_radical_inverse() { return SelfTestScrambledRadicalInverse(); }
 
 // detmath probes

@@ -144,4 +144,58 @@ inline int SelfTestScrambledRadicalInverse() {
     return failures;
 }
 
+// The claim behind the product's quadric pre-test (csrc/device/dev_intersect.h: sphere_may_hit): evaluating only the VALUE
+// lanes of SphereTest's EFloat arithmetic, "discriminant < 0", "t0.v > tMax" and "t1.v <= 0" each imply that the full
+// interval test returns false.  Counts rays the value-lane test rejects although SphereTest accepts them (must be 0), and
+// reports how many rays each side accepted.  Rays: origins around the sphere at every scale, directions partly aimed at it,
+// tMax partly just short of / just beyond the surface (the shadow-ray situation).
+inline int SelfTestSpherePretest(int nRays, int *nFull, int *nMaybe) {
+    int violations = 0, full = 0, maybe = 0;
+    RNG rng(77);
+    for (int i = 0; i < nRays; ++i) {
+        Sphere s;
+        const Float radius = pExp(rng, 2.);
+        V3 c(Lerp(rng.UniformFloat(), -50, 50), Lerp(rng.UniformFloat(), -50, 50), Lerp(rng.UniformFloat(), -50, 50));
+        const Float sx = pExp(rng, .5), sy = pExp(rng, .5), sz = pExp(rng, .5);
+        Xf x = XfMul(XfTranslate(c), XfScale(sx, sy, sz));
+        s.o2w = x.m; s.w2o = x.mInv;
+        s.radius = radius; s.zMin = -radius; s.zMax = radius; s.thetaMin = Pi; s.thetaMax = 0; s.phiMax = 2 * Pi;
+        if (i % 7 == 0) { s.zMax = radius * 0.4f; s.phiMax = 4.f; }
+        V3 o = c + V3(Lerp(rng.UniformFloat(), -4, 4) * radius * sx, Lerp(rng.UniformFloat(), -4, 4) * radius * sy, Lerp(rng.UniformFloat(), -4, 4) * radius * sz);
+        V3 target = c + V3(Lerp(rng.UniformFloat(), -1.3f, 1.3f) * radius * sx, Lerp(rng.UniformFloat(), -1.3f, 1.3f) * radius * sy, Lerp(rng.UniformFloat(), -1.3f, 1.3f) * radius * sz);
+        V3 d = target - o;
+        if (i % 3 == 0) d = Normalize(d);
+        Float tMax = Infinity;
+        Ray probe(o, d, Infinity);
+        Ray ro; V3 ph; Float phi, t;
+        if (i % 2 == 0 && SphereTest(s, probe, &ro, &ph, &phi, &t)) {
+            const Float f[5] = {0.9999f, 0.99999994f, 1.f, 1.0000001f, 1.0001f};
+            tMax = t * f[i % 5];
+        }
+        Ray r(o, d, tMax);
+        // value lanes only
+        V3 oErr, dErr;
+        Ray ray = XfRayErr(s.w2o, r, &oErr, &dErr);
+        const Float a = (ray.d.x * ray.d.x + ray.d.y * ray.d.y) + ray.d.z * ray.d.z;
+        const Float b = 2.f * ((ray.d.x * ray.o.x + ray.d.y * ray.o.y) + ray.d.z * ray.o.z);
+        const Float cc = ((ray.o.x * ray.o.x + ray.o.y * ray.o.y) + ray.o.z * ray.o.z) - s.radius * s.radius;
+        bool may = true;
+        const double discrim = (double)b * (double)b - 4. * (double)a * (double)cc;
+        if (discrim < 0.) may = false;
+        else {
+            const Float fr = (Float)std::sqrt(discrim);
+            const Float q = b < 0 ? -.5f * (b - fr) : -.5f * (b + fr);
+            Float t0 = q / a, t1 = cc / q;
+            if (t0 > t1) std::swap(t0, t1);
+            if (t0 > r.tMax || t1 <= 0) may = false;
+        }
+        const bool hit = SphereTest(s, r, &ro, &ph, &phi, &t);
+        if (hit) ++full;
+        if (may) ++maybe;
+        if (hit && !may) ++violations;
+    }
+    *nFull = full; *nMaybe = maybe;
+    return violations;
+}
+
 }  // namespace orc

@@ -60,6 +60,17 @@ def test_reference_unit_tests_restated(orc):
     assert n.value > 150
 
 
+def test_value_lanes_of_the_quadric_test_never_reject_a_hit(orc):
+    """The exact pre-test the HIP kernel runs in front of the interval-arithmetic sphere test (csrc/device/dev_intersect.h):
+    over two million rays at every scale — half of them cut just short of / just beyond the surface, as shadow rays are —
+    the value-lane rejections never contradict the full test, and they do settle most rays."""
+    lib = orc.lib
+    full, maybe = C.c_int(), C.c_int()
+    n = 2000000
+    assert lib.orc_selftest_sphere_pretest(n, C.byref(full), C.byref(maybe)) == 0
+    assert 0 < full.value <= maybe.value < 0.6 * n         # (the rest of "maybe": clipped partial spheres and interval border cases)
+
+
 def test_triangle_bad_case_kat(orc):
     # Triangle.BadCases, tests/shapes.cpp:544-559: a degenerate triangle must not be hit
     p = np.array([-1113.45459, -79.049614, -56.2431908, -1113.45459, -87.0922699, -56.2431908,
