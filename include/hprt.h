@@ -243,6 +243,13 @@ typedef struct HprtRenderDesc {
 } HprtRenderDesc;
 #define HPRT_RENDER_COUNT_WORK 1   /* collect node/triangle counters (slower) */
 #define HPRT_RENDER_PIXEL_STATS 2  /* also keep them per pixel: the fork's GeneralStats heat-map data (implies COUNT_WORK) */
+/* EstimateDirect's BSDF-sampled ray (core/integrator.cpp:176-190) is only traced to learn whether its closest hit is the
+ * emitter.  A plain render does not trace it when a cheap exact test proves that it cannot reach the emitter's sphere
+ * (it would add exactly zero): same film, fewer rays.  A counting render traces every ray the reference traces, so that
+ * its counters are the reference's — unless COUNT_TRACED asks it to count what a plain render traces.  TRACE_ALL makes a
+ * plain render trace the reference's full ray set too. */
+#define HPRT_RENDER_COUNT_TRACED 4
+#define HPRT_RENDER_TRACE_ALL 8
 
 typedef struct HprtRenderStats {
     uint64_t camera_rays;          /* nCameraRays, core/integrator.cpp:48,293 */

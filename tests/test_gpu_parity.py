@@ -229,3 +229,30 @@ def test_reference_regression_scenes_full_frame(hprt, orc, name):
     assert np.array_equal(film0.view(np.uint32), film1.view(np.uint32))
     assert st["rays"] == c0["rays"] and st["shadow_rays"] == c0["shadow_rays"] and st["nodes_fetched"] == c0["nodes_fetched"]
     assert st["tri_tests"] == c0["tri_tests"] and st["sphere_tests_p"] == c0["sphere_tests_p"]
+
+
+def test_untraced_light_rays_change_nothing(hprt, killeroo_model, killeroo_scene, killeroo_oracle):
+    """EstimateDirect's BSDF-sampled ray (core/integrator.cpp:176-190) is traced only to learn whether its closest hit is the
+    emitter.  A plain render skips it when the quadric pre-test proves that the emitter's Intersect would return false for
+    it whatever tMax is (tests/test_oracle_pins.py holds the pre-test to the interval test): the film must be the film of
+    the render that traces every ray, bit for bit, with far fewer closest-hit rays; a counting render traces the
+    reference's full ray set unless told to count what a plain render traces."""
+    opt = killeroo_model.options.copy()
+    crop = (0.30, 0.30 + 160 / 700.0, 0.40, 0.40 + 128 / 700.0)
+    for i in range(4):
+        opt.crop[i] = crop[i]
+    opt.spp = 32
+    film_all, st_all = killeroo_scene.render(opt, trace_all=True)
+    film_cut, st_cut = killeroo_scene.render(opt)
+    assert np.array_equal(film_all.view(np.uint32), film_cut.view(np.uint32))
+    assert st_cut["shadow_rays"] == st_all["shadow_rays"] and st_cut["camera_rays"] == st_all["camera_rays"]
+    assert st_cut["rays"] < 0.8 * st_all["rays"]
+    _, st_ref = killeroo_scene.render(opt, count_work=True)                        # the reference's ray set and counters
+    _, st_traced = killeroo_scene.render(opt, count_work=True, count_traced=True)   # what the plain render traced
+    assert st_ref["rays"] == st_all["rays"] and st_traced["rays"] == st_cut["rays"]
+    assert st_traced["nodes_fetched"] < st_ref["nodes_fetched"] and st_traced["nodes_fetched_p"] == st_ref["nodes_fetched_p"]
+    killeroo_oracle.set_film(crop=crop, spp=32)
+    _, film0, c0, _, _ = killeroo_oracle.render(spp=32, threads=8)
+    killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
+    assert np.array_equal(film0.view(np.uint32), film_cut.view(np.uint32))
+    assert c0["rays"] == st_ref["rays"] and c0["nodes_fetched"] == st_ref["nodes_fetched"]

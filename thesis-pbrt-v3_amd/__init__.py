@@ -31,6 +31,8 @@ class HprtError(RuntimeError):
 E_INVALID, E_IO, E_PARSE, E_NO_DEVICE, E_DEVICE, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 RENDER_COUNT_WORK = 1
 RENDER_PIXEL_STATS = 2
+RENDER_COUNT_TRACED = 4
+RENDER_TRACE_ALL = 8
 
 
 class RenderOptions(C.Structure):
@@ -293,14 +295,16 @@ class Scene:
         _check(lib.hprt_occluded_device(self._h, n, rays7_ptr, occ_ptr, stream))
 
     def render(self, opt=None, tile_begin=0, tile_end=0, tile_stride=1, spp_chunk=0, count_work=False, film_ptr=None,
-               stream=None, pixel_stats=False):
+               stream=None, pixel_stats=False, count_traced=False, trace_all=False):
         """Render(): returns (film_xyzw [H,W,4] float32 or None when film_ptr is given, stats dict)."""
         opt = opt or self._model.options
         desc = RenderDesc()
         desc.opt = opt
         desc.tile_begin, desc.tile_end, desc.tile_stride = tile_begin, tile_end, tile_stride
         desc.spp_chunk = spp_chunk
-        desc.flags = (RENDER_COUNT_WORK if count_work else 0) | (RENDER_PIXEL_STATS if pixel_stats else 0)
+        # count_traced / trace_all: see HPRT_RENDER_COUNT_TRACED / HPRT_RENDER_TRACE_ALL in include/hprt.h
+        desc.flags = (RENDER_COUNT_WORK if count_work else 0) | (RENDER_PIXEL_STATS if pixel_stats else 0) | \
+                     (RENDER_COUNT_TRACED if count_traced else 0) | (RENDER_TRACE_ALL if trace_all else 0)
         self._film_shape = tuple(int(v) for v in (opt.film_bounds()[3] - opt.film_bounds()[1], opt.film_bounds()[2] - opt.film_bounds()[0]))
         st = RenderStats()
         _check(lib.hprt_render(self._h, C.byref(desc), film_ptr, stream, C.byref(st)))

@@ -880,6 +880,8 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     rp.invSqrtSpp = 1 / std::sqrt((float)spp);      // ScaleDifferentials' factor, core/integrator.cpp:288-289
     const bool wantPixelStats = (desc->flags & HPRT_RENDER_PIXEL_STATS) != 0;
     const bool count = (desc->flags & HPRT_RENDER_COUNT_WORK) != 0 || wantPixelStats;
+    // a counting render traces exactly the reference's rays (its counters are the reference's) unless asked to count what a plain render traces
+    rp.cullMis = (!count || (desc->flags & HPRT_RENDER_COUNT_TRACED) != 0) && !(desc->flags & HPRT_RENDER_TRACE_ALL) ? 1 : 0;
     uint32_t *pixelStats = nullptr;
     if (wantPixelStats) {
         HIP_TRY(s->rayStats.alloc(sizeof(uint4) * maxSlots));
@@ -1033,6 +1035,7 @@ int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, c
     rp.hal.samplePixelCenter = opt->sample_pixel_center;
     rp.pixelXY = s->pixelXY.as<uint32_t>(); rp.pixelOffset = s->pixelOffset.as<uint64_t>(); rp.nPix = (uint32_t)n;
     rp.maxDepth = opt->max_depth; rp.rrThreshold = opt->rr_threshold;
+    rp.invSqrtSpp = 1 / std::sqrt((float)std::max(1, opt->spp)); rp.cullMis = 1;
     EventTimer ev; BatchTimers bt; HprtRenderStats stats; memset(&stats, 0, sizeof(stats));
     rc = RunBatch(s, nullptr, rp, ps, qa, qb, bins, 0, (uint32_t)n, false, ev, &bt, &stats);
     if (rc != HPRT_OK) return rc;

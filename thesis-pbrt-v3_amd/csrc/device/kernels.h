@@ -44,6 +44,7 @@ struct RenderParams {
     int32_t maxDepth;
     float rrThreshold;
     float invSqrtSpp;               // 1 / sqrt(samplesPerPixel): ray differential scale (image textures only)
+    int32_t cullMis;                // do not trace a BSDF-sampled light ray that provably cannot reach its emitter (k_shade)
 };
 struct FilmGeom {
     int32_t cx0, cy0, cx1, cy1;     // croppedPixelBounds

@@ -46,6 +46,8 @@ if args.cpu_spp:
     baked = os.path.join(tmp, "scene.hprt"); model.save(baked)
     o = orc.OracleScene(baked)
     _, _, c, sec, nt = o.render(spp=args.cpu_spp, threads=os.cpu_count())
-    out["cpu_port"] = {"mrays_per_s": round((c["rays"] + c["shadow_rays"]) / sec / 1e6, 2), "threads": nt, "spp": args.cpu_spp, "seconds": round(sec, 2)}
-    out["gpu_over_cpu"] = round(out["mrays_per_s"] / out["cpu_port"]["mrays_per_s"], 1)
+    out["cpu_port"] = {"mrays_per_s": round((c["rays"] + c["shadow_rays"]) / sec / 1e6, 2), "msamples_per_s": round(c["camera_rays"] / sec / 1e6, 3),
+                       "threads": nt, "spp": args.cpu_spp, "seconds": round(sec, 2)}
+    # same frame on both sides: ratio of frame rates (the GPU's mrays_per_s counts traced rays only, the CPU port traces the reference's full set)
+    out["gpu_over_cpu"] = round(out["msamples_per_s"] / out["cpu_port"]["msamples_per_s"], 1)
 print(json.dumps(out))
