@@ -245,7 +245,8 @@ typedef struct HprtRenderDesc {
 #define HPRT_RENDER_PIXEL_STATS 2  /* also keep them per pixel: the fork's GeneralStats heat-map data (implies COUNT_WORK) */
 /* EstimateDirect's BSDF-sampled ray (core/integrator.cpp:176-190) is only traced to learn whether its closest hit is the
  * emitter.  A plain render does not trace it when a cheap exact test proves that it cannot reach the emitter's sphere
- * (it would add exactly zero): same film, fewer rays.  A counting render traces every ray the reference traces, so that
+ * (it would add exactly zero), nor the segment that leaves a path's last vertex (the reference intersects it and stops,
+ * integrators/path.cpp:97-110): same film, fewer rays.  A counting render traces every ray the reference traces, so that
  * its counters are the reference's — unless COUNT_TRACED asks it to count what a plain render traces.  TRACE_ALL makes a
  * plain render trace the reference's full ray set too. */
 #define HPRT_RENDER_COUNT_TRACED 4

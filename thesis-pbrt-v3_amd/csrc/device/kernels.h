@@ -44,7 +44,8 @@ struct RenderParams {
     int32_t maxDepth;
     float rrThreshold;
     float invSqrtSpp;               // 1 / sqrt(samplesPerPixel): ray differential scale (image textures only)
-    int32_t cullMis;                // do not trace a BSDF-sampled light ray that provably cannot reach its emitter (k_shade)
+    int32_t cullMis;                // do not trace rays whose result provably changes nothing (k_shade): a BSDF-sampled light ray that
+                                    // cannot reach its emitter, the segment behind the last vertex of a path
 };
 struct FilmGeom {
     int32_t cx0, cy0, cx1, cy1;     // croppedPixelBounds

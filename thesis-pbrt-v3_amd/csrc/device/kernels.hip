@@ -775,6 +775,10 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                     if (u < qv) alive = false;
                     else beta = beta / (1 - qv);
                 }
+                // The reference also traces the segment that leaves the path's last vertex (bounces == maxDepth) and then
+                // stops without using its hit: no emission is added after a non-specular bounce (path.cpp:97-110).  A plain
+                // render does not trace that ray; a counting render does, the reference counts it.
+                if (rp.cullMis && bounces + 1 >= rp.maxDepth) alive = false;
                 if (alive) {
                     out.ray.a[j] = make_float4(o.x, o.y, o.z, HPRT_INF);
                     out.ray.b[j] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((uint32_t)dim | ((uint32_t)(bounces + 1) << 8)));
