@@ -723,23 +723,23 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                         rgb f = bsdf_sample(bsdf, si.wo, &wi, us0, us1, &scatteringPdf, &sampledType);
                         f = f * absdot(wi, si.ns);
                         if (!is_black(f) && scatteringPdf > 0) {
-                            float lp = light_pdf<MODE == 2>(sc, light, it, wi);
-                            if (lp != 0) {     // "if (lightPdf == 0) return Ld;" keeps the light-sampling term only
-                                float w = power_heuristic(scatteringPdf, lp);
-                                vec3 o = offset_ray_origin(si.p, si.pErr, si.n, wi);
-                                // EstimateDirect traces this ray only to learn whether its closest hit is the emitter
-                                // (core/integrator.cpp:176-190); Sphere::Pdf is non-zero for every direction, so most of these
-                                // rays point nowhere near it.  The quadric pre-test (dev_intersect.h) proves for a ray that the
-                                // emitter's Intersect returns false whatever tMax is; such a ray adds exactly nothing and is
-                                // not traced.  (Counting renders trace it anyway unless told otherwise: the reference counts it.)
-                                DRay mr; mr.o = o; mr.d = wi; mr.tMax = HPRT_INF;
-                                if (!rp.cullMis || sphere_may_hit(sc.spheres[light.sphere], mr)) {
-                                vs.mis.a[j] = make_float4(o.x, o.y, o.z, HPRT_INF);
-                                vs.mis.b[j] = make_float4(wi.x, wi.y, wi.z, 0.f);
-                                // contribution if the ray reaches the light's emitting side: f * Li * Tr * weight / pdf
-                                rgb Lemit(light.I[0], light.I[1], light.I[2]);
-                                pendMis = f * Lemit * rgb(1.f) * w / scatteringPdf;
-                                wantMis = true;
+                            // EstimateDirect traces this ray only to learn whether its closest hit is the emitter
+                            // (core/integrator.cpp:176-190); Sphere::Pdf is non-zero for every direction, so most of these
+                            // rays point nowhere near it.  The quadric pre-test (dev_intersect.h) proves for a ray that the
+                            // emitter's Intersect returns false whatever tMax is; such a ray adds exactly nothing and is
+                            // not traced.  (Counting renders trace it anyway unless told otherwise: the reference counts it.)
+                            const vec3 o = offset_ray_origin(si.p, si.pErr, si.n, wi);
+                            DRay mr; mr.o = o; mr.d = wi; mr.tMax = HPRT_INF;
+                            if (!rp.cullMis || sphere_may_hit(sc.spheres[light.sphere], mr)) {
+                                const float lp = light_pdf<MODE == 2>(sc, light, it, wi);
+                                if (lp != 0) {     // "if (lightPdf == 0) return Ld;" keeps the light-sampling term only
+                                    const float w = power_heuristic(scatteringPdf, lp);
+                                    vs.mis.a[j] = make_float4(o.x, o.y, o.z, HPRT_INF);
+                                    vs.mis.b[j] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                                    // contribution if the ray reaches the light's emitting side: f * Li * Tr * weight / pdf
+                                    rgb Lemit(light.I[0], light.I[1], light.I[2]);
+                                    pendMis = f * Lemit * rgb(1.f) * w / scatteringPdf;
+                                    wantMis = true;
                                 }
                             }
                         }
