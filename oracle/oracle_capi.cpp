@@ -200,6 +200,9 @@ void orc_sample_radiance(void *h, size_t n, const int *px, const int *py, const 
     Renderer *r = (Renderer *)h;
     int sx0, sy0, sx1, sy1; r->film.GetSampleBounds(&sx0, &sy0, &sx1, &sy1);
     HaltonSampler s(1 << 30, sx0, sy0, sx1, sy1, r->scene.prm.samplePixelCenter != 0);
+    // any sample index may be asked for, but the samples belong to the frame of the scene's spp: the camera ray differentials
+    // are scaled by 1/sqrt(samplesPerPixel) (core/integrator.cpp:288-289; only image textures see them)
+    s.samplesPerPixel = r->scene.prm.spp;
     Counters ctr;
     for (size_t i = 0; i < n; ++i) {
         s.StartPixel(px[i], py[i]); s.SetSampleNumber(sn[i]);

@@ -133,3 +133,26 @@ def test_pixel_statistics_with_instances_and_textures(hprt, orc, tmp_path):
     assert got.shape == ref.shape and ref[..., 1].sum() > 0 and ref[..., 4].sum() > 0
     assert np.array_equal(got, ref)
     assert int(got[..., 1].sum()) == st["tri_tests"] + st["sphere_tests"]
+
+
+def test_per_sample_radiance_on_a_textured_scene(hprt, orc, tmp_path):
+    """hprt_sample_radiance (single camera samples, the entry point the reference-side parity harness would use) must scale
+    the camera ray differentials by 1/sqrt(spp) exactly as the frame render does (core/integrator.cpp:288-289): radiance of
+    random (pixel, sample index) pairs of a textured scene against the oracle."""
+    name = "floor_ewa_repeat"
+    _write_images(tmp_path)
+    p = tmp_path / (name + ".pbrt")
+    p.write_text(CASES[name] % {"dir": str(tmp_path)})
+    model = hprt.Model.parse(str(p))
+    baked = str(tmp_path / (name + ".hprt")); model.save(baked)
+    oracle = orc.OracleScene(baked)
+    scene = hprt.Scene(model, hprt.Bvh(model))
+    rng = np.random.default_rng(5)
+    n = 20000
+    px = rng.integers(0, 128, n).astype(np.int32); py = rng.integers(0, 96, n).astype(np.int32)
+    s = rng.integers(0, 4, n).astype(np.int64)
+    L0 = oracle.sample_radiance(px, py, s)
+    L1 = scene.sample_radiance(px, py, s)
+    bad = np.any(L0.view(np.uint32) != L1.view(np.uint32), axis=1)
+    assert not bad.any(), "%d of %d samples differ; max |d| = %g" % (int(bad.sum()), n, float(np.abs(L0 - L1).max()))
+    assert L0.max() > 0
