@@ -150,8 +150,8 @@ int hprt_bvh_info(const HprtBvh *b, uint32_t info[4], float bounds6[6]) {
 }
 int hprt_bvh_copy(const HprtBvh *b, void *nodes32, uint32_t *prim_order) {
     if (!b) return SetError(HPRT_E_INVALID, "hprt_bvh_copy: null argument");
-    if (nodes32) memcpy(nodes32, b->tree.nodes.data(), b->tree.nodes.size() * sizeof(BvhNode));
-    if (prim_order) memcpy(prim_order, b->tree.primOrder.data(), b->tree.primOrder.size() * 4);
+    if (nodes32 && !b->tree.nodes.empty()) memcpy(nodes32, b->tree.nodes.data(), b->tree.nodes.size() * sizeof(BvhNode));
+    if (prim_order && !b->tree.primOrder.empty()) memcpy(prim_order, b->tree.primOrder.data(), b->tree.primOrder.size() * 4);
     return HPRT_OK;
 }
 
@@ -168,8 +168,8 @@ int hprt_bvh_object_info(const HprtBvh *b, uint32_t object, uint32_t info[4], fl
 int hprt_bvh_object_copy(const HprtBvh *b, uint32_t object, void *nodes32, uint32_t *prim_order) {
     if (!b || object >= b->objects.size()) return SetError(HPRT_E_INVALID, "hprt_bvh_object_copy: bad argument");
     const BvhTree &t = b->objects[object];
-    if (nodes32) memcpy(nodes32, t.nodes.data(), t.nodes.size() * sizeof(BvhNode));
-    if (prim_order) memcpy(prim_order, t.primOrder.data(), t.primOrder.size() * 4);
+    if (nodes32 && !t.nodes.empty()) memcpy(nodes32, t.nodes.data(), t.nodes.size() * sizeof(BvhNode));
+    if (prim_order && !t.primOrder.empty()) memcpy(prim_order, t.primOrder.data(), t.primOrder.size() * 4);
     return HPRT_OK;
 }
 
