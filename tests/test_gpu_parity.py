@@ -227,6 +227,8 @@ def test_reference_regression_scenes_full_frame(hprt, orc, name):
     _, film0, c0, _, _ = oracle.render(threads=16)
     film1, st = scene.render(count_work=True)
     assert np.array_equal(film0.view(np.uint32), film1.view(np.uint32))
+    film_plain, st_plain = scene.render()      # plain render: dead rays not traced, same film
+    assert np.array_equal(film0.view(np.uint32), film_plain.view(np.uint32)) and st_plain["rays"] <= st["rays"]
     assert st["rays"] == c0["rays"] and st["shadow_rays"] == c0["shadow_rays"] and st["nodes_fetched"] == c0["nodes_fetched"]
     assert st["tri_tests"] == c0["tri_tests"] and st["sphere_tests_p"] == c0["sphere_tests_p"]
 

@@ -105,6 +105,9 @@ def test_scene_film_parity(hprt, orc, tmp_path, name):
     scene = hprt.Scene(model, bvh)
     rgb0, film0, c0, _, _ = oracle.render(threads=8)
     film1, st = scene.render(count_work=True)
+    # the plain render (rays that provably change nothing are not traced) must give the same film
+    film_plain, st_plain = scene.render()
+    assert np.array_equal(film_plain.view(np.uint32), film1.view(np.uint32)) and st_plain["rays"] <= st["rays"] and st_plain["shadow_rays"] == st["shadow_rays"]
     assert film1.shape == film0.shape
     bad = np.any(film0.view(np.uint32) != film1.view(np.uint32), axis=2)
     assert not bad.any(), "%s: %d pixels differ, max |d| = %g" % (name, int(bad.sum()), float(np.abs(film0 - film1).max()))
@@ -166,6 +169,9 @@ def test_ten_million_instanced_triangles(hprt, orc, tmp_path):
     scene = hprt.Scene(model, bvh); oracle = orc.OracleScene(baked)
     _, film0, c0, _, _ = oracle.render(threads=8)
     film1, st = scene.render(count_work=True)
+    # the plain render (rays that provably change nothing are not traced) must give the same film
+    film_plain, st_plain = scene.render()
+    assert np.array_equal(film_plain.view(np.uint32), film1.view(np.uint32)) and st_plain["rays"] <= st["rays"] and st_plain["shadow_rays"] == st["shadow_rays"]
     assert np.array_equal(film0.view(np.uint32), film1.view(np.uint32))
     assert st["nodes_fetched"] == c0["nodes_fetched"] and st["tri_tests"] == c0["tri_tests"] and st["tri_tests_p"] == c0["tri_tests_p"]
     assert film0[..., :3].max() > 0
@@ -194,6 +200,9 @@ def test_sponza_class_interior(hprt, orc, tmp_path):
     scene = hprt.Scene(model, bvh)
     _, film0, c0, _, _ = oracle.render(threads=8)
     film1, st = scene.render(count_work=True)
+    # the plain render (rays that provably change nothing are not traced) must give the same film
+    film_plain, st_plain = scene.render()
+    assert np.array_equal(film_plain.view(np.uint32), film1.view(np.uint32)) and st_plain["rays"] <= st["rays"] and st_plain["shadow_rays"] == st["shadow_rays"]
     assert np.array_equal(film0.view(np.uint32), film1.view(np.uint32))
     for k in ("rays", "shadow_rays", "nodes_fetched", "nodes_fetched_p", "tri_tests", "tri_tests_p"):
         assert st[k] == c0[k], k
@@ -217,8 +226,11 @@ def test_living_room_real_interior(hprt, orc):
     opt.xres, opt.yres, opt.spp = 192, 108, 4
     oracle.set_film(xres=192, yres=108, spp=4)
     _, film0, c0, _, _ = oracle.render(threads=8)
-    film1, st = hprt.Scene(model, bvh).render(opt, count_work=True)
+    scene = hprt.Scene(model, bvh)
+    film1, st = scene.render(opt, count_work=True)
     assert np.array_equal(film0.view(np.uint32), film1.view(np.uint32))
+    film_plain, st_plain = scene.render(opt)       # plain render: the segment behind the last vertex is not traced
+    assert np.array_equal(film0.view(np.uint32), film_plain.view(np.uint32)) and st_plain["rays"] < st["rays"]
     for k in ("camera_rays", "rays", "shadow_rays", "nodes_fetched", "nodes_fetched_p", "tri_tests", "tri_tests_p"):
         assert st[k] == c0[k], (k, st[k], c0[k])
     assert (film0[..., :3].sum(axis=2) > 0).mean() > 0.9      # a lit room, not a black frame

@@ -90,6 +90,9 @@ def test_textured_film_parity(hprt, orc, tmp_path, name):
     scene = hprt.Scene(model, bvh)
     rgb0, film0, c0, _, _ = oracle.render(threads=8)
     film1, st = scene.render(count_work=True)
+    # the plain render (rays that provably change nothing are not traced) must give the same film
+    film_plain, st_plain = scene.render()
+    assert np.array_equal(film_plain.view(np.uint32), film1.view(np.uint32)) and st_plain["rays"] <= st["rays"] and st_plain["shadow_rays"] == st["shadow_rays"]
     assert film1.shape == film0.shape
     bad = np.any(film0.view(np.uint32) != film1.view(np.uint32), axis=2)
     assert not bad.any(), "%s: %d pixels differ, max |d| = %g" % (name, int(bad.sum()), float(np.abs(film0 - film1).max()))
