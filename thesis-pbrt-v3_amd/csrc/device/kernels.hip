@@ -747,7 +747,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                     if (wantShadow || wantMis) {
                         vs.pendLight[j] = make_float4(pendLight.r, pendLight.g, pendLight.b,
                                                       __uint_as_float((uint32_t)lightNum | (wantShadow ? 0x40000000u : 0u) | (wantMis ? 0x80000000u : 0u)));
-                        vs.pendMis[j] = make_float4(pendMis.r, pendMis.g, pendMis.b, pickPdf);
+                        if (wantMis) vs.pendMis[j] = make_float4(pendMis.r, pendMis.g, pendMis.b, pickPdf);      // (k_resolve re-derives pickPdf from the light number)
                         vs.pendBeta[j] = make_float4(beta.r, beta.g, beta.b, beta4.w);
                         wantResolve = true;
                     }
@@ -820,9 +820,14 @@ __global__ __launch_bounds__(256) void k_resolve(DevScene sc, VertexStreams vs, 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t j = queue[i];
-    const float4 pl = vs.pendLight[j], pm = vs.pendMis[j], pb = vs.pendBeta[j], L4 = Lio[j];
+    const float4 pl = vs.pendLight[j], pb = vs.pendBeta[j], L4 = Lio[j];
     const uint32_t info = __float_as_uint(pl.w);
     const int lightNum = (int)(info & 0x3fffffffu);
+    // the pending BSDF-sampled term exists for few vertices (most such rays are never queued): read it only then
+    float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (info & 0x80000000u) pm = vs.pendMis[j];
+    // lightPdf of UniformSampleOneLight, as light_pick computed it for this light (core/integrator.cpp:94-99)
+    const float pickPdf = (sc.lightFuncInt > 0) ? sc.lightFunc[lightNum] / (sc.lightFuncInt * (int)sc.nLights) : 0;
     rgb Ld(0.f);
     if ((info & 0x40000000u) && !vs.occluded[j]) Ld = Ld + rgb(pl.x, pl.y, pl.z);
     if (info & 0x80000000u) {
@@ -841,7 +846,7 @@ __global__ __launch_bounds__(256) void k_resolve(DevScene sc, VertexStreams vs, 
             }
         }
     }
-    rgb add = rgb(pb.x, pb.y, pb.z) * (Ld / pm.w);
+    rgb add = rgb(pb.x, pb.y, pb.z) * (Ld / pickPdf);
     const float4 Lnew = make_float4(L4.x + add.r, L4.y + add.g, L4.z + add.b, L4.w);
     if (L4.w != 0.f) Lio[j] = Lnew;                                   // the path goes on: radiance travels with it
     else Lfinal[__float_as_uint(pb.w)] = Lnew;                        // last vertex of the path
