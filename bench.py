@@ -79,11 +79,11 @@ def main():
     film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)   # device memory via torch: plumbing only
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def step(count_work=False, gather=True, count_traced=True):
+    def step(count_work=False, gather=True, count_traced=True, trace_all=False):
         # count_traced: the counting pass counts the rays the timed passes trace (a plain render does not trace a BSDF-sampled
         # light ray that provably cannot reach its emitter; include/hprt.h, HPRT_RENDER_COUNT_TRACED)
         _, st = scene.render(opt, spp_chunk=args.spp_chunk, count_work=count_work, count_traced=count_work and count_traced,
-                             film_ptr=film.data_ptr(), stream=stream, **tiles.shard(rank, max(1, world)))
+                             trace_all=trace_all, film_ptr=film.data_ptr(), stream=stream, **tiles.shard(rank, max(1, world)))
         if dist is not None and gather:
             tiles.gather_film(film, dist, dst=0)             # Film tiles -> rank 0 (RCCL over xGMI); addends are disjoint
         return st
@@ -123,6 +123,14 @@ def main():
         st_ref = step(count_work=True, gather=False, count_traced=False)   # untimed: the reference's full ray set (what the CPU baseline traces)
         torch.cuda.synchronize(dev)
         ref_over_traced = (st_ref["rays"] + st_ref["shadow_rays"]) / max(1, st_c["rays"] + st_c["shadow_rays"])
+        # for comparison (untimed for `value`): the same frame with every ray of the reference traced (HPRT_RENDER_TRACE_ALL)
+        trace_all_info = None
+        if world == 1:
+            torch.cuda.synchronize(dev); ta0 = time.perf_counter()
+            ta = [step(gather=False, trace_all=True) for _ in range(args.steps)]
+            torch.cuda.synchronize(dev); ta_sec = time.perf_counter() - ta0
+            trace_all_info = {"ms_per_step": round(1e3 * ta_sec / max(1, args.steps), 2),
+                              "mrays_per_s": round(sum(s["rays"] + s["shadow_rays"] for s in ta) / ta_sec / 1e6, 2)}
         ext_rays = sum(s["extend_rays"] for s in stats)
         ext_sec = sum(s["extend_seconds"] for s in stats)
         ext_launches = sum(s["extend_launches"] for s in stats)
@@ -178,6 +186,7 @@ def main():
             # reach the emitter are answered without a trace here (same film, bit for bit) and are NOT counted in `value`.
             "rays_per_step": int(total_rays / max(1, args.steps)),
             "reference_rays_per_step": int(total_rays * ref_over_traced / max(1, args.steps)),
+            "with_every_reference_ray_traced": trace_all_info,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         if cpu_baseline:
