@@ -750,7 +750,7 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         hipEvent_t e0 = ev.get(), e1 = ev.get();
         HIP_TRY(hipEventRecord(e0, st));
         LaunchTrace(st, s->dev, false, count, activeQ, nullptr, active, active, in.ray, w.hit, nullptr, ctr, s->workCounter.as<uint32_t>(), rayStats);
-        if (pixelStats) LaunchPixelStats(st, rayStats, in.beta, activeQ, nullptr, active, active, rp.nPix, false, pixelStats);
+        if (pixelStats) LaunchPixelStats(st, rayStats, bounce == 0 ? nullptr : in.beta, activeQ, nullptr, active, active, rp.nPix, false, pixelStats);
         HIP_TRY(hipEventRecord(e1, st));
         evExt.push_back({e0, e1}); bt->extendRays += active; ++bt->extendLaunches;
         stats->rays += active;
@@ -760,7 +760,7 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         HIP_TRY(hipMemcpyAsync(bins.count + 3, bins.count + 2, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));   // bin 2 before deferrals
         // one launch per material bin; grids are sized for the upper bound, surplus blocks exit on the bin's count
         for (int mode = 0; mode < 3; ++mode)
-            LaunchShade(st, mode, s->dev, rp, in, w.hit, active, s0, out, w.vs, cur, bins, w.Lfinal);
+            LaunchShade(st, mode, s->dev, rp, in, w.hit, active, s0, out, w.vs, cur, bins, w.Lfinal, bounce == 0);
         HIP_TRY(hipMemcpyAsync(s->hostCounts + 4096, cur.nextCount, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const uint32_t nNext = s->hostCounts[4096], nShadow = s->hostCounts[4096 + 64], nMis = s->hostCounts[4096 + 128], nResolve = s->hostCounts[4096 + 192];

@@ -77,7 +77,7 @@ void LaunchBin(hipStream_t st, const DevScene &sc, const PathStream &in, const H
                float4 *Lfinal);
 void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathStream &in, const HitStream &hit,
                  uint32_t gridItems, uint32_t s0, const PathStream &out, const VertexStreams &vs, const QueueSet &q,
-                 const BinSet &bins, float4 *Lfinal);
+                 const BinSet &bins, float4 *Lfinal, bool firstBounce);
 void LaunchResolve(hipStream_t st, const DevScene &sc, const VertexStreams &vs, float4 *L, float4 *Lfinal, const uint32_t *queue,
                    const uint32_t *countPtr, uint32_t gridItems);
 void LaunchStoreRadiance(hipStream_t st, const float4 *Lfinal, float *LallR, float *LallG, float *LallB, uint32_t nPix, uint32_t s0,

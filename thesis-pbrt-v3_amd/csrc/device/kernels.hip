@@ -514,8 +514,7 @@ __global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, 
     camera_ray(rp.cam, fx, fy, lu, lv, &ray);
     out.ray.a[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tMax);
     out.ray.b[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(5u));   // sampler dimension 5 (after pFilm, time, pLens), bounce 0
-    out.beta[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(slot));
-    out.L[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
+    // beta = (1,1,1 | path id = slot) and L = (0,0,0 | continues) of a fresh path are not stored: k_bin and k_shade know them at bounce 0
 }
 
 // ---------------------------------------------------------------------------
@@ -549,7 +548,10 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
             else if (generic) bin = 2;
             else bin = ((uint32_t)word & HIT_PLASTIC) ? 1 : 0;
         }
-        if (bin < 0) Lfinal[__float_as_uint(in.beta[slot].w)] = in.L[slot];      // the path ends here
+        if (bin < 0) {      // the path ends here
+            if (bounces == 0) Lfinal[slot] = make_float4(0.f, 0.f, 0.f, 1.f);      // fresh path: path id = slot, L = 0 (k_generate)
+            else Lfinal[__float_as_uint(in.beta[slot].w)] = in.L[slot];
+        }
     }
     uint32_t *const ctr[3] = {bins.count + 0, bins.count + 1, bins.count + 2};
     const bool pred[3] = {bin == 0, bin == 1, bin == 2};
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
 // call stack that every other scene would pay for in occupancy).
 template <int MODE, int BS, bool TEX = false>
 __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, PathStream in, HitStream hit, uint32_t s0,
-                                               PathStream out, VertexStreams vs, QueueSet q, BinSet bins, float4 *Lfinal) {
+                                               PathStream out, VertexStreams vs, QueueSet q, BinSet bins, float4 *Lfinal, uint32_t firstBounce) {
     __shared__ HaltonLds hl;
     __shared__ BlockAppendLds al;
     const uint32_t n = bins.count[MODE];
@@ -586,7 +588,10 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
         slot = bins.q[MODE][i];
         j = (MODE == 0 ? 0u : MODE == 1 ? bins.count[0] : bins.count[0] + bins.count[1]) + i;
         if (MODE == 2 && i >= bins.count[3]) j = bins.aux[i];       // deferred by a specialised variant: keeps that variant's index
-        const float4 rayA = in.ray.a[slot], rayB = in.ray.b[slot], beta4 = in.beta[slot], L4 = in.L[slot], hitA = hit.a[slot];
+        const float4 rayA = in.ray.a[slot], rayB = in.ray.b[slot], hitA = hit.a[slot];
+        // a fresh path's throughput and radiance are constants (k_generate does not store them)
+        const float4 beta4 = firstBounce ? make_float4(1.f, 1.f, 1.f, __uint_as_float(slot)) : in.beta[slot];
+        const float4 L4 = firstBounce ? make_float4(0.f, 0.f, 0.f, 1.f) : in.L[slot];
         const uint32_t st = __float_as_uint(rayB.w);
         int dim = (int)(st & 0xffu);
         const int bounces = (int)((st >> 8) & 0xffu);
@@ -1026,7 +1031,7 @@ void LaunchBin(hipStream_t st, const DevScene &sc, const PathStream &in, const H
 }
 void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathStream &in, const HitStream &hit,
                  uint32_t gridItems, uint32_t s0, const PathStream &out, const VertexStreams &vs, const QueueSet &q,
-                 const BinSet &bins, float4 *Lfinal) {
+                 const BinSet &bins, float4 *Lfinal, bool firstBounce) {
     if (gridItems == 0) return;
     // workgroup size of the specialised variants (HPRT_SHADE_BLOCK = 1024 | 512 | 256); measured on
     // killeroo-simple: 512 is 3 % faster per frame than 1024 (two decoupled workgroups per CU instead of
@@ -1038,9 +1043,9 @@ void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParam
     }();
     const uint32_t bs = mode == 2 ? 256u : (shadeCfg == 0 ? 1024u : shadeCfg == 1 ? 512u : 256u);
     dim3 grid(blocks_for(gridItems, bs)), block(bs);
-#define HPRT_SHADE_LAUNCH(M, B) hipLaunchKernelGGL((k_shade<M, B>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal)
+#define HPRT_SHADE_LAUNCH(M, B) hipLaunchKernelGGL((k_shade<M, B>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal, firstBounce ? 1u : 0u)
 #define HPRT_SHADE_PICK(M) switch (shadeCfg) { case 0: HPRT_SHADE_LAUNCH(M, 1024); break; case 1: HPRT_SHADE_LAUNCH(M, 512); break; default: HPRT_SHADE_LAUNCH(M, 256); break; }
-    if (mode == 2) { if (sc.textures) hipLaunchKernelGGL((k_shade<2, 256, true>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal); else HPRT_SHADE_LAUNCH(2, 256); }
+    if (mode == 2) { if (sc.textures) hipLaunchKernelGGL((k_shade<2, 256, true>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal, firstBounce ? 1u : 0u); else HPRT_SHADE_LAUNCH(2, 256); }
     else if (mode == 0) { HPRT_SHADE_PICK(0) }
     else { HPRT_SHADE_PICK(1) }
 #undef HPRT_SHADE_PICK
@@ -1078,7 +1083,7 @@ __global__ __launch_bounds__(256) void k_pixel_stats(const uint4 *rayStats, cons
     if (i >= n) return;
     const uint32_t slot = queue ? queue[i] : i;
     const uint4 c = rayStats[slot];
-    const uint32_t p = __float_as_uint(ids[slot].w) % nPix;
+    const uint32_t p = (ids ? __float_as_uint(ids[slot].w) : slot) % nPix;      // ids == nullptr: camera rays, path id = slot
     uint32_t *base = pix + (anyHit ? nPix : 0u) + p;
     if (c.z) atomicAdd(base, c.z);
     if (c.y) atomicAdd(base + 2 * (size_t)nPix, c.y);
