@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--spp-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=128)
+    ap.add_argument("--no-trace-all", action="store_true", help="skip the extra (untimed for value) frames that trace every reference ray; profiling runs use it")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug: all ranks share cuda:0 and the film is reduced with gloo (checks the N>1 control flow on a 1-GPU box)")
     args = ap.parse_args()
@@ -125,7 +126,7 @@ def main():
         ref_over_traced = (st_ref["rays"] + st_ref["shadow_rays"]) / max(1, st_c["rays"] + st_c["shadow_rays"])
         # for comparison (untimed for `value`): the same frame with every ray of the reference traced (HPRT_RENDER_TRACE_ALL)
         trace_all_info = None
-        if world == 1:
+        if world == 1 and not args.no_trace_all:
             torch.cuda.synchronize(dev); ta0 = time.perf_counter()
             ta = [step(gather=False, trace_all=True) for _ in range(args.steps)]
             torch.cuda.synchronize(dev); ta_sec = time.perf_counter() - ta0

@@ -10,7 +10,7 @@ echo "tests rc=$?"; tail -3 gpurun_out/$L/tests.log
 timeout -k 10 600 python bench.py --steps 3 --warmup 1 > gpurun_out/$L/bench.log 2>&1
 echo "bench rc=$?"; grep '"metric"' gpurun_out/$L/bench.log | tail -1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$L/prof -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/$L/prof.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$L/prof -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-trace-all > $R/gpurun_out/$L/prof.log 2>&1
 echo "prof rc=$?"
 python3 - <<PY
 import csv,glob

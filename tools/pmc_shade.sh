@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-pmcs}
 mkdir -p $OUT
 run() {
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $OUT/$1 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp 64 > $OUT/$1.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $OUT/$1 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-trace-all --spp 64 > $OUT/$1.log 2>&1
   echo "$1 rc=$?"
 }
 run p1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU" &&

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-traffic}
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-trace-all > $OUT/$c.log 2>&1
   echo "$c rc=$?"
 done
 python3 $R/tools/traffic_summary.py $OUT > $OUT/traffic.json

@@ -23,5 +23,5 @@ for k, v in agg.items():
     hbm = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
     out[k] = {"launches": v["launches"], "fetch_kib": v["FETCH_SIZE"], "write_kib": v["WRITE_SIZE"],
               "hbm_bytes_per_launch": hbm / max(1, v["launches"]), "hbm_bytes_total": hbm}
-print(json.dumps({"command": "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline", "correction": "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
+print(json.dumps({"command": "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-trace-all", "correction": "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
                   "kernels": out}, indent=1))
