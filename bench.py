@@ -1,58 +1,156 @@
-"""bench.py — Mrays/s of the wavefront path tracer on BASELINE.json's config[1]:
-killeroo-simple (66,532 triangles + 1 sphere emitter), 700x700, Halton 256 spp,
-PathIntegrator maxdepth 5, Accelerator "bvh", on N MI355X.
+"""bench.py — Mrays/s + Msamples/s of the wavefront path tracer on N MI355X (BASELINE.json's metric).
 
-A STEP is one complete Render(): every camera sample of the frame traced through the
-wavefront kernels and folded into the film (inputs — scene, BVH, sampler tables — are
-resident in HBM before the timed region).  With N > 1 the image's 16x16 tiles are dealt
-round-robin to the ranks and the sample count scales with N (spp = 256*N, weak scaling:
-each GPU does the work of the single-GPU frame); the per-rank films are summed onto
-rank 0 with one RCCL reduce over xGMI inside the timed step.
+HEADLINE workload (config.workload) = BASELINE.json configs[2], the largest single-GPU configuration:
+"Sponza (~260k tris) 1024 spp".  The reference repository ships only the scene's header (scenes/sponza:1-17; its
+geometry and textures are git-ignored), so the geometry is a STAND-IN, labelled as such everywhere: the procedural
+312 k-triangle atrium of tools/scene_gen.py (two storeys of arcades, tessellated columns and arches, curtains; matte and
+plastic; one point light as scenes/sponza has), 700x700, Halton 1024 spp, PathIntegrator maxdepth 5, Accelerator "bvh".
+Secondary workloads ride in the same JSON line (`secondary`): configs[1] killeroo-simple 256 spp (the reference's own
+asset, baked) and the reference's living-room meshes at 1280x720, 256 spp (configs[3]'s class with real geometry).
 
-Rays = closest-hit + shadow rays, as the reference counts them (core/scene.cpp:40-55).
+A STEP is one complete Render() of the headline frame: every camera sample traced through the wavefront kernels and
+folded into the film; scene, BVH and sampler tables are resident in HBM before the timed region.  With N > 1 the
+image's 16x16 tiles are dealt round-robin to the ranks at FIXED total spp (strong scaling, the metric's "at fixed spp";
+--weak multiplies spp by N instead) and the per-rank films are merged onto rank 0 inside the timed step by
+hprt_film_gather: one RCCL reduce over xGMI plus the ordered merge of the cross-tile records (csrc/capi_gather.hip).
 
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel = k_trace<closest>; achieved = algorithmic bytes
-                (32 B per BVH node fetched + 48 B per triangle test + 28 B ray read +
-                20 B hit write) / HIP-event time inside that kernel's
-                launches, against the 8 TB/s HBM3E peak.
-  cpu_baseline  the oracle (CPU port of the same path) on all host threads, on a
-                bounded sample of the same workload.
+`python bench.py --gpus N` without WORLD_SIZE in the environment starts N fresh rank processes itself (before this
+process touches the GPU) and relays rank 0's line; under torch.distributed.run it reads RANK/LOCAL_RANK/WORLD_SIZE.
+`n_gpus` is the size the RCCL communicator reports, never the flag.
+
+Rays = closest-hit + shadow rays, as the reference counts them (core/scene.cpp:40-55), TRACED rays only.
+
+Extra objects in the line:
+  roofline      dominant kernel = k_trace<closest>.  achieved/frac = ALGORITHMIC bytes (32 B per BVH node fetched + 48 B
+                per primitive test + 28 B ray read + 20 B hit write; V and T counted by the kernel) /
+                HIP-event time of that kernel's launches, against the 8 TB/s HBM3E peak — the contract's figure.  The
+                BVH lives in L2/MALL, so that figure is NOT an HBM utilisation; the measured ones are beside it:
+                traffic / hbm_counter_frac (FETCH_SIZE/WRITE_SIZE PMC passes), lane_utilisation and wait_frac (SQ
+                counters) per kernel, and the whole frame's hbm_bytes_per_step, all read from the committed summary
+                profiles/r02_counters.json that tools/counters_passes.sh made from `bench.py --profile-step`.
+  cpu_baseline  the oracle (CPU port of the same path, kind "port") on all host threads, on a bounded sample of the
+                same frame.  BASELINE.md §3 relates the port's speed to the reference binary's.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-FIXTURE = os.path.join(ROOT, "tests", "golden", "killeroo_simple.hprt")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")
+
+WORKLOADS = {
+    # name: (description, how to build the model, spp, cpu sample spp, data label)
+    "atrium": ("Sponza-class atrium STAND-IN (311,728 tris, matte+plastic, point light; the reference ships no Sponza geometry) 700x700, "
+               "halton %d spp, path maxdepth 5, bvh", 1024, 32, "synthetic (procedural stand-in geometry, tools/scene_gen.py)"),
+    "killeroo-simple": ("killeroo-simple (66,532 tris + sphere area light) 700x700, halton %d spp, path maxdepth 5, bvh", 256, 64,
+                        "reference asset scenes/killeroo-simple, baked (tests/golden/killeroo_simple.hprt)"),
+    "living-room": ("living room (143,163 tris of the reference's scenes/living-room meshes, matte, point light for its missing sky map) "
+                    "1280x720, halton %d spp, path maxdepth 5, bvh", 256, 16, "reference meshes, baked (tests/golden/living_room.hprt)"),
+}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per GPU (BASELINE config[1]: 256)")
+    ap.add_argument("--workload", default="atrium", choices=sorted(WORKLOADS), help="headline workload (default: BASELINE configs[2])")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel of the headline workload (0: the configuration's own)")
     ap.add_argument("--spp-chunk", type=int, default=0)
+    ap.add_argument("--weak", action="store_true", help="weak scaling: spp x N (default: fixed total spp, strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=128)
-    ap.add_argument("--no-trace-all", action="store_true", help="skip the extra (untimed for value) frames that trace every reference ray; profiling runs use it")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--no-trace-all", action="store_true", help="skip the comparison frames that trace every reference ray")
+    ap.add_argument("--profile-step", action="store_true",
+                    help="profiling runs: ONE plain step of the headline workload and nothing else (no warm-up, counting passes, "
+                         "secondary workloads or CPU baseline), so that a rocprofv3 summary of the process is the summary of a step")
+    ap.add_argument("--dump-film", default="", help="rank 0 saves the merged film of the last headline step (numpy [H,W,4]); tests use it")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="debug: all ranks share cuda:0 and the film is reduced with gloo (checks the N>1 control flow on a 1-GPU box)")
-    args = ap.parse_args()
+                    help="all ranks share cuda:0 and the films are merged through gloo (RCCL refuses two ranks on one device): "
+                         "the N>1 control flow on a 1-GPU box")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------
+# launcher: N fresh rank processes, started before this process makes any GPU call
+# ---------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ---------------------------------------------------------------------------------------------
+def build_model(hprt, name):
+    if name == "atrium":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import scene_gen
+        text, _ = scene_gen.atrium(1.0)
+        d = tempfile.mkdtemp(prefix="hprt_bench_")
+        path = os.path.join(d, "atrium.pbrt")
+        with open(path, "w") as f:
+            f.write(text)
+        return hprt.Model.parse(path)
+    return hprt.Model.load(os.path.join(GOLDEN, {"killeroo-simple": "killeroo_simple.hprt", "living-room": "living_room.hprt"}[name]))
+
+
+class Workload:
+    """One scene resident on this rank's GPU + its film buffer."""
+
+    def __init__(self, hprt, tiles, torch, name, spp, dev, rank, world):
+        self.name = name
+        self.model = build_model(hprt, name)
+        self.bvh = hprt.Bvh(self.model)
+        self.scene = hprt.Scene(self.model, self.bvh, device=dev.index)
+        self.opt = self.model.options.copy()
+        self.opt.spp = spp
+        x0, y0, x1, y1 = self.opt.film_bounds()
+        self.W, self.H = x1 - x0, y1 - y0
+        self.film = torch.zeros((self.H, self.W, 4), dtype=torch.float32, device=dev)   # device memory via torch: plumbing only
+        self.stream = torch.cuda.current_stream(dev).cuda_stream
+        self.shard = tiles.shard(rank, world)
+        self.sharded = world > 1
+
+    def render(self, spp_chunk=0, **kw):
+        _, st = self.scene.render(self.opt, spp_chunk=spp_chunk, film_ptr=self.film.data_ptr(), stream=self.stream,
+                                  export_foreign=self.sharded, **self.shard, **kw)
+        return st
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))          # nothing above touched the GPU
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to label one as the other\n" % (args.gpus, world))
+        sys.exit(2)
 
     import numpy as np
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -64,131 +162,202 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
-        dist = None
+        local_rank = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank)
 
     hprt = importlib.import_module("thesis-pbrt-v3_amd")
     tiles = importlib.import_module("thesis-pbrt-v3_amd.tiles")
-    model = hprt.Model.load(FIXTURE)
-    bvh = hprt.Bvh(model)
-    scene = hprt.Scene(model, bvh, device=dev.index)
-    opt = model.options.copy()
-    opt.spp = args.spp * max(1, world)                # weak scaling: per-GPU work constant
-    x0, y0, x1, y1 = opt.film_bounds()
-    W, H = x1 - x0, y1 - y0
-    film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)   # device memory via torch: plumbing only
-    stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def step(count_work=False, gather=True, count_traced=True, trace_all=False):
-        # count_traced: the counting pass counts the rays the timed passes trace (a plain render does not trace a BSDF-sampled
-        # light ray that provably cannot reach its emitter; include/hprt.h, HPRT_RENDER_COUNT_TRACED)
-        _, st = scene.render(opt, spp_chunk=args.spp_chunk, count_work=count_work, count_traced=count_work and count_traced,
-                             trace_all=trace_all, film_ptr=film.data_ptr(), stream=stream, **tiles.shard(rank, max(1, world)))
-        if dist is not None and gather:
-            tiles.gather_film(film, dist, dst=0)             # Film tiles -> rank 0 (RCCL over xGMI); addends are disjoint
-        return st
+    # ---- the film gather's communicator: RCCL through the C ABI (hprt_comm_*); the id travels over torch.distributed ----
+    comm, transport, rccl_ranks = None, "none (single GPU)", None
+    if world > 1 and not args.rehearse_on_one_gpu:
+        idt = torch.zeros(hprt.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(hprt.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        comm = hprt.Comm(bytes(idt.cpu().numpy().tobytes()), rank, world, device=dev.index)
+        info = comm.info()
+        rccl_ranks, transport = info["n_ranks"], "RCCL (hprt_film_gather: ncclReduce + grouped send/recv)"
+    elif world > 1:
+        transport = "gloo rehearsal on one GPU (tiles.gather_film)"
+    n_gpus = rccl_ranks if rccl_ranks is not None else (1 if world == 1 else world)
+
+    def merge(w):
+        """Film::MergeFilmTile across ranks; part of the timed step."""
+        if comm is not None:
+            comm.film_gather(w.scene, w.film.data_ptr(), w.W * w.H, root=0, stream=w.stream)
+        elif dist is not None:
+            tiles.gather_film(w.film, dist, dst=0, records=w.scene.film_records())
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    stats = []
-    for _ in range(args.steps):
-        stats.append(step())
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        cdev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tot = torch.tensor([sum(s["rays"] + s["shadow_rays"] for s in stats), sum(s["camera_rays"] for s in stats)],
-                           dtype=torch.float64, device=cdev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_rays, total_samples = float(tot[0].item()), float(tot[1].item())
-    else:
-        total_rays = float(sum(s["rays"] + s["shadow_rays"] for s in stats))
-        total_samples = float(sum(s["camera_rays"] for s in stats))
+    def reduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=torch.device("cpu") if args.rehearse_on_one_gpu else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # ---- roofline of the dominant kernel (k_trace<closest hit>), rank 0's launches ----
-    roofline = None
-    cpu_baseline = None
-    if rank == 0:
-        st_c = step(count_work=True, gather=False)   # untimed, rank-local counting pass: V (nodes fetched), T (primitive tests)
-        st_ref = step(count_work=True, gather=False, count_traced=False)   # untimed: the reference's full ray set (what the CPU baseline traces)
+    def reduce_sum(xs):
+        if dist is None:
+            return [float(x) for x in xs]
+        t = torch.tensor(xs, dtype=torch.float64, device=torch.device("cpu") if args.rehearse_on_one_gpu else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    def timed(w, steps, warmup):
+        for _ in range(warmup):
+            w.render(args.spp_chunk); merge(w)
+        barrier()
+        t0 = time.perf_counter()
+        stats = []
+        for _ in range(steps):
+            stats.append(w.render(args.spp_chunk)); merge(w)
+        barrier()
+        elapsed = reduce_max(time.perf_counter() - t0)
+        rays, samples = reduce_sum([sum(s["rays"] + s["shadow_rays"] for s in stats), sum(s["camera_rays"] for s in stats)])
+        return elapsed, rays, samples, stats
+
+    def cpu_port(name, spp_sample, spp_full):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc   # the oracle: CPU port of the same path (checker / baseline only)
+        d = tempfile.mkdtemp(prefix="hprt_bench_")
+        baked = os.path.join(d, name + ".hprt")
+        build_model(hprt, name).save(baked)
+        oracle = orc.OracleScene(baked)
+        threads = os.cpu_count() or 1
+        _, _, c, sec, nt = oracle.render(spp=spp_sample, threads=threads)
+        return {"value": round((c["rays"] + c["shadow_rays"]) / sec / 1e6, 3), "unit": "Mrays/s", "cores": int(nt), "kind": "port",
+                "sample": "%s at %d spp (of the %d spp workload), whole frame, tile loop only" % (name, spp_sample, spp_full),
+                "msamples_per_s": round(c["camera_rays"] / sec / 1e6, 3), "seconds": round(sec, 2)}
+
+    # =========================================================================================
+    # headline workload
+    # =========================================================================================
+    desc, spp_cfg, cpu_spp, data_label = WORKLOADS[args.workload]
+    spp = (args.spp or spp_cfg) * (world if args.weak else 1)
+    head = Workload(hprt, tiles, torch, args.workload, spp, dev, rank, world)
+
+    if args.profile_step:
+        barrier()
+        t0 = time.perf_counter(); st = head.render(args.spp_chunk); merge(head); barrier()
+        if rank == 0:
+            print(json.dumps({"profile_step": args.workload, "spp": spp, "ms": round(1e3 * (time.perf_counter() - t0), 2),
+                              "rays": st["rays"] + st["shadow_rays"]}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    elapsed, total_rays, total_samples, stats = timed(head, args.steps, args.warmup)
+    if rank == 0 and args.dump_film:
+        np.save(args.dump_film, head.film.cpu().numpy())
+
+    def kernel_figures(w, stats):
+        """rank 0: counting passes (untimed) + the roofline object of k_trace<closest> for workload w"""
+        st_c = w.render(count_work=True, count_traced=True)     # V (nodes fetched), T (primitive tests) of the rays the timed steps trace
+        st_ref = w.render(count_work=True)                      # the reference's full ray set (what the CPU baseline traces)
         torch.cuda.synchronize(dev)
         ref_over_traced = (st_ref["rays"] + st_ref["shadow_rays"]) / max(1, st_c["rays"] + st_c["shadow_rays"])
-        # for comparison (untimed for `value`): the same frame with every ray of the reference traced (HPRT_RENDER_TRACE_ALL)
-        trace_all_info = None
-        if world == 1 and not args.no_trace_all:
-            torch.cuda.synchronize(dev); ta0 = time.perf_counter()
-            ta = [step(gather=False, trace_all=True) for _ in range(args.steps)]
-            torch.cuda.synchronize(dev); ta_sec = time.perf_counter() - ta0
-            trace_all_info = {"ms_per_step": round(1e3 * ta_sec / max(1, args.steps), 2),
-                              "mrays_per_s": round(sum(s["rays"] + s["shadow_rays"] for s in ta) / ta_sec / 1e6, 2)}
-        ext_rays = sum(s["extend_rays"] for s in stats)
-        ext_sec = sum(s["extend_seconds"] for s in stats)
+        ext_rays = sum(s["extend_rays"] for s in stats); ext_sec = sum(s["extend_seconds"] for s in stats)
         ext_launches = sum(s["extend_launches"] for s in stats)
         v_per_ray = st_c["nodes_fetched"] / max(1, st_c["rays"])
         t_per_ray = (st_c["tri_tests"] + st_c["sphere_tests"]) / max(1, st_c["rays"])
         bytes_per_ray = 32.0 * v_per_ray + 48.0 * t_per_ray + 28.0 + 20.0
         achieved = ext_rays * bytes_per_ray / max(ext_sec, 1e-12) / 1e9
-        # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 cannot run inside this
-        # process): tools/traffic_passes.sh on this same command, summary committed under profiles/.
-        traffic, traffic_from = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if world == 1 and args.spp == 256 and os.path.exists(tpath):
-            try:
-                kernels = json.load(open(tpath))["kernels"]
-                tk = next((v for k, v in kernels.items() if k.startswith("k_trace<false, 0")), None)   # closest hit, plain (not the counting pass)
-                if tk:
-                    traffic, traffic_from = round(tk["hbm_bytes_per_launch"]), "profiles/r01_traffic.json"
-            except Exception:
-                pass
-        roofline = {
+        avg_ms = 1e3 * ext_sec / max(1, ext_launches)
+        roof = {
             "bound": "hbm", "kernel": "k_trace<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_from": traffic_from,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "what_frac_is": "algorithmic bytes (SURVEY §8(d) model) / kernel time / HBM peak; the BVH is served by L2/MALL, so this is not "
+                            "an HBM utilisation (see hbm_counter_frac) and the kernel is limited by instruction issue on divergent lanes "
+                            "(see lane_utilisation, wait_frac)",
             "algorithmic_bytes_per_launch": round(ext_rays * bytes_per_ray / max(1, ext_launches)),
             "bytes_per_ray": round(bytes_per_ray, 1), "nodes_fetched_per_ray": round(v_per_ray, 3),
-            "prim_tests_per_ray": round(t_per_ray, 3), "launches": int(ext_launches),
-            "avg_launch_ms": round(1e3 * ext_sec / max(1, ext_launches), 4),
+            "prim_tests_per_ray": round(t_per_ray, 3), "launches": int(ext_launches), "avg_launch_ms": round(avg_ms, 4),
             "kernel_mrays_per_s": round(ext_rays / max(ext_sec, 1e-12) / 1e6, 1),
             "occluded_kernel_mrays_per_s": round(sum(s["occluded_rays"] for s in stats) / max(sum(s["occluded_seconds"] for s in stats), 1e-12) / 1e6, 1),
         }
-        if not args.no_cpu_baseline and world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import orc   # the oracle: CPU port of the same path (checker / baseline only)
-            oracle = orc.OracleScene(FIXTURE)
-            threads = os.cpu_count() or 1
-            _, _, c, sec, nt = oracle.render(spp=args.cpu_spp, threads=threads)
-            cpu_baseline = {
-                "value": round((c["rays"] + c["shadow_rays"]) / sec / 1e6, 3), "unit": "Mrays/s", "cores": int(nt), "kind": "port",
-                "sample": "killeroo-simple 700x700 at %d spp (of the %d spp workload), tile loop only" % (args.cpu_spp, args.spp),
-                "msamples_per_s": round(c["camera_rays"] / sec / 1e6, 3), "seconds": round(sec, 2),
-            }
+        return roof, ref_over_traced
+
+    roofline = cpu_baseline = trace_all_info = None
+    ref_over_traced = 1.0
+    if rank == 0 and world == 1:
+        roofline, ref_over_traced = kernel_figures(head, stats)
+        # measured counters of the same step (rocprofv3 cannot run inside this process): profiles/r02_counters.json
+        if os.path.exists(COUNTERS) and not args.spp and not args.weak:
+            try:
+                cj = json.load(open(COUNTERS)).get(args.workload)
+                if cj:
+                    k = cj["kernels"]
+                    tc = k.get("k_trace<closest>")
+                    if tc and tc.get("hbm_bytes_per_launch") is not None:
+                        roofline["traffic"] = round(tc["hbm_bytes_per_launch"])
+                        roofline["traffic_from"] = "profiles/r02_counters.json"
+                        roofline["hbm_counter_frac"] = round(tc["hbm_bytes_per_launch"] / (tc["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    roofline["per_kernel"] = {name: {f: v[f] for f in ("lane_utilisation", "wait_frac", "avg_launch_ms", "launches", "hbm_gbs", "hbm_frac") if f in v}
+                                              for name, v in k.items()}
+                    roofline["hbm_bytes_per_step"] = cj.get("hbm_bytes_per_step")
+                    roofline["step_hbm_frac"] = cj.get("step_hbm_frac")
+            except Exception as e:   # a malformed summary must not take the bench down
+                roofline["counters_error"] = repr(e)
+        if not args.no_trace_all:
+            torch.cuda.synchronize(dev); ta0 = time.perf_counter()
+            ta = [head.render(args.spp_chunk, trace_all=True) for _ in range(args.steps)]
+            torch.cuda.synchronize(dev); ta_sec = time.perf_counter() - ta0
+            trace_all_info = {"ms_per_step": round(1e3 * ta_sec / max(1, args.steps), 2),
+                              "mrays_per_s": round(sum(s["rays"] + s["shadow_rays"] for s in ta) / ta_sec / 1e6, 2)}
+
+    # =========================================================================================
+    # secondary workloads (same line, not the headline)
+    # =========================================================================================
+    secondary = []
+    if not args.no_secondary:
+        for name in [n for n in ("killeroo-simple", "living-room") if n != args.workload] + (["atrium"] if args.workload != "atrium" else []):
+            d2, spp2, cpu2, label2 = WORKLOADS[name]
+            spp2 = spp2 * (world if args.weak else 1)
+            del_w = Workload(hprt, tiles, torch, name, spp2, dev, rank, world)
+            steps2 = max(1, min(args.steps, 3))
+            e2, r2, s2, st2 = timed(del_w, steps2, 1)
+            item = None
+            if rank == 0:
+                item = {"workload": d2 % spp2, "data": label2, "steps": steps2, "ms_per_step": round(1e3 * e2 / steps2, 2),
+                        "mrays_per_s": round(r2 / e2 / 1e6, 2), "msamples_per_s": round(s2 / e2 / 1e6, 3), "rays_per_step": int(r2 / steps2)}
+                if world == 1:
+                    roof2, rot2 = kernel_figures(del_w, st2)
+                    item["reference_rays_per_step"] = int(r2 * rot2 / steps2)
+                    item["roofline"] = roof2
+                    if not args.no_cpu_baseline:
+                        item["cpu_baseline"] = cpu_port(name, cpu2, spp2)
+                        item["gpu_over_cpu"] = round(item["msamples_per_s"] / item["cpu_baseline"]["msamples_per_s"], 1)
+                secondary.append(item)
+            del del_w
+            torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = cpu_port(args.workload, cpu_spp, spp)
     if dist is not None:
         dist.barrier()
     if rank == 0:
         value = total_rays / elapsed / 1e6
         out = {
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "killeroo-simple (66,532 tris + sphere light) 700x700, halton %d spp/GPU, path maxdepth 5, bvh" % args.spp,
-                       "spp_total": int(opt.spp), "tiles": "16x16 round-robin over %d GPU(s)" % max(1, world), "parallelism": "tile-dp%d" % max(1, world)},
+            "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 2), "higher_is_better": True,
+            "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f32", "data": data_label,
+            "config": {"workload": desc % spp, "baseline_config": "configs[2]" if args.workload == "atrium" else args.workload,
+                       "spp_total": int(spp), "tiles": "16x16 round-robin over %d GPU(s)" % world, "parallelism": "tile-dp%d" % world,
+                       "film_merge": transport},
+            "rccl_ranks": rccl_ranks, "world_size": world,
             "msamples_per_s": round(total_samples / elapsed / 1e6, 3),
-            # rays actually traced.  The reference's PathIntegrator traces more: its BSDF-sampled light rays that provably cannot
-            # reach the emitter are answered without a trace here (same film, bit for bit) and are NOT counted in `value`.
+            # rays actually traced.  The reference's PathIntegrator traces more: BSDF-sampled light rays that provably cannot reach
+            # the emitter and the segment behind a path's last vertex are not traced here (same film, bit for bit), nor counted.
             "rays_per_step": int(total_rays / max(1, args.steps)),
-            "reference_rays_per_step": int(total_rays * ref_over_traced / max(1, args.steps)),
+            "reference_rays_per_step": int(total_rays * ref_over_traced / max(1, args.steps)) if world == 1 else None,
             "with_every_reference_ray_traced": trace_all_info,
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "secondary": secondary,
         }
         if cpu_baseline:
             # same frame on both sides: ratio of frame rates (the CPU port traces the reference's full ray set)

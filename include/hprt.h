@@ -251,6 +251,10 @@ typedef struct HprtRenderDesc {
  * plain render trace the reference's full ray set too. */
 #define HPRT_RENDER_COUNT_TRACED 4
 #define HPRT_RENDER_TRACE_ALL 8
+/* Tile-sharded renders whose films hprt_film_gather will merge: box-filter contributions that cross a tile border
+ * (FilmTile pixels outside the tile's own 16x16 block, core/film.cpp:98-103) are not merged into the film but kept as
+ * HprtFilmRecords, so that the gather can merge the records of ALL ranks into each pixel in source-tile order. */
+#define HPRT_RENDER_EXPORT_FOREIGN 16
 
 typedef struct HprtRenderStats {
     uint64_t camera_rays;          /* nCameraRays, core/integrator.cpp:48,293 */
@@ -291,6 +295,45 @@ int hprt_film_resolve(const float *xyzw, size_t n_pixels, float film_scale, floa
 int hprt_film_read(HprtScene *s, float *xyzw_out, size_t n_pixels);
 /* imageio.cpp:437+ : PFM writer (bottom row first, little endian). */
 int hprt_write_pfm(const char *path, const float *rgb, int width, int height);
+
+/* ------------------------------------------------------------------------ */
+/* Multi-GPU film gather.  Stands in for Film::MergeFilmTile                  */
+/* (core/film.cpp:118-132) across GPUs: the reference merges every worker's   */
+/* FilmTile into Film::pixels under a mutex; here rank r of n renders tiles   */
+/* r, r+n, ... (HprtRenderDesc::tile_begin / tile_stride) with                */
+/* HPRT_RENDER_EXPORT_FOREIGN and ONE RCCL step over xGMI lands the frame on  */
+/* the root: ncclReduce(sum) of the per-rank films (disjoint addends: exact)  */
+/* plus a grouped ncclSend/ncclRecv of the few cross-tile records, which the  */
+/* root adds per pixel in ascending source-tile order — the order of the      */
+/* single-GPU film, so the n-GPU film equals it bit for bit.                  */
+/* ------------------------------------------------------------------------ */
+typedef struct HprtComm HprtComm;
+#define HPRT_COMM_ID_BYTES 128
+/* One process per GPU: rank 0 draws an id (ncclGetUniqueId), the host program hands the 128 bytes to every
+ * rank by whatever means it has, and every rank creates its communicator (ncclCommInitRank) on `device`
+ * (< 0: the current HIP device).  RCCL refuses two ranks on one device. */
+int hprt_comm_unique_id(uint8_t id[HPRT_COMM_ID_BYTES]);
+int hprt_comm_create(const uint8_t id[HPRT_COMM_ID_BYTES], int rank, int n_ranks, int device, HprtComm **out);
+/* rank, size and device as the communicator reports them (ncclCommUserRank / Count / CuDevice); any may be NULL */
+int hprt_comm_info(const HprtComm *c, int *rank, int *n_ranks, int *device);
+void hprt_comm_destroy(HprtComm *c);
+/* Collective over the communicator, after each rank's hprt_render(..., HPRT_RENDER_EXPORT_FOREIGN).  d_film_xyzw is the
+ * DEVICE buffer that render wrote (NULL: the scene's own film); on return the root's buffer holds the merged frame
+ * (what Film::pixels holds before WriteImage), other ranks' buffers are unspecified.  Blocks until `stream` is done. */
+int hprt_film_gather(HprtComm *c, HprtScene *s, float *d_film_xyzw, size_t n_pixels, int root, void *stream);
+/* The same for ONE process that drives n GPUs with one HprtScene each (how an adapter inside pbrt would: the proposal
+ * of SURVEY.md §8(b)); communicators come from ncclCommInitAll on first use.  d_films may be NULL (every scene's own film). */
+int hprt_film_gather_local(HprtScene *const *per_gpu, float *const *d_films, int n, size_t n_pixels, int root);
+/* The transport-free halves, for hosts that move the data themselves (the gloo rehearsals in tests/ do): the records of
+ * the last HPRT_RENDER_EXPORT_FOREIGN render (out == NULL: count only), and the ordered merge of any ranks' records into
+ * a HOST copy of the summed films (sorts `records` by destination pixel and source tile, then adds; no GPU involved). */
+typedef struct HprtFilmRecord {
+    uint32_t dest_pixel;             /* row-major index into the cropped film */
+    uint32_t src_tile;               /* tile (core/integrator.cpp:237-244 grid) whose samples these are */
+    float xyz[3], weight;            /* that FilmTile pixel's contribSum as XYZ and its filterWeightSum */
+} HprtFilmRecord;
+int hprt_film_records_read(HprtScene *s, HprtFilmRecord *out, size_t capacity, size_t *n_records);
+int hprt_film_records_merge(float *xyzw, size_t n_pixels, HprtFilmRecord *records, size_t n_records);
 
 /* Radiance of individual camera samples (pixel x, y, sample index), after the
  * NaN/negative/inf guards of core/integrator.cpp:300-321; L_out = 3*n floats.

@@ -144,7 +144,7 @@ def test_full_size_frame_is_independent_of_batching_and_sharding(killeroo_model,
     assert np.array_equal(total.view(np.uint32), film_a.view(np.uint32))
 
 
-def _two_rank_worker(rank, world, port, out_path, crop, spp):
+def _rank_worker(rank, world, port, out_path, crop, spp):
     import importlib, os, sys
     import numpy as np
     import torch
@@ -161,28 +161,106 @@ def _two_rank_worker(rank, world, port, out_path, crop, spp):
     opt.spp = spp
     x0, y0, x1, y1 = opt.film_bounds()
     film = torch.zeros((y1 - y0, x1 - x0, 4), dtype=torch.float32, device="cuda:0")
-    scene.render(opt, film_ptr=film.data_ptr(), **tiles.shard(rank, world))
-    tiles.gather_film(film, dist, dst=0)
+    scene.render(opt, film_ptr=film.data_ptr(), export_foreign=True, **tiles.shard(rank, world))
+    rec = scene.film_records()
+    tiles.gather_film(film, dist, dst=0, records=rec)
+    n = torch.tensor([len(rec)], dtype=torch.int64)
+    dist.all_reduce(n)
     if rank == 0:
         np.save(out_path, film.cpu().numpy())
+        np.save(out_path + ".nrec.npy", n.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_sharing_the_gpu_reproduce_the_film(tmp_path, killeroo_oracle):
-    """N > 1 path on the 1-GPU box: two processes render alternate tiles on cuda:0, the films are
-    summed (gloo here, RCCL in bench.py) and must equal the oracle's single-process film."""
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_ranks_sharing_the_gpu_reproduce_the_film(tmp_path, killeroo_oracle, killeroo_scene, killeroo_model, world):
+    """N > 1 path on the 1-GPU box: `world` processes render interleaved tiles of the WHOLE 700x700 frame on cuda:0 with
+    HPRT_RENDER_EXPORT_FOREIGN; films are summed and the cross-tile records merged in source-tile order (tiles.gather_film:
+    the gloo twin of hprt_film_gather, RCCL refuses ranks that share a device).  The merged film must equal the oracle's
+    single-process film AND the product's own unsharded film bit for bit — including tile-corner pixels that receive
+    samples from tiles of several other ranks (world 3: the right, lower and lower-right neighbours of a tile belong to
+    three different ranks)."""
     import socket
     import torch.multiprocessing as mp
-    crop = (0.40, 0.40 + 96 / 700.0, 0.45, 0.45 + 80 / 700.0)
+    crop = (0.0, 1.0, 0.0, 1.0)
+    spp = 2
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    out = str(tmp_path / "film2.npy")
-    mp.spawn(_two_rank_worker, args=(2, port, out, crop, 8), nprocs=2, join=True)
+    out = str(tmp_path / "film.npy")
+    mp.spawn(_rank_worker, args=(world, port, out, crop, spp), nprocs=world, join=True)
     got = np.load(out)
-    killeroo_oracle.set_film(crop=crop, spp=8)
-    _, film0, _, _, _ = killeroo_oracle.render(spp=8, threads=8)
+    assert int(np.load(out + ".nrec.npy")[0]) > 100          # the frame does have cross-tile contributions
+    opt = killeroo_model.options.copy(); opt.spp = spp
+    plain, _ = killeroo_scene.render(opt)
+    assert np.array_equal(got.view(np.uint32), plain.view(np.uint32))
+    killeroo_oracle.set_film(crop=crop, spp=spp)
+    _, film0, _, _, _ = killeroo_oracle.render(spp=spp, threads=16)
     killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
     assert np.array_equal(got.view(np.uint32), film0.view(np.uint32))
+
+
+def test_rccl_film_gather_through_the_c_abi(hprt, killeroo_model, killeroo_scene):
+    """hprt_comm_* / hprt_film_gather on real RCCL with the one rank a 1-GPU box allows: ncclCommInitRank from a unique id,
+    ncclAllGather of the record counts, ncclReduce of the film, and the device-side ordered merge of the exported cross-tile
+    records must turn an EXPORT_FOREIGN render into exactly the plain render's film; hprt_film_gather_local (one process,
+    one scene per GPU: ncclCommInitAll) likewise.  Multi-GPU RCCL runs only in the driver's SCALE bench."""
+    import torch
+    opt = killeroo_model.options.copy(); opt.spp = 4
+    plain, _ = killeroo_scene.render(opt)
+    x0, y0, x1, y1 = opt.film_bounds()
+    n_pix = (x1 - x0) * (y1 - y0)
+    film = torch.zeros((y1 - y0, x1 - x0, 4), dtype=torch.float32, device="cuda:0")
+    killeroo_scene.render(opt, film_ptr=film.data_ptr(), export_foreign=True)
+    rec = killeroo_scene.film_records()
+    assert len(rec) > 100 and not np.array_equal(film.cpu().numpy().view(np.uint32), plain.view(np.uint32))
+    # the records name pixels of OTHER tiles; several records may meet in one pixel
+    comm = hprt.Comm(hprt.Comm.unique_id(), 0, 1, device=0)
+    assert comm.info() == {"rank": 0, "n_ranks": 1, "device": 0}
+    comm.film_gather(killeroo_scene, film.data_ptr(), n_pix, root=0, stream=torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(film.cpu().numpy().view(np.uint32), plain.view(np.uint32))
+    # host twin of the merge (what the gloo path uses)
+    killeroo_scene.render(opt, film_ptr=film.data_ptr(), export_foreign=True)
+    host = film.cpu().numpy().copy()
+    hprt.film_records_merge(host, rec[::-1])
+    assert np.array_equal(host.view(np.uint32), plain.view(np.uint32))
+    # single-process variant, library-owned film
+    killeroo_scene.render(opt, export_foreign=True)
+    hprt.film_gather_local([killeroo_scene], None, n_pix, root=0)
+    own = np.zeros((y1 - y0, x1 - x0, 4), np.float32)
+    hprt._check(hprt.lib.hprt_film_read(killeroo_scene._h, hprt._ptr(own), n_pix))
+    assert np.array_equal(own.view(np.uint32), plain.view(np.uint32))
+    # a gather after a render without the flag is refused
+    killeroo_scene.render(opt, film_ptr=film.data_ptr())
+    with pytest.raises(hprt.HprtError):
+        comm.film_gather(killeroo_scene, film.data_ptr(), n_pix)
+    del comm
+
+
+def test_bench_launches_its_own_ranks(tmp_path, killeroo_oracle):
+    """`python bench.py --gpus 2` without WORLD_SIZE starts two fresh rank processes itself (before touching the GPU) and
+    reports the world size the merge actually ran over.  On the 1-GPU box the ranks share cuda:0 (--rehearse-on-one-gpu,
+    gloo transport: RCCL refuses duplicate devices); everything else is the code path of the driver's multi-GPU runs:
+    fixed total spp, tiles dealt round-robin, EXPORT_FOREIGN renders, merged film on rank 0 == the oracle's film."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    dump = str(tmp_path / "film.npy")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--workload", "killeroo-simple", "--spp", "4",
+           "--steps", "1", "--warmup", "0", "--no-secondary", "--no-cpu-baseline", "--dump-film", dump]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["scaling"] == "strong" and line["config"]["spp_total"] == 4
+    assert line["rays_per_step"] > 0 and line["value"] > 0
+    got = np.load(dump)
+    killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=4)
+    _, film0, c0, _, _ = killeroo_oracle.render(spp=4, threads=16)
+    killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
+    assert np.array_equal(got.view(np.uint32), film0.view(np.uint32))
+    assert line["msamples_per_s"] > 0 and abs(line["rays_per_step"] / (c0["rays"] + c0["shadow_rays"]) - 1) < 0.5
+    # a rank count that does not match the flag is refused, not mislabelled
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True)
+    assert r.returncode == 2 and "refusing" in r.stderr
 
 
 def test_per_pixel_statistics_match(hprt, orc, killeroo_scene, killeroo_oracle, tmp_path):

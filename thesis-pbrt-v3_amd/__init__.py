@@ -33,6 +33,11 @@ RENDER_COUNT_WORK = 1
 RENDER_PIXEL_STATS = 2
 RENDER_COUNT_TRACED = 4
 RENDER_TRACE_ALL = 8
+RENDER_EXPORT_FOREIGN = 16
+COMM_ID_BYTES = 128
+# HprtFilmRecord: one cross-tile film contribution (include/hprt.h)
+FILM_RECORD = np.dtype([("dest_pixel", np.uint32), ("src_tile", np.uint32), ("xyz", np.float32, 3), ("weight", np.float32)])
+assert FILM_RECORD.itemsize == 24
 
 
 class RenderOptions(C.Structure):
@@ -119,6 +124,14 @@ def _load():
         "hprt_write_pfm": (C.c_int, [cp, vp, C.c_int, C.c_int]),
         "hprt_sample_radiance": (C.c_int, [vp, P(RenderOptions), sz, vp, vp, vp, vp]),
         "hprt_halton_permutations": (C.c_int, [vp, sz, P(sz)]),
+        "hprt_comm_unique_id": (C.c_int, [vp]),
+        "hprt_comm_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, P(vp)]),
+        "hprt_comm_info": (C.c_int, [vp, P(C.c_int), P(C.c_int), P(C.c_int)]),
+        "hprt_comm_destroy": (None, [vp]),
+        "hprt_film_gather": (C.c_int, [vp, vp, vp, sz, C.c_int, vp]),
+        "hprt_film_gather_local": (C.c_int, [P(vp), P(vp), C.c_int, sz, C.c_int]),
+        "hprt_film_records_read": (C.c_int, [vp, vp, sz, P(sz)]),
+        "hprt_film_records_merge": (C.c_int, [vp, sz, vp, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # raises AttributeError if an export is missing
@@ -295,7 +308,7 @@ class Scene:
         _check(lib.hprt_occluded_device(self._h, n, rays7_ptr, occ_ptr, stream))
 
     def render(self, opt=None, tile_begin=0, tile_end=0, tile_stride=1, spp_chunk=0, count_work=False, film_ptr=None,
-               stream=None, pixel_stats=False, count_traced=False, trace_all=False):
+               stream=None, pixel_stats=False, count_traced=False, trace_all=False, export_foreign=False):
         """Render(): returns (film_xyzw [H,W,4] float32 or None when film_ptr is given, stats dict)."""
         opt = opt or self._model.options
         desc = RenderDesc()
@@ -304,7 +317,8 @@ class Scene:
         desc.spp_chunk = spp_chunk
         # count_traced / trace_all: see HPRT_RENDER_COUNT_TRACED / HPRT_RENDER_TRACE_ALL in include/hprt.h
         desc.flags = (RENDER_COUNT_WORK if count_work else 0) | (RENDER_PIXEL_STATS if pixel_stats else 0) | \
-                     (RENDER_COUNT_TRACED if count_traced else 0) | (RENDER_TRACE_ALL if trace_all else 0)
+                     (RENDER_COUNT_TRACED if count_traced else 0) | (RENDER_TRACE_ALL if trace_all else 0) | \
+                     (RENDER_EXPORT_FOREIGN if export_foreign else 0)      # export_foreign: see film_records() / Comm.film_gather()
         self._film_shape = tuple(int(v) for v in (opt.film_bounds()[3] - opt.film_bounds()[1], opt.film_bounds()[2] - opt.film_bounds()[0]))
         st = RenderStats()
         _check(lib.hprt_render(self._h, C.byref(desc), film_ptr, stream, C.byref(st)))
@@ -314,6 +328,15 @@ class Scene:
             film = np.zeros((y1 - y0, x1 - x0, 4), np.float32)
             _check(lib.hprt_film_read(self._h, _ptr(film), film.shape[0] * film.shape[1]))
         return film, st.as_dict()
+
+    def film_records(self):
+        """Cross-tile film contributions of the last render(export_foreign=True): FILM_RECORD array (HprtFilmRecord)."""
+        n = C.c_size_t()
+        _check(lib.hprt_film_records_read(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, FILM_RECORD)
+        if n.value:
+            _check(lib.hprt_film_records_read(self._h, _ptr(out), n.value, C.byref(n)))
+        return out
 
     def pixel_stats(self):
         """[H, W, 7] uint64 Pixel::stats of the last render(pixel_stats=True): rays, primitiveIntersections[P],
@@ -335,6 +358,56 @@ class Scene:
         if getattr(self, "_h", None) and lib is not None:      # (module globals are cleared at interpreter exit)
             lib.hprt_scene_destroy(self._h)
             self._h = None
+
+
+class Comm:
+    """RCCL communicator for the film gather (hprt_comm_*): one process per GPU.  Rank 0 draws `Comm.unique_id()`, the
+    host program distributes the 128 bytes (bench.py: through torch.distributed's store), every rank constructs."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        _check(lib.hprt_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, n_ranks, device=-1):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % COMM_ID_BYTES)
+        h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib.hprt_comm_create(buf, rank, n_ranks, device, C.byref(h)))
+        self._h = h
+
+    def info(self):
+        r, n, d = C.c_int(), C.c_int(), C.c_int()
+        _check(lib.hprt_comm_info(self._h, C.byref(r), C.byref(n), C.byref(d)))
+        return {"rank": r.value, "n_ranks": n.value, "device": d.value}
+
+    def film_gather(self, scene, film_ptr, n_pixels, root=0, stream=None):
+        """Film::MergeFilmTile across ranks (hprt_film_gather): ncclReduce of the films + ordered merge of the
+        cross-tile records on the root.  Every rank's last render must have used export_foreign=True."""
+        _check(lib.hprt_film_gather(self._h, scene._h, film_ptr, n_pixels, root, stream))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib.hprt_comm_destroy(self._h)
+            self._h = None
+
+
+def film_gather_local(scenes, film_ptrs, n_pixels, root=0):
+    """hprt_film_gather_local: one process, one Scene per GPU."""
+    n = len(scenes)
+    hs = (C.c_void_p * n)(*[s._h for s in scenes])
+    fs = (C.c_void_p * n)(*[C.c_void_p(p) if p else None for p in (film_ptrs or [None] * n)])
+    _check(lib.hprt_film_gather_local(hs, fs, n, n_pixels, root))
+
+
+def film_records_merge(film_xyzw, records):
+    """Adds cross-tile records (any ranks', any order) into a host film [H,W,4] in place, per pixel in source-tile order."""
+    assert film_xyzw.dtype == np.float32 and film_xyzw.flags.c_contiguous
+    rec = np.ascontiguousarray(records, FILM_RECORD).copy()
+    _check(lib.hprt_film_records_merge(_ptr(film_xyzw), film_xyzw.size // 4, _ptr(rec), rec.shape[0]))
+    return film_xyzw
 
 
 def film_resolve(film_xyzw, scale=1.0):

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib")
 HOST_SRCS = ["pbrt_frontend.cpp", "loop_subdiv.cpp", "scene_io.cpp", "texture_io.cpp", "bvh_builder.cpp", "halton_tables.cpp", "capi_host.cpp"]
-HIP_SRCS = ["device/kernels.hip", "capi_device.hip"]
+HIP_SRCS = ["device/kernels.hip", "capi_device.hip", "capi_gather.hip"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
@@ -73,7 +73,7 @@ def build(verbose=False, force=False):
     lib = os.path.join(LIB, "libhprt.so")
     objs = [j[1] for j in jobs]
     if force or _newer(objs, lib):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", lib] + objs + ["-lz"]   # zlib: PNG textures (texture_io.cpp)
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", lib] + objs + ["-lz", "-L/opt/rocm/lib", "-lrccl"]   # zlib: PNG textures (texture_io.cpp); RCCL: film gather (capi_gather.hip)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stderr))

@@ -17,57 +17,10 @@
 #include "halton_tables.h"
 #include "host_transform.h"
 #include "hprt_internal.h"
+#include "device_state.h"
 
 using namespace hprt;
 
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e__ = (expr);                                                                        \
-        if (e__ != hipSuccess)                                                                          \
-            return SetError(HPRT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));         \
-    } while (0)
-
-namespace {
-
-struct DevBuf {
-    void *p = nullptr; size_t bytes = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) {
-        if (p && bytes >= n) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        if (n == 0) return hipSuccess;
-        hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) bytes = n;
-        return e;
-    }
-    template <typename T> T *as() const { return (T *)p; }
-};
-template <typename T> hipError_t upload(DevBuf &b, const std::vector<T> &v) {
-    hipError_t e = b.alloc(std::max<size_t>(v.size() * sizeof(T), 16));
-    if (e != hipSuccess || v.empty()) return e;
-    return hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-}
-
-}  // namespace
-
-struct HprtScene {
-    int device = 0;
-    DevScene dev;
-    DevBuf textures, mipLevels, texels, weightLut;
-    DevBuf nodes, tris, primVtx, primN, vUV, vS, shapes, materials, lights, spheres, instances, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
-    DevBuf counters, workCounter;
-    DevBuf rayStats, pixelStatsLocal, pixelStatsFilm; bool pixelStatsValid = false;   // HPRT_RENDER_PIXEL_STATS
-    // render-time state
-    DevBuf planes;                                    // backing store of the path streams (Workspace)
-    DevBuf apiRays, apiHits;                          // stream copies of the plane-layout arguments of the *_device calls
-    DevBuf queues, queueCounts;
-    DevBuf pixelXY, pixelOffset, Lall, film, irregular, irregularCount;
-    DevBuf exOwnBegin, exOwnSrc, exOwnSample, exOwnPre, exFDest, exFDestBegin, exFGroupBegin, exFSrc, exFSample;
-    uint32_t *hostCounts = nullptr;                   // pinned
-    size_t filmPixels = 0;
-    uint32_t nPrims = 0;
-    ~HprtScene() { if (hostCounts) (void)hipHostFree(hostCounts); }
-};
 
 namespace {
 
@@ -165,6 +118,15 @@ void MakeCamera(const HprtRenderOptions &o, DevCamera *cam) {
     // cameras/perspective.cpp:55-58
     cam->dxCamera = xf_point(cam->rasterToCamera, vec3(1, 0, 0)) - xf_point(cam->rasterToCamera, vec3(0, 0, 0));
     cam->dyCamera = xf_point(cam->rasterToCamera, vec3(0, 1, 0)) - xf_point(cam->rasterToCamera, vec3(0, 0, 0));
+}
+
+// A path vertex consumes up to 8 sampler dimensions after the camera sample's 5; the reference's
+// Halton sampler aborts at dimension PrimeTableSize = 1000 (core/lowdiscrepancy.h:52, lowdiscrepancy.cpp:4558), so depths
+// whose paths could get there are refused instead of sampled from a dimension the reference does not have.
+int CheckDepth(int maxDepth) {
+    if (5 + 8 * ((int64_t)maxDepth + 1) > 1000)
+        return SetError(HPRT_E_UNSUPPORTED, "maxdepth above 123: a path could pass the 1,000 sampler dimensions of the reference's Halton tables");
+    return HPRT_OK;
 }
 
 struct FrameSetup {
@@ -785,7 +747,8 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         }
         if (nResolve) LaunchResolve(st, s->dev, w.vs, out.L, w.Lfinal, cur.resolve, cur.resolveCount, nResolve);
         activeQ = cur.next; active = nNext;
-        if (bounce > 250) break;
+        // (maxDepth is bounded by CheckDepth, and no path outlives bounce maxDepth)
+        if (active > 0 && bounce > rp.maxDepth) return SetError(HPRT_E_DEVICE, "internal error: paths are still active beyond maxdepth");
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
@@ -825,7 +788,9 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     const HprtRenderOptions &o = desc->opt;
+    int rc0;
     if (o.spp <= 0 || o.max_depth < 0) return SetError(HPRT_E_INVALID, "spp must be positive and max_depth non-negative");
+    if ((rc0 = CheckDepth(o.max_depth)) != HPRT_OK) return rc0;
     FrameSetup f;
     int rc = SetupFrame(o, &f);
     if (rc != HPRT_OK) return rc;
@@ -841,6 +806,8 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     const uint32_t nPix = (uint32_t)f.pixelXY.size();
     const uint32_t spp = (uint32_t)o.spp;
     s->filmPixels = (size_t)f.W * f.H;
+    s->filmW = f.W; s->filmH = f.H;
+    s->nForeignRecords = 0; s->foreignExported = (desc->flags & HPRT_RENDER_EXPORT_FOREIGN) != 0;
     float *film = d_film_xyzw;
     if (!film) { HIP_TRY(s->film.alloc(16 * s->filmPixels)); film = s->film.as<float>(); }
     HIP_TRY(hipMemsetAsync(film, 0, 16 * s->filmPixels, st));
@@ -941,6 +908,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
         return a.sample < b.sample;
     });
     FilmExtras ex; memset(&ex, 0, sizeof(ex));
+    std::vector<uint32_t> groupDest, groupTile;      // per foreign group (destination film pixel, source tile), sorted by both
     {
         std::vector<uint32_t> begin(nPix + 1, 0), src(own.size()), smp(own.size()); std::vector<uint8_t> pre(own.size());
         for (const ExtraEntry &e : own) ++begin[e.dest + 1];
@@ -953,7 +921,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
             const bool newDest = i == 0 || foreign[i].dest != foreign[i - 1].dest;
             const bool newGroup = newDest || foreign[i].srcTile != foreign[i - 1].srcTile;
             if (newDest) { dest.push_back(foreign[i].dest); destBegin.push_back((uint32_t)groupBegin.size()); }
-            if (newGroup) groupBegin.push_back((uint32_t)i);
+            if (newGroup) { groupBegin.push_back((uint32_t)i); groupDest.push_back(foreign[i].dest); groupTile.push_back(foreign[i].srcTile); }
             fsrc[i] = foreign[i].srcPix; fsmp[i] = foreign[i].sample;
         }
         destBegin.push_back((uint32_t)groupBegin.size()); groupBegin.push_back((uint32_t)foreign.size());
@@ -972,7 +940,16 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
         LaunchStoreRadiance(st, ps.Lfinal, LallR, LallG, LallB, nPix, s0, nSlots);
     }
     LaunchFilmOwn(st, rp, f.fg, LallR, LallG, LallB, spp, ex, film);
-    LaunchFilmForeign(st, rp, f.fg, LallR, LallG, LallB, ex, film);
+    if (desc->flags & HPRT_RENDER_EXPORT_FOREIGN) {
+        // cross-tile contributions leave as records: hprt_film_gather merges those of all ranks in source-tile order
+        const uint32_t nGroups = (uint32_t)groupDest.size();
+        HIP_TRY(upload(s->exGroupDest, groupDest)); HIP_TRY(upload(s->exGroupTile, groupTile));
+        HIP_TRY(s->foreignRecords.alloc(std::max<size_t>(1, nGroups) * sizeof(FilmRecord)));
+        LaunchFilmForeignExport(st, rp, f.fg, LallR, LallG, LallB, ex, nGroups, s->exGroupDest.as<uint32_t>(), s->exGroupTile.as<uint32_t>(),
+                                s->foreignRecords.as<FilmRecord>());
+        s->nForeignRecords = nGroups;
+    } else
+        LaunchFilmForeign(st, rp, f.fg, LallR, LallG, LallB, ex, film);
     if (pixelStats) {
         LaunchPixelStatsToFilm(st, pixelStats, rp.pixelXY, nPix, spp, f.fg.cx0, f.fg.cy0, f.W, s->pixelStatsFilm.as<unsigned long long>());
         s->pixelStatsValid = true;
@@ -1015,6 +992,8 @@ int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, c
     if (!s || !opt || (n && (!px || !py || !sample || !L_out))) return SetError(HPRT_E_INVALID, "hprt_sample_radiance: null argument");
     if (n == 0) return HPRT_OK;
     if (n > (1u << 26)) return SetError(HPRT_E_INVALID, "hprt_sample_radiance: too many samples in one call");
+    if (opt->max_depth < 0) return SetError(HPRT_E_INVALID, "max_depth must be non-negative");
+    if (int rcd = CheckDepth(opt->max_depth)) return rcd;
     HIP_TRY(hipSetDevice(s->device));
     FrameSetup f;
     int rc = SetupFrame(*opt, &f);

@@ -1,0 +1,230 @@
+// hprt — multi-GPU half of the C ABI (include/hprt.h): the film gather that follows a tile-sharded Render.
+//
+// The reference merges each worker's FilmTile into Film::pixels under a mutex (Film::MergeFilmTile,
+// core/film.cpp:118-132).  Here every GPU holds the film of ITS tiles (hprt_render with tile_begin / tile_stride and
+// HPRT_RENDER_EXPORT_FOREIGN) and the merge is one RCCL step over xGMI:
+//   1. ncclReduce(sum) of the per-rank films onto the root.  The addends are disjoint — a pixel is non-zero on the one
+//      rank that owns its tile — so the sum is exact whatever order the collective adds in.
+//   2. The few box-filter contributions that cross a tile border (a sample whose Halton offset is exactly 0, core/film.h:
+//      136-143) travel as 24-byte records: counts by ncclAllGather, records by a group of ncclSend / ncclRecv (peer ->
+//      root, each over its own xGMI link).  The root sorts them by (destination pixel, source tile) and adds them in that
+//      order, which is the order the single-GPU film adds them in: the N-GPU film equals the 1-GPU film bit for bit.
+// One process per GPU uses hprt_comm_* + hprt_film_gather; a single process that drives several GPUs (how a pbrt-side
+// adapter would, one HprtScene per GPU) uses hprt_film_gather_local.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/hprt.h"
+#include "device_state.h"
+
+using namespace hprt;
+
+static_assert(sizeof(HprtFilmRecord) == sizeof(FilmRecord) && sizeof(FilmRecord) == 24, "film record layout");
+static_assert(HPRT_COMM_ID_BYTES == sizeof(ncclUniqueId), "ncclUniqueId size");
+
+#define NCCL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        ncclResult_t r__ = (expr);                                                                      \
+        if (r__ != ncclSuccess)                                                                         \
+            return SetError(HPRT_E_DEVICE, std::string(#expr) + ": " + ncclGetErrorString(r__));       \
+    } while (0)
+
+struct HprtComm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nRanks = 1, device = 0;
+    DevBuf counts, staging, destBegin;
+    uint32_t *hostCounts = nullptr;      // pinned
+    ~HprtComm() {
+        if (hostCounts) (void)hipHostFree(hostCounts);
+        if (comm) (void)ncclCommDestroy(comm);
+    }
+};
+
+namespace {
+
+// Sort by (destination, source tile) and add on `device` into `film`; `scratch` receives the uploads.
+int ApplyRecords(std::vector<FilmRecord> &rec, float *film, size_t nPixels, DevBuf &recBuf, DevBuf &beginBuf, hipStream_t st) {
+    if (rec.empty()) return HPRT_OK;
+    std::sort(rec.begin(), rec.end(), [](const FilmRecord &a, const FilmRecord &b) { return a.dest != b.dest ? a.dest < b.dest : a.srcTile < b.srcTile; });
+    std::vector<uint32_t> destBegin;
+    for (size_t i = 0; i < rec.size(); ++i) {
+        if (rec[i].dest >= nPixels) return SetError(HPRT_E_INVALID, "film record outside the film");
+        if (i == 0 || rec[i].dest != rec[i - 1].dest) destBegin.push_back((uint32_t)i);
+    }
+    const uint32_t nDest = (uint32_t)destBegin.size();
+    destBegin.push_back((uint32_t)rec.size());
+    HIP_TRY(recBuf.alloc(rec.size() * sizeof(FilmRecord)));
+    HIP_TRY(beginBuf.alloc(destBegin.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(recBuf.p, rec.data(), rec.size() * sizeof(FilmRecord), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(beginBuf.p, destBegin.data(), destBegin.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    LaunchFilmApplyRecords(st, recBuf.as<FilmRecord>(), beginBuf.as<uint32_t>(), nDest, film);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));      // the host vectors above must outlive the copies
+    return HPRT_OK;
+}
+
+int CheckGatherable(const HprtScene *s, size_t nPixels) {
+    if (!s->foreignExported) return SetError(HPRT_E_INVALID, "film gather: the scene's last render did not set HPRT_RENDER_EXPORT_FOREIGN");
+    if (nPixels != s->filmPixels) return SetError(HPRT_E_INVALID, "film gather: pixel count differs from the last render's film");
+    return HPRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hprt_comm_unique_id(uint8_t id[HPRT_COMM_ID_BYTES]) {
+    if (!id) return SetError(HPRT_E_INVALID, "hprt_comm_unique_id: null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SetError(HPRT_E_NO_DEVICE, "no HIP device available (hprt has no CPU fallback)");
+    ncclUniqueId u;
+    NCCL_TRY(ncclGetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return HPRT_OK;
+}
+
+int hprt_comm_create(const uint8_t id[HPRT_COMM_ID_BYTES], int rank, int n_ranks, int device, HprtComm **out) {
+    if (!id || !out) return SetError(HPRT_E_INVALID, "hprt_comm_create: null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return SetError(HPRT_E_INVALID, "hprt_comm_create: rank outside [0, n_ranks)");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SetError(HPRT_E_NO_DEVICE, "no HIP device available (hprt has no CPU fallback)");
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= n) return SetError(HPRT_E_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<HprtComm> c(new HprtComm());
+    c->rank = rank; c->nRanks = n_ranks; c->device = device;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    NCCL_TRY(ncclCommInitRank(&c->comm, n_ranks, u, rank));
+    HIP_TRY(c->counts.alloc(((size_t)n_ranks + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void **)&c->hostCounts, ((size_t)n_ranks + 1) * sizeof(uint32_t)));
+    *out = c.release();
+    return HPRT_OK;
+}
+
+int hprt_comm_info(const HprtComm *c, int *rank, int *n_ranks, int *device) {
+    if (!c) return SetError(HPRT_E_INVALID, "hprt_comm_info: null argument");
+    // what the communicator itself reports, not what the caller passed in
+    int r = -1, n = -1, d = -1;
+    NCCL_TRY(ncclCommUserRank(c->comm, &r));
+    NCCL_TRY(ncclCommCount(c->comm, &n));
+    NCCL_TRY(ncclCommCuDevice(c->comm, &d));
+    if (rank) *rank = r;
+    if (n_ranks) *n_ranks = n;
+    if (device) *device = d;
+    return HPRT_OK;
+}
+
+void hprt_comm_destroy(HprtComm *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    delete c;
+}
+
+int hprt_film_gather(HprtComm *c, HprtScene *s, float *d_film_xyzw, size_t n_pixels, int root, void *stream) {
+    if (!c || !s) return SetError(HPRT_E_INVALID, "hprt_film_gather: null argument");
+    if (root < 0 || root >= c->nRanks) return SetError(HPRT_E_INVALID, "hprt_film_gather: root outside the communicator");
+    if (s->device != c->device) return SetError(HPRT_E_INVALID, "hprt_film_gather: scene and communicator live on different devices");
+    int rc = CheckGatherable(s, n_pixels);
+    if (rc != HPRT_OK) return rc;
+    float *film = d_film_xyzw ? d_film_xyzw : s->film.as<float>();
+    if (!film) return SetError(HPRT_E_INVALID, "hprt_film_gather: no film (render first)");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int n = c->nRanks;
+    // ---- record counts of every rank ----
+    uint32_t *dCounts = c->counts.as<uint32_t>();
+    c->hostCounts[n] = s->nForeignRecords;
+    HIP_TRY(hipMemcpyAsync(dCounts + n, c->hostCounts + n, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    NCCL_TRY(ncclAllGather(dCounts + n, dCounts, 1, ncclUint32, c->comm, st));
+    HIP_TRY(hipMemcpyAsync(c->hostCounts, dCounts, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    size_t total = 0;
+    std::vector<size_t> offset((size_t)n + 1, 0);
+    for (int r = 0; r < n; ++r) { offset[r] = total; total += c->hostCounts[r]; }
+    offset[n] = total;
+    if (c->rank == root) HIP_TRY(c->staging.alloc(std::max<size_t>(1, total) * sizeof(FilmRecord)));
+    // ---- films: one reduce; records: peer -> root ----
+    constexpr size_t kWords = sizeof(FilmRecord) / sizeof(uint32_t);
+    NCCL_TRY(ncclGroupStart());
+    NCCL_TRY(ncclReduce(film, film, 4 * n_pixels, ncclFloat, ncclSum, root, c->comm, st));
+    if (c->rank == root) {
+        for (int r = 0; r < n; ++r)
+            if (r != root && c->hostCounts[r])
+                NCCL_TRY(ncclRecv(c->staging.as<FilmRecord>() + offset[r], c->hostCounts[r] * kWords, ncclUint32, r, c->comm, st));
+    } else if (s->nForeignRecords)
+        NCCL_TRY(ncclSend(s->foreignRecords.p, s->nForeignRecords * kWords, ncclUint32, root, c->comm, st));
+    NCCL_TRY(ncclGroupEnd());
+    if (c->rank != root) { HIP_TRY(hipStreamSynchronize(st)); return HPRT_OK; }
+    if (s->nForeignRecords)
+        HIP_TRY(hipMemcpyAsync(c->staging.as<FilmRecord>() + offset[root], s->foreignRecords.p, s->nForeignRecords * sizeof(FilmRecord), hipMemcpyDeviceToDevice, st));
+    std::vector<FilmRecord> rec(total);
+    if (total) HIP_TRY(hipMemcpyAsync(rec.data(), c->staging.p, total * sizeof(FilmRecord), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return ApplyRecords(rec, film, n_pixels, c->staging, c->destBegin, st);
+}
+
+int hprt_film_gather_local(HprtScene *const *per_gpu, float *const *d_films, int n, size_t n_pixels, int root) {
+    if (!per_gpu || n < 1 || root < 0 || root >= n) return SetError(HPRT_E_INVALID, "hprt_film_gather_local: bad argument");
+    std::vector<int> devs(n);
+    std::vector<float *> films(n);
+    for (int i = 0; i < n; ++i) {
+        if (!per_gpu[i]) return SetError(HPRT_E_INVALID, "hprt_film_gather_local: null scene");
+        int rc = CheckGatherable(per_gpu[i], n_pixels);
+        if (rc != HPRT_OK) return rc;
+        devs[i] = per_gpu[i]->device;
+        films[i] = (d_films && d_films[i]) ? d_films[i] : per_gpu[i]->film.as<float>();
+        if (!films[i]) return SetError(HPRT_E_INVALID, "hprt_film_gather_local: a scene has no film (render first)");
+        for (int k = 0; k < i; ++k) if (devs[k] == devs[i]) return SetError(HPRT_E_INVALID, "hprt_film_gather_local: two scenes on one device (RCCL refuses duplicate GPUs)");
+    }
+    // one clique of communicators per device list, created on first use and kept for the life of the process
+    struct Clique { std::vector<ncclComm_t> comms; DevBuf recBuf, beginBuf; };
+    static std::mutex mu;
+    static std::map<std::vector<int>, std::unique_ptr<Clique>> cliques;
+    std::lock_guard<std::mutex> lock(mu);
+    std::unique_ptr<Clique> &cl = cliques[devs];
+    if (!cl) {
+        std::unique_ptr<Clique> fresh(new Clique());
+        fresh->comms.resize(n);
+        NCCL_TRY(ncclCommInitAll(fresh->comms.data(), n, devs.data()));
+        cl = std::move(fresh);
+    }
+    NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < n; ++i) {
+        HIP_TRY(hipSetDevice(devs[i]));
+        NCCL_TRY(ncclReduce(films[i], films[i], 4 * n_pixels, ncclFloat, ncclSum, root, cl->comms[i], nullptr));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    // one process sees every device's memory: the records need no collective
+    std::vector<FilmRecord> rec;
+    for (int i = 0; i < n; ++i) {
+        HIP_TRY(hipSetDevice(devs[i]));
+        HIP_TRY(hipDeviceSynchronize());
+        const size_t k = per_gpu[i]->nForeignRecords, at = rec.size();
+        if (!k) continue;
+        rec.resize(at + k);
+        HIP_TRY(hipMemcpy(rec.data() + at, per_gpu[i]->foreignRecords.p, k * sizeof(FilmRecord), hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipSetDevice(devs[root]));
+    return ApplyRecords(rec, films[root], n_pixels, cl->recBuf, cl->beginBuf, nullptr);
+}
+
+int hprt_film_records_read(HprtScene *s, HprtFilmRecord *out, size_t capacity, size_t *n_records) {
+    if (!s || !n_records) return SetError(HPRT_E_INVALID, "hprt_film_records_read: null argument");
+    if (!s->foreignExported) return SetError(HPRT_E_INVALID, "hprt_film_records_read: the last render did not set HPRT_RENDER_EXPORT_FOREIGN");
+    *n_records = s->nForeignRecords;
+    if (!out || s->nForeignRecords == 0) return HPRT_OK;
+    if (capacity < s->nForeignRecords) return SetError(HPRT_E_INVALID, "hprt_film_records_read: buffer too small");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, s->foreignRecords.p, (size_t)s->nForeignRecords * sizeof(FilmRecord), hipMemcpyDeviceToHost));
+    return HPRT_OK;
+}
+
+}  // extern "C"

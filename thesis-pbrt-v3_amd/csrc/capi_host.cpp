@@ -1,6 +1,7 @@
 // hprt — host half of the C ABI (include/hprt.h): scene front-end, baked scenes,
 // BVH build, Halton tables, film resolve, PFM writer.  No HIP calls here; the
 // device half lives in capi_device.hip.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -235,6 +236,21 @@ int hprt_write_pfm(const char *path, const float *rgb, int width, int height) {
     for (int y = height - 1; y >= 0 && ok; --y) ok = fwrite(&rgb[3 * (size_t)y * width], sizeof(float), 3 * (size_t)width, fp) == 3 * (size_t)width;
     if (fclose(fp) != 0) ok = false;
     return ok ? HPRT_OK : SetError(HPRT_E_IO, std::string("write error on ") + path);
+}
+
+// Film::MergeFilmTile's accumulation (core/film.cpp:124-131) for cross-tile records on a host copy of the film: per
+// destination pixel in ascending source-tile order, exactly as the single-GPU film kernels add them.
+int hprt_film_records_merge(float *xyzw, size_t n_pixels, HprtFilmRecord *rec, size_t n) {
+    if (!xyzw || (n && !rec)) return SetError(HPRT_E_INVALID, "hprt_film_records_merge: null argument");
+    std::sort(rec, rec + n, [](const HprtFilmRecord &a, const HprtFilmRecord &b) {
+        return a.dest_pixel != b.dest_pixel ? a.dest_pixel < b.dest_pixel : a.src_tile < b.src_tile;
+    });
+    for (size_t i = 0; i < n; ++i) if (rec[i].dest_pixel >= n_pixels) return SetError(HPRT_E_INVALID, "film record outside the film");
+    for (size_t i = 0; i < n; ++i) {
+        float *px = xyzw + 4 * (size_t)rec[i].dest_pixel;
+        px[0] += rec[i].xyz[0]; px[1] += rec[i].xyz[1]; px[2] += rec[i].xyz[2]; px[3] += rec[i].weight;
+    }
+    return HPRT_OK;
 }
 
 }  // extern "C"

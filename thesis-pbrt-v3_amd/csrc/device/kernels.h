@@ -16,7 +16,7 @@ namespace hprt {
 struct RayStream { float4 *a, *b; };                 // a = {o.xyz, tMax}   b = {d.xyz, aux}
 struct HitStream { float4 *a; float2 *b; };           // a = {t, prim, b0, b1}   b = {b2, instance or -1}; b may be null
 struct PathStream {
-    RayStream ray;          // current path segment; ray.b.w = sampler dimension (bits 0-7) | bounces (bits 8-15)
+    RayStream ray;          // current path segment; ray.b.w = sampler dimension (bits 0-15) | bounces (bits 16-31)
     float4 *beta;           // {beta.rgb, path id}   path id = sampleInBatch * nPix + pixel
     float4 *L;              // {L.rgb, 1 if the path continues after this vertex else 0}
 };
@@ -64,6 +64,10 @@ struct FilmExtras {
     const uint32_t *foreignSrcPix; const uint32_t *foreignSample;
 };
 
+// One cross-tile film contribution (HprtFilmRecord of include/hprt.h): the fold of one source tile's samples that land in
+// film pixel `dest` of another tile
+struct FilmRecord { uint32_t dest, srcTile; float xyz[3]; float w; };
+
 void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
                  uint32_t countImm, uint32_t gridItems, const RayStream &rays, const HitStream &hits, uint8_t *occ,
                  DevCounters *counters, uint32_t *workCounter, uint4 *rayStats = nullptr);
@@ -91,5 +95,9 @@ void LaunchFilmOwn(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, c
                    uint32_t spp, const FilmExtras &ex, float *film);
 void LaunchFilmForeign(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, const float *LallR, const float *LallG,
                        const float *LallB, const FilmExtras &ex, float *film);
+void LaunchFilmForeignExport(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, const float *LallR, const float *LallG,
+                             const float *LallB, const FilmExtras &ex, uint32_t nGroups, const uint32_t *groupDest, const uint32_t *groupTile,
+                             FilmRecord *out);
+void LaunchFilmApplyRecords(hipStream_t st, const FilmRecord *rec, const uint32_t *destBegin, uint32_t nDest, float *film);
 
 }  // namespace hprt

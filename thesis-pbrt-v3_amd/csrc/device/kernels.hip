@@ -593,8 +593,8 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
         const float4 beta4 = firstBounce ? make_float4(1.f, 1.f, 1.f, __uint_as_float(slot)) : in.beta[slot];
         const float4 L4 = firstBounce ? make_float4(0.f, 0.f, 0.f, 1.f) : in.L[slot];
         const uint32_t st = __float_as_uint(rayB.w);
-        int dim = (int)(st & 0xffu);
-        const int bounces = (int)((st >> 8) & 0xffu);
+        int dim = (int)(st & 0xffffu);
+        const int bounces = (int)(st >> 16);
         const uint32_t pathId = __float_as_uint(beta4.w);
         const uint32_t pix = pathId % rp.nPix, sIdx = pathId / rp.nPix;
         const uint64_t index = (uint64_t)rp.pixelOffset[pix] + (uint64_t)(s0 + sIdx) * (uint64_t)rp.hal.sampleStride;
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                 if (rp.cullMis && bounces + 1 >= rp.maxDepth) alive = false;
                 if (alive) {
                     out.ray.a[j] = make_float4(o.x, o.y, o.z, HPRT_INF);
-                    out.ray.b[j] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((uint32_t)dim | ((uint32_t)(bounces + 1) << 8)));
+                    out.ray.b[j] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((uint32_t)dim | ((uint32_t)(bounces + 1) << 16)));
                     out.beta[j] = make_float4(beta.r, beta.g, beta.b, beta4.w);
                     wantNext = true;
                 }
@@ -973,6 +973,37 @@ __global__ __launch_bounds__(64) void k_film_foreign(RenderParams rp, FilmGeom f
     }
 }
 
+// HPRT_RENDER_EXPORT_FOREIGN (tile-sharded renders): the same per-source-tile folds as k_film_foreign, but each
+// group's {xyz, weight} is written out as a record instead of being merged, so that the gather can merge the groups of
+// ALL ranks into the destination pixel in ascending source-tile order — the order of the single-GPU film.
+__global__ __launch_bounds__(64) void k_film_foreign_export(RenderParams rp, FilmGeom fg, const float *LallR, const float *LallG,
+                                                            const float *LallB, FilmExtras ex, uint32_t nGroups, const uint32_t *groupDest,
+                                                            const uint32_t *groupTile, FilmRecord *out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nGroups) return;
+    rgb c(0.f); float w = 0.f;
+    for (uint32_t e = ex.foreignGroupBegin[g]; e < ex.foreignGroupBegin[g + 1]; ++e) {
+        const size_t o = (size_t)ex.foreignSample[e] * rp.nPix + ex.foreignSrcPix[e];
+        c = c + clamp_luminance(rgb(LallR[o], LallG[o], LallB[o]), fg.maxSampleLuminance) * 1.0f * 1.0f;
+        w += 1.f;
+    }
+    FilmRecord r;
+    r.dest = groupDest[g]; r.srcTile = groupTile[g];
+    rgb_to_xyz(c, r.xyz);
+    r.w = w;
+    out[g] = r;
+}
+// Film::MergeFilmTile's `mergePixel.xyz[i] += xyz[i]; filterWeightSum += ...` (core/film.cpp:124-131) for exported
+// records: one thread per destination pixel, its records in ascending source-tile order.
+__global__ __launch_bounds__(64) void k_film_apply_records(const FilmRecord *rec, const uint32_t *destBegin, uint32_t nDest, float *filmXYZW) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nDest) return;
+    const size_t fo = 4 * (size_t)rec[destBegin[d]].dest;
+    for (uint32_t k = destBegin[d]; k < destBegin[d + 1]; ++k) {
+        filmXYZW[fo] += rec[k].xyz[0]; filmXYZW[fo + 1] += rec[k].xyz[1]; filmXYZW[fo + 2] += rec[k].xyz[2]; filmXYZW[fo + 3] += rec[k].w;
+    }
+}
+
 __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1126,6 +1157,14 @@ void LaunchFilmOwn(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, c
 void LaunchFilmForeign(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, const float *LallR, const float *LallG,
                        const float *LallB, const FilmExtras &ex, float *film) {
     if (ex.nForeignDest) hipLaunchKernelGGL(k_film_foreign, dim3(blocks_for(ex.nForeignDest, 64)), dim3(64), 0, st, rp, fg, LallR, LallG, LallB, ex, film);
+}
+void LaunchFilmForeignExport(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, const float *LallR, const float *LallG,
+                             const float *LallB, const FilmExtras &ex, uint32_t nGroups, const uint32_t *groupDest, const uint32_t *groupTile,
+                             FilmRecord *out) {
+    if (nGroups) hipLaunchKernelGGL(k_film_foreign_export, dim3(blocks_for(nGroups, 64)), dim3(64), 0, st, rp, fg, LallR, LallG, LallB, ex, nGroups, groupDest, groupTile, out);
+}
+void LaunchFilmApplyRecords(hipStream_t st, const FilmRecord *rec, const uint32_t *destBegin, uint32_t nDest, float *film) {
+    if (nDest) hipLaunchKernelGGL(k_film_apply_records, dim3(blocks_for(nDest, 64)), dim3(64), 0, st, rec, destBegin, nDest, film);
 }
 
 }  // namespace hprt

@@ -1,0 +1,63 @@
+// hprt — host-side state of a device scene, shared by capi_device.hip (upload, trace, render) and
+// capi_gather.hip (multi-GPU film gather).  Library-internal.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "../../include/hprt.h"
+#include "device/kernels.h"
+#include "hprt_internal.h"
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return hprt::SetError(HPRT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));   \
+    } while (0)
+
+namespace hprt {
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) {
+        if (p && bytes >= n) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (n == 0) return hipSuccess;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <typename T> T *as() const { return (T *)p; }
+};
+template <typename T> hipError_t upload(DevBuf &b, const std::vector<T> &v) {
+    hipError_t e = b.alloc(std::max<size_t>(v.size() * sizeof(T), 16));
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+}  // namespace hprt
+
+struct HprtScene {
+    int device = 0;
+    hprt::DevScene dev;
+    hprt::DevBuf textures, mipLevels, texels, weightLut;
+    hprt::DevBuf nodes, tris, primVtx, primN, vUV, vS, shapes, materials, lights, spheres, instances, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
+    hprt::DevBuf counters, workCounter;
+    hprt::DevBuf rayStats, pixelStatsLocal, pixelStatsFilm; bool pixelStatsValid = false;   // HPRT_RENDER_PIXEL_STATS
+    // render-time state
+    hprt::DevBuf planes;                                    // backing store of the path streams (Workspace)
+    hprt::DevBuf apiRays, apiHits;                          // stream copies of the plane-layout arguments of the *_device calls
+    hprt::DevBuf queues, queueCounts;
+    hprt::DevBuf pixelXY, pixelOffset, Lall, film, irregular, irregularCount;
+    hprt::DevBuf exOwnBegin, exOwnSrc, exOwnSample, exOwnPre, exFDest, exFDestBegin, exFGroupBegin, exFSrc, exFSample;
+    // HPRT_RENDER_EXPORT_FOREIGN: the cross-tile film contributions of the last render, one record per (destination
+    // pixel, source tile), sorted by both; applied by hprt_film_gather on the root in the single-GPU order
+    hprt::DevBuf foreignRecords, exGroupDest, exGroupTile; uint32_t nForeignRecords = 0; bool foreignExported = false;
+    int filmW = 0, filmH = 0;
+    uint32_t *hostCounts = nullptr;                   // pinned
+    size_t filmPixels = 0;
+    uint32_t nPrims = 0;
+    ~HprtScene() { if (hostCounts) (void)hipHostFree(hostCounts); }
+};

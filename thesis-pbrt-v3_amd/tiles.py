@@ -4,11 +4,20 @@ The reference renders 16x16 tiles from a shared-memory worker pool
 (core/integrator.cpp:237-244, core/parallel.cpp:247-299) and merges each FilmTile under
 a mutex (core/film.cpp:118-132).  Here rank r of `world` renders tiles r, r+world, ...
 of the same row-major tile grid into its own film buffer (xyz + filterWeightSum per
-pixel, zeros for pixels of tiles it does not own) and the buffers are SUMMED onto rank 0
-with one reduce (RCCL over xGMI on GPUs, gloo in the CPU tests).  Every pixel has one
-non-zero addend except the few that receive a box-filter sample from a neighbouring
-tile (core/film.h:136-143), where the sum is exactly MergeFilmTile's `xyz += ...`.
+pixel, zeros for pixels of tiles it does not own) and the buffers are merged on rank 0.
+
+On GPUs the merge is `Comm.film_gather` (hprt_film_gather, csrc/capi_gather.hip): one
+ncclReduce of the films over xGMI plus a grouped send/recv of the few box-filter
+contributions that cross a tile border (core/film.h:136-143), which the root adds per
+pixel in source-tile order — the order of the single-GPU film, so the result does not
+depend on the number of ranks.  `gather_film` below is the same merge with
+torch.distributed as the transport (gloo: CPU tests, or several ranks sharing one GPU,
+which RCCL refuses): reduce(SUM) of the films, gather of the records, ordered merge on
+the host (hprt_film_records_merge).
 """
+import importlib
+
+import numpy as np
 
 
 def shard(rank, world):
@@ -18,18 +27,31 @@ def shard(rank, world):
     return {"tile_begin": rank, "tile_end": 0, "tile_stride": world}
 
 
-def gather_film(film, dist, dst=0):
-    """Sum the per-rank film tensors onto `dst` (in place).  `dist` is torch.distributed.
+def gather_film(film, dist, dst=0, records=None):
+    """Merge the per-rank film tensors onto `dst` (in place).  `dist` is torch.distributed.
 
-    With the RCCL backend ("nccl") the device tensor is reduced directly over xGMI.  With
-    gloo (CPU rehearsals, or several ranks sharing one GPU in the tests) a device tensor
-    takes a round trip through host memory."""
-    if film.is_cuda and dist.get_backend() == "gloo":
-        host = film.cpu()
-        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+    records: this rank's cross-tile records (`Scene.film_records()`, or an empty FILM_RECORD array) when the films were
+    rendered with export_foreign=True; None when each rank merged its cross-tile contributions into its own film
+    (then the plain sum is the merged film, exact as long as no pixel receives contributions from more than two ranks).
+    With the RCCL backend ("nccl") a device tensor is reduced directly over xGMI; with gloo it takes a round trip
+    through host memory."""
+    via_host = film.is_cuda and dist.get_backend() == "gloo"
+    host = film.cpu() if via_host else film
+    dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+    if records is not None:
+        world = dist.get_world_size()
+        parts = [None] * world if dist.get_rank() == dst else None
+        dist.gather_object(np.ascontiguousarray(records), parts, dst=dst)
+        if dist.get_rank() == dst:
+            hprt = importlib.import_module(__package__)
+            allrec = np.concatenate([np.asarray(p, hprt.FILM_RECORD) for p in parts]) if parts else np.zeros(0, hprt.FILM_RECORD)
+            merged = host.cpu().numpy() if host.is_cuda else host.numpy()
+            hprt.film_records_merge(merged, allrec)
+            if host.is_cuda:
+                import torch
+                host.copy_(torch.from_numpy(merged))
+    if via_host:
         film.copy_(host)
-    else:
-        dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
     return film
 
 

@@ -1,0 +1,62 @@
+"""Summarise tools/counters_passes.sh for one workload: per kernel of ONE plain bench step
+  launches, avg_launch_ms (kernel trace), hbm_bytes_per_launch / hbm_gbs / hbm_frac (FETCH_SIZE + WRITE_SIZE passes),
+  lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU), wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES,
+and for the step: kernel time, HBM bytes, HBM bytes / kernel time / peak.
+Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM): FETCH_SIZE and WRITE_SIZE count KiB; FETCH_SIZE
+reports half of the bytes of 16-B-per-lane reads on gfx950 and is doubled; WRITE_SIZE is taken as is.
+usage: counters_summary.py <dir with stats/ sq/ fetch/ write/> <workload name>   -> JSON on stdout"""
+import collections, csv, glob, json, re, sys
+
+root, workload = sys.argv[1], sys.argv[2]
+PEAK = 8000.0e9
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "").replace("hprt::", "").strip()
+    m = re.match(r"k_trace<(false|true), (\d), (false|true)>", n)
+    if m:
+        base = "k_trace<%s>" % ("any" if m.group(1) == "true" else "closest")
+        return base + ("" if m.group(2) == "0" else "[mode %s]" % m.group(2)) + ("[inst]" if m.group(3) == "true" else "")
+    m = re.match(r"k_shade<(\d), (\d+)(, (false|true))?>", n)
+    if m:
+        return "k_shade<%s>" % {"0": "matte", "1": "plastic", "2": "generic"}[m.group(1)] + ("[tex]" if m.group(4) == "true" else "")
+    return n
+
+
+def rows(sub, pattern):
+    for f in glob.glob("%s/%s/*/%s" % (root, sub, pattern)):
+        for r in csv.DictReader(open(f)):
+            yield r
+
+
+K = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in rows("stats", "*_kernel_stats.csv"):
+    k = short(r["Name"])
+    K[k]["launches"] += int(r["Calls"]); K[k]["total_ns"] += float(r["TotalDurationNs"])
+for sub in ("sq", "fetch", "write"):
+    for r in rows(sub, "*_counter_collection.csv"):
+        K[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+out = {}
+step_ns = step_hbm = 0.0
+for k, v in K.items():
+    if not k.startswith("k_") or not v.get("launches"):
+        continue
+    e = {"launches": int(v["launches"]), "avg_launch_ms": round(v["total_ns"] / v["launches"] / 1e6, 4), "total_ms": round(v["total_ns"] / 1e6, 3)}
+    if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
+        hbm = (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
+        e["hbm_bytes_per_launch"] = round(hbm / v["launches"]); e["hbm_bytes_total"] = round(hbm)
+        e["hbm_gbs"] = round(hbm / (v["total_ns"] * 1e-9) / 1e9, 1); e["hbm_frac"] = round(hbm / (v["total_ns"] * 1e-9) / PEAK, 4)
+        step_hbm += hbm
+    if v.get("SQ_ACTIVE_INST_VALU"):
+        e["lane_utilisation"] = round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4)
+    if v.get("SQ_WAVE_CYCLES"):
+        e["wait_frac"] = round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4)
+        e["valu_per_wave"] = round(v["SQ_INSTS_VALU"] / max(1.0, v["SQ_WAVES"]), 1); e["salu_per_wave"] = round(v["SQ_INSTS_SALU"] / max(1.0, v["SQ_WAVES"]), 1)
+    step_ns += v["total_ns"]
+    out[k] = e
+res = {"command": "python3 bench.py --profile-step --workload " + workload,
+       "correction": "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (KiB units; FETCH_SIZE doubled on gfx950)",
+       "kernel_ms_per_step": round(step_ns / 1e6, 2), "hbm_bytes_per_step": round(step_hbm),
+       "step_hbm_frac": round(step_hbm / max(step_ns * 1e-9, 1e-12) / PEAK, 4) if step_ns else None,
+       "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["total_ms"]))}
+print(json.dumps({workload: res}, indent=1))
