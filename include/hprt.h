@@ -255,6 +255,11 @@ typedef struct HprtRenderDesc {
  * (FilmTile pixels outside the tile's own 16x16 block, core/film.cpp:98-103) are not merged into the film but kept as
  * HprtFilmRecords, so that the gather can merge the records of ALL ranks into each pixel in source-tile order. */
 #define HPRT_RENDER_EXPORT_FOREIGN 16
+/* The shadow-ray trace, the MIS-ray trace and the next bounce's path trace that follow a shading pass are independent
+ * and normally run on three HIP streams (each fills the tails of the others' persistent kernels).  SERIAL keeps every
+ * kernel on the caller's stream, so that extend_seconds / occluded_seconds (and a profiler's per-kernel durations) are
+ * exclusive times; counting renders are always serial.  Same film either way. */
+#define HPRT_RENDER_SERIAL 32
 
 typedef struct HprtRenderStats {
     uint64_t camera_rays;          /* nCameraRays, core/integrator.cpp:48,293 */
@@ -268,6 +273,7 @@ typedef struct HprtRenderStats {
     double extend_seconds, occluded_seconds;  /* HIP-event time inside the traversal kernels */
     uint64_t extend_launches, occluded_launches;
     uint64_t extend_rays, occluded_rays;
+    uint64_t traces_overlapped;    /* 1: the traces ran on concurrent streams, the *_seconds above overlap each other */
 } HprtRenderStats;
 
 /* Renders into the scene's film.  d_film_xyzw, if not NULL, is a caller-owned

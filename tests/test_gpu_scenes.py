@@ -81,6 +81,12 @@ CASES = {
     "instances_only_point_light": _scene('LightSource "point" "point from" [1 -2 4] "color I" [30 30 30]\n' + MATTE +
                                          'ObjectBegin "bump"\nShape "trianglemesh" ' + BUMPY + "\nObjectEnd\n" +
                                          'ObjectInstance "bump"\nAttributeBegin\nTranslate 0 0 -1\nScale 2 2 1\nObjectInstance "bump"\nAttributeEnd\n'),
+    # a closed, nearly white room: with rrthreshold 0 no path is ever cut by Russian roulette, so every path runs to maxdepth 40 and
+    # consumes sampler dimensions far beyond 256 (the dimension / bounce packing of the path state)
+    "maxdepth40_high_albedo": _scene('LightSource "point" "point from" [0 -3 3] "color I" [8 8 8]\nMaterial "matte" "color Kd" [.97 .97 .97]\n'
+                                     'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3  4 6 5 4 7 6  0 4 5 0 5 1  1 5 6 1 6 2  2 6 7 2 7 3  3 7 4 3 4 0] '
+                                     '"point P" [-8 -8 -2  8 -8 -2  8 8 -2  -8 8 -2  -8 -8 9  8 -8 9  8 8 9  -8 8 9]\n' + PLASTIC +
+                                     'Shape "trianglemesh" ' + BUMPY + "\n", xres=48, yres=36, spp=2, maxdepth=40, integ='"float rrthreshold" [0]'),
     "no_lights": _scene(GEOM),
     "empty_scene": _scene(""),
     "light_only": _scene(SPHERE_LIGHT),

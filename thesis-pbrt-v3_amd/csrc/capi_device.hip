@@ -470,7 +470,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     HIP_TRY(upload(sc->textures, textures)); HIP_TRY(upload(sc->mipLevels, mipLevels)); HIP_TRY(upload(sc->texels, texels)); HIP_TRY(upload(sc->weightLut, weightLut));
     HIP_TRY(sc->counters.alloc(sizeof(DevCounters)));
     HIP_TRY(hipMemset(sc->counters.p, 0, sizeof(DevCounters)));
-    HIP_TRY(sc->workCounter.alloc(64));
+    HIP_TRY(sc->workCounter.alloc(1024));      // three queue-head counters, 256 bytes apart
     DevScene &dv = sc->dev;
     dv.pairs = sc->nodes.as<DevPair>(); dv.nPairs = (uint32_t)pairs.size();
     dv.tris = sc->tris.as<float4>(); dv.nPrims = totalPrims;
@@ -697,58 +697,85 @@ struct BatchTimers { double extendMs = 0, occludedMs = 0; uint64_t extendLaunche
 
 // Runs the bounce loop for one batch of nSlots freshly generated paths.
 // pixelStats (or null): [6][nPix] per-pixel counters of the local pixels, fed from the per-ray counts of every trace
+//
+// Per bounce b:   trace(path b) -> bin -> shade x3 -> [counts to the host] -> trace(shadow b) | trace(MIS b) | trace(path b+1)
+//                 -> resolve(b) -> bin(b+1) ...
+// The three traces that follow a shading pass depend on nothing but that pass, so with `overlap` they run on three
+// streams: every persistent trace kernel ends with a tail of half-empty waves, and the other two fill it.  Radiance is
+// still added in the reference's order (resolve(b) before anything of bounce b+1 reads L).  Counting renders and
+// HPRT_RENDER_SERIAL keep everything on the caller's stream, where the HIP-event times of the kernels are exclusive.
 int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspace &w, const QueueSet &qa, const QueueSet &qb,
-             const BinSet &bins, uint32_t s0, uint32_t nSlots, bool count, EventTimer &ev, BatchTimers *bt, HprtRenderStats *stats,
+             const BinSet &bins, uint32_t s0, uint32_t nSlots, bool count, bool overlap, EventTimer &ev, BatchTimers *bt, HprtRenderStats *stats,
              uint32_t *pixelStats = nullptr) {
     uint4 *rayStats = pixelStats ? s->rayStats.as<uint4>() : nullptr;
+    if (count || pixelStats) overlap = false;
+    hipStream_t stShadow = st, stMis = st;
+    if (overlap) {
+        for (int k = 0; k < 2; ++k) if (!s->auxStream[k]) HIP_TRY(hipStreamCreateWithFlags(&s->auxStream[k], hipStreamNonBlocking));
+        stShadow = s->auxStream[0]; stMis = s->auxStream[1];
+    }
+    // one queue-head counter per stream (256 bytes apart)
+    uint32_t *wcPath = s->workCounter.as<uint32_t>(), *wcShadow = wcPath + 64, *wcMis = wcPath + 128;
     LaunchGenerate(st, s->dev, rp, w.path[0], s0, nSlots);
     const uint32_t *activeQ = nullptr; uint32_t active = nSlots;
     QueueSet q[2] = {qa, qb};
     DevCounters *ctr = s->counters.as<DevCounters>();
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evExt, evOcc;
-    for (int bounce = 0; active > 0; ++bounce) {
-        const QueueSet &cur = q[bounce & 1];
-        const PathStream &in = w.path[bounce & 1], &out = w.path[(bounce + 1) & 1];
+    auto tracePath = [&](int bounce) -> int {      // closest hits of the path segments entering bounce `bounce`
+        const PathStream &in = w.path[bounce & 1];
         hipEvent_t e0 = ev.get(), e1 = ev.get();
         HIP_TRY(hipEventRecord(e0, st));
-        LaunchTrace(st, s->dev, false, count, activeQ, nullptr, active, active, in.ray, w.hit, nullptr, ctr, s->workCounter.as<uint32_t>(), rayStats);
+        LaunchTrace(st, s->dev, false, count, activeQ, nullptr, active, active, in.ray, w.hit, nullptr, ctr, wcPath, rayStats);
         if (pixelStats) LaunchPixelStats(st, rayStats, bounce == 0 ? nullptr : in.beta, activeQ, nullptr, active, active, rp.nPix, false, pixelStats);
         HIP_TRY(hipEventRecord(e1, st));
         evExt.push_back({e0, e1}); bt->extendRays += active; ++bt->extendLaunches;
         stats->rays += active;
+        return HPRT_OK;
+    };
+    if (active > 0) { int rc = tracePath(0); if (rc != HPRT_OK) return rc; }
+    for (int bounce = 0; active > 0; ++bounce) {
+        const QueueSet &cur = q[bounce & 1];
+        const PathStream &in = w.path[bounce & 1], &out = w.path[(bounce + 1) & 1];
         HIP_TRY(hipMemsetAsync(cur.nextCount, 0, 256 * sizeof(uint32_t), st));   // the four counters, 64 words apart
-        HIP_TRY(hipMemsetAsync(bins.count, 0, 4 * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(bins.count, 0, 4 * BIN_STRIDE * sizeof(uint32_t), st));
         LaunchBin(st, s->dev, in, w.hit, activeQ, nullptr, active, active, rp.maxDepth, bounce, bins, w.Lfinal);
-        HIP_TRY(hipMemcpyAsync(bins.count + 3, bins.count + 2, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));   // bin 2 before deferrals
+        HIP_TRY(hipMemcpyAsync(bins.count + 3 * BIN_STRIDE, bins.count + 2 * BIN_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));   // bin 2 before deferrals
         // one launch per material bin; grids are sized for the upper bound, surplus blocks exit on the bin's count
         for (int mode = 0; mode < 3; ++mode)
             LaunchShade(st, mode, s->dev, rp, in, w.hit, active, s0, out, w.vs, cur, bins, w.Lfinal, bounce == 0);
         HIP_TRY(hipMemcpyAsync(s->hostCounts + 4096, cur.nextCount, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipStreamSynchronize(st));      // (the other streams may start now: everything they read is complete)
+        hipEvent_t evShadowEnd = nullptr, evMisEnd = nullptr;
         const uint32_t nNext = s->hostCounts[4096], nShadow = s->hostCounts[4096 + 64], nMis = s->hostCounts[4096 + 128], nResolve = s->hostCounts[4096 + 192];
         if (nShadow) {
             hipEvent_t a = ev.get(), b = ev.get();
-            HIP_TRY(hipEventRecord(a, st));
+            HIP_TRY(hipEventRecord(a, stShadow));
             HitStream none; none.a = nullptr; none.b = nullptr;
-            LaunchTrace(st, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, w.vs.shadow, none, w.vs.occluded, ctr, s->workCounter.as<uint32_t>(), rayStats);
-            if (pixelStats) LaunchPixelStats(st, rayStats, w.vs.pendBeta, cur.shadow, nullptr, nShadow, nShadow, rp.nPix, true, pixelStats);
-            HIP_TRY(hipEventRecord(b, st));
+            LaunchTrace(stShadow, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, w.vs.shadow, none, w.vs.occluded, ctr, wcShadow, rayStats);
+            if (pixelStats) LaunchPixelStats(stShadow, rayStats, w.vs.pendBeta, cur.shadow, nullptr, nShadow, nShadow, rp.nPix, true, pixelStats);
+            HIP_TRY(hipEventRecord(b, stShadow));
             evOcc.push_back({a, b}); bt->occludedRays += nShadow; ++bt->occludedLaunches;
             stats->shadow_rays += nShadow;
+            evShadowEnd = b;
         }
         if (nMis) {
             hipEvent_t a = ev.get(), b = ev.get();
-            HIP_TRY(hipEventRecord(a, st));
-            LaunchTrace(st, s->dev, false, count, cur.mis, nullptr, nMis, nMis, w.vs.mis, w.vs.misHit, nullptr, ctr, s->workCounter.as<uint32_t>(), rayStats);
-            if (pixelStats) LaunchPixelStats(st, rayStats, w.vs.pendBeta, cur.mis, nullptr, nMis, nMis, rp.nPix, false, pixelStats);
-            HIP_TRY(hipEventRecord(b, st));
+            HIP_TRY(hipEventRecord(a, stMis));
+            LaunchTrace(stMis, s->dev, false, count, cur.mis, nullptr, nMis, nMis, w.vs.mis, w.vs.misHit, nullptr, ctr, wcMis, rayStats);
+            if (pixelStats) LaunchPixelStats(stMis, rayStats, w.vs.pendBeta, cur.mis, nullptr, nMis, nMis, rp.nPix, false, pixelStats);
+            HIP_TRY(hipEventRecord(b, stMis));
             evExt.push_back({a, b}); bt->extendRays += nMis; ++bt->extendLaunches;
             stats->rays += nMis;
+            evMisEnd = b;
         }
-        if (nResolve) LaunchResolve(st, s->dev, w.vs, out.L, w.Lfinal, cur.resolve, cur.resolveCount, nResolve);
         activeQ = cur.next; active = nNext;
         // (maxDepth is bounded by CheckDepth, and no path outlives bounce maxDepth)
         if (active > 0 && bounce > rp.maxDepth) return SetError(HPRT_E_DEVICE, "internal error: paths are still active beyond maxdepth");
+        // the next bounce's path trace is enqueued BEFORE st waits for the shadow / MIS traces, so the three run together
+        if (active > 0) { int rc = tracePath(bounce + 1); if (rc != HPRT_OK) return rc; }
+        if (overlap && evShadowEnd) HIP_TRY(hipStreamWaitEvent(st, evShadowEnd, 0));
+        if (overlap && evMisEnd) HIP_TRY(hipStreamWaitEvent(st, evMisEnd, 0));
+        if (nResolve) LaunchResolve(st, s->dev, w.vs, out.L, w.Lfinal, cur.resolve, cur.resolveCount, nResolve);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
@@ -849,6 +876,8 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     rp.invSqrtSpp = 1 / std::sqrt((float)spp);      // ScaleDifferentials' factor, core/integrator.cpp:288-289
     const bool wantPixelStats = (desc->flags & HPRT_RENDER_PIXEL_STATS) != 0;
     const bool count = (desc->flags & HPRT_RENDER_COUNT_WORK) != 0 || wantPixelStats;
+    static const bool serialEnv = getenv("HPRT_SERIAL") != nullptr;
+    const bool overlap = !count && !(desc->flags & HPRT_RENDER_SERIAL) && !serialEnv;
     // a counting render traces exactly the reference's rays (its counters are the reference's) unless asked to count what a plain render traces
     rp.cullMis = (!count || (desc->flags & HPRT_RENDER_COUNT_TRACED) != 0) && !(desc->flags & HPRT_RENDER_TRACE_ALL) ? 1 : 0;
     uint32_t *pixelStats = nullptr;
@@ -935,7 +964,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     EventTimer ev; BatchTimers bt;
     for (uint32_t s0 = 0; s0 < spp; s0 += chunk) {
         const uint32_t c = std::min(chunk, spp - s0), nSlots = c * nPix;
-        rc = RunBatch(s, st, rp, ps, qa, qb, bins, s0, nSlots, count, ev, &bt, stats, pixelStats);
+        rc = RunBatch(s, st, rp, ps, qa, qb, bins, s0, nSlots, count, overlap, ev, &bt, stats, pixelStats);
         if (rc != HPRT_OK) return rc;
         LaunchStoreRadiance(st, ps.Lfinal, LallR, LallG, LallB, nPix, s0, nSlots);
     }
@@ -961,6 +990,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     stats->extend_seconds = bt.extendMs * 1e-3; stats->occluded_seconds = bt.occludedMs * 1e-3;
     stats->extend_launches = bt.extendLaunches; stats->occluded_launches = bt.occludedLaunches;
     stats->extend_rays = bt.extendRays; stats->occluded_rays = bt.occludedRays;
+    stats->traces_overlapped = overlap ? 1 : 0;
     if (count) {
         DevCounters c;
         HIP_TRY(hipMemcpy(&c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
@@ -1018,7 +1048,7 @@ int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, c
     rp.maxDepth = opt->max_depth; rp.rrThreshold = opt->rr_threshold;
     rp.invSqrtSpp = 1 / std::sqrt((float)std::max(1, opt->spp)); rp.cullMis = 1;
     EventTimer ev; BatchTimers bt; HprtRenderStats stats; memset(&stats, 0, sizeof(stats));
-    rc = RunBatch(s, nullptr, rp, ps, qa, qb, bins, 0, (uint32_t)n, false, ev, &bt, &stats);
+    rc = RunBatch(s, nullptr, rp, ps, qa, qb, bins, 0, (uint32_t)n, false, false, ev, &bt, &stats);
     if (rc != HPRT_OK) return rc;
     float *LR = s->Lall.as<float>();
     LaunchStoreRadiance(nullptr, ps.Lfinal, LR, LR + n, LR + 2 * n, (uint32_t)n, 0, (uint32_t)n);

@@ -32,8 +32,10 @@ struct QueueSet {
     uint32_t *next, *shadow, *mis, *resolve;
     uint32_t *nextCount, *shadowCount, *misCount, *resolveCount;
 };
-// material bins: 0 matte, 1 plastic, 2 generic.  count[0..2] sizes, count[3] = size of bin 2 before
-// the specialised variants deferred vertices to it; aux[k] = output index of a deferred entry k.
+// material bins: 0 matte, 1 plastic, 2 generic.  count[k * BIN_STRIDE], k = 0..2: sizes; k = 3: size of bin 2 before
+// the specialised variants deferred vertices to it (counters 256 bytes apart: atomics on different bins do not share a
+// line); aux[k] = output index of a deferred entry k.
+enum : uint32_t { BIN_STRIDE = 64u };
 struct BinSet { uint32_t *q[3]; uint32_t *aux; uint32_t *count; };
 struct RenderParams {
     DevCamera cam;

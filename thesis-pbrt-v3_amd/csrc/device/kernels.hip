@@ -528,38 +528,79 @@ __global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, 
 // shading: they end here and hand their radiance to Lfinal[path id]; emitted radiance is
 // only added at bounce 0 (path.cpp:97).
 // ---------------------------------------------------------------------------
+// Every workgroup bins HPRT_BIN_ITEMS x 1024 paths and appends to each bin with ONE atomic: single-address atomics retire
+// at ~90 per microsecond on this chip, and with one workgroup per 1024 paths the three atomics of 122 k workgroups were most
+// of this kernel's time (it moved 2.9 TB/s where plain stream kernels reach 5-6).  The counters of the bins sit on separate
+// 256-byte lines (BIN_STRIDE).
+#define HPRT_BIN_ITEMS 4
 __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStream hit, const uint32_t *queue, const uint32_t *countPtr,
                                               uint32_t countImm, int32_t maxDepth, int32_t bounces, BinSet bins, float4 *Lfinal) {
-    __shared__ BlockAppendLds al;
+    __shared__ uint32_t waveCount[3][HPRT_BIN_ITEMS * 16];      // [bin][item round * 16 + wave]
+    __shared__ uint32_t binBase[3];
     const uint32_t n = countPtr ? *countPtr : countImm;
-    if (blockIdx.x * blockDim.x >= n) return;      // whole block beyond the queue (grids are sized for the batch)
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    int bin = -1;
-    uint32_t slot = 0;
-    if (i < n) {
-        slot = queue ? queue[i] : i;
-        // the hit's primitive word carries the bin (dev_scene.h); every path of this pass is at the same bounce
-        const int32_t word = __float_as_int(hit.a[slot].y);
-        if (word >= 0) {
-            // triangles reached directly go to the material-specialised variants; quadrics and hits inside
-            // object instances (surface interaction transformed back to world space) to the generic one
-            const bool generic = ((uint32_t)word & HIT_GENERIC) != 0u;
-            if (bounces >= maxDepth) { if (bounces == 0 && generic) bin = 2; }   // only an emitter hit by a camera ray matters
-            else if (generic) bin = 2;
-            else bin = ((uint32_t)word & HIT_PLASTIC) ? 1 : 0;
+    const uint32_t first = blockIdx.x * (HPRT_BIN_ITEMS * 1024u);
+    if (first >= n) return;      // whole block beyond the queue (grids are sized for the batch)
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    int bin[HPRT_BIN_ITEMS];
+    uint32_t slot[HPRT_BIN_ITEMS];
+    float4 hitA[HPRT_BIN_ITEMS];
+    // round k of the block covers the 1024 consecutive queue entries first + k * 1024 ...: all loads of a thread in flight together
+#pragma unroll
+    for (int k = 0; k < HPRT_BIN_ITEMS; ++k) {
+        const uint32_t i = first + k * 1024u + threadIdx.x;
+        slot[k] = i < n ? (queue ? queue[i] : i) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < HPRT_BIN_ITEMS; ++k) {
+        const uint32_t i = first + k * 1024u + threadIdx.x;
+        if (i < n) hitA[k] = hit.a[slot[k]];
+    }
+    unsigned long long mask[HPRT_BIN_ITEMS][3];
+#pragma unroll
+    for (int k = 0; k < HPRT_BIN_ITEMS; ++k) {
+        const uint32_t i = first + k * 1024u + threadIdx.x;
+        bin[k] = -1;
+        if (i < n) {
+            // the hit's primitive word carries the bin (dev_scene.h); every path of this pass is at the same bounce
+            const int32_t word = __float_as_int(hitA[k].y);
+            if (word >= 0) {
+                // triangles reached directly go to the material-specialised variants; quadrics and hits inside
+                // object instances (surface interaction transformed back to world space) to the generic one
+                const bool generic = ((uint32_t)word & HIT_GENERIC) != 0u;
+                if (bounces >= maxDepth) { if (bounces == 0 && generic) bin[k] = 2; }   // only an emitter hit by a camera ray matters
+                else if (generic) bin[k] = 2;
+                else bin[k] = ((uint32_t)word & HIT_PLASTIC) ? 1 : 0;
+            }
+            if (bin[k] < 0) {      // the path ends here
+                if (bounces == 0) Lfinal[slot[k]] = make_float4(0.f, 0.f, 0.f, 1.f);      // fresh path: path id = slot, L = 0 (k_generate)
+                else Lfinal[__float_as_uint(in.beta[slot[k]].w)] = in.L[slot[k]];
+            }
         }
-        if (bin < 0) {      // the path ends here
-            if (bounces == 0) Lfinal[slot] = make_float4(0.f, 0.f, 0.f, 1.f);      // fresh path: path id = slot, L = 0 (k_generate)
-            else Lfinal[__float_as_uint(in.beta[slot].w)] = in.L[slot];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            mask[k][b] = __ballot(bin[k] == b);
+            if (lane == 0) waveCount[b][k * 16 + wave] = (uint32_t)__popcll(mask[k][b]);
         }
     }
-    uint32_t *const ctr[3] = {bins.count + 0, bins.count + 1, bins.count + 2};
-    const bool pred[3] = {bin == 0, bin == 1, bin == 2};
-    uint32_t pos[3];
-    block_append<3>(&al, ctr, pred, pos);
-    if (bin == 0) bins.q[0][pos[0]] = slot;
-    else if (bin == 1) bins.q[1][pos[1]] = slot;
-    else if (bin == 2) bins.q[2][pos[2]] = slot;
+    __syncthreads();
+    // exclusive scan of the 64 (round, wave) counts of each bin by one wave per bin, then one atomic per bin
+    if (wave < 3) {
+        const uint32_t c = waveCount[wave][lane];
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if ((int)lane >= off) incl += t; }
+        waveCount[wave][lane] = incl - c;
+        if (lane == 63) binBase[wave] = incl ? atomicAdd(bins.count + wave * BIN_STRIDE, incl) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < HPRT_BIN_ITEMS; ++k) {
+        if (bin[k] < 0) continue;
+        const int b = bin[k];
+        const unsigned long long m = b == 0 ? mask[k][0] : b == 1 ? mask[k][1] : mask[k][2];
+        const uint32_t pos = binBase[b] + waveCount[b][k * 16 + wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        bins.q[b][pos] = slot[k];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -577,7 +618,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                                                PathStream out, VertexStreams vs, QueueSet q, BinSet bins, float4 *Lfinal, uint32_t firstBounce) {
     __shared__ HaltonLds hl;
     __shared__ BlockAppendLds al;
-    const uint32_t n = bins.count[MODE];
+    const uint32_t n = bins.count[MODE * BIN_STRIDE];
     if (blockIdx.x * blockDim.x >= n) return;      // whole block beyond the bin (grids are sized for the upper bound)
     halton_lds_load(sc, &hl);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -586,8 +627,8 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
     uint32_t j = 0;             // index in the output streams
     if (i < n) {
         slot = bins.q[MODE][i];
-        j = (MODE == 0 ? 0u : MODE == 1 ? bins.count[0] : bins.count[0] + bins.count[1]) + i;
-        if (MODE == 2 && i >= bins.count[3]) j = bins.aux[i];       // deferred by a specialised variant: keeps that variant's index
+        j = (MODE == 0 ? 0u : MODE == 1 ? bins.count[0] : bins.count[0] + bins.count[BIN_STRIDE]) + i;
+        if (MODE == 2 && i >= bins.count[3 * BIN_STRIDE]) j = bins.aux[i];       // deferred by a specialised variant: keeps that variant's index
         const float4 rayA = in.ray.a[slot], rayB = in.ray.b[slot], hitA = hit.a[slot];
         // a fresh path's throughput and radiance are constants (k_generate does not store them)
         const float4 beta4 = firstBounce ? make_float4(1.f, 1.f, 1.f, __uint_as_float(slot)) : in.beta[slot];
@@ -802,7 +843,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
     }
     // queue appends in block-uniform control flow
     if (MODE != 2) {   // (almost) never
-        const uint32_t p2 = wave_append(bins.count + 2, defer);
+        const uint32_t p2 = wave_append(bins.count + 2 * BIN_STRIDE, defer);
         if (defer) { bins.q[2][p2] = slot; bins.aux[p2] = j; }
     }
     uint32_t *const ctr[4] = {q.nextCount, q.shadowCount, q.misCount, q.resolveCount};
@@ -1058,7 +1099,7 @@ void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, 
 void LaunchBin(hipStream_t st, const DevScene &sc, const PathStream &in, const HitStream &hit, const uint32_t *queue,
                const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, int32_t maxDepth, int32_t bounces, const BinSet &bins,
                float4 *Lfinal) {
-    if (gridItems) hipLaunchKernelGGL(k_bin, dim3(blocks_for(gridItems, 1024)), dim3(1024), 0, st, sc, in, hit, queue, countPtr, countImm, maxDepth, bounces, bins, Lfinal);
+    if (gridItems) hipLaunchKernelGGL(k_bin, dim3(blocks_for(gridItems, HPRT_BIN_ITEMS * 1024)), dim3(1024), 0, st, sc, in, hit, queue, countPtr, countImm, maxDepth, bounces, bins, Lfinal);
 }
 void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathStream &in, const HitStream &hit,
                  uint32_t gridItems, uint32_t s0, const PathStream &out, const VertexStreams &vs, const QueueSet &q,
