@@ -73,8 +73,6 @@ def parse_args():
     ap.add_argument("--profile-step", action="store_true",
                     help="profiling runs: ONE plain step of the headline workload and nothing else (no warm-up, counting passes, "
                          "secondary workloads or CPU baseline), so that a rocprofv3 summary of the process is the summary of a step")
-    ap.add_argument("--profile-overlapped", action="store_true", help="with --profile-step: keep the traces on concurrent streams (default: serial, "
-                    "so that a profiler's per-kernel durations are exclusive)")
     ap.add_argument("--dump-film", default="", help="rank 0 saves the merged film of the last headline step (numpy [H,W,4]); tests use it")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and the films are merged through gloo (RCCL refuses two ranks on one device): "
@@ -246,9 +244,9 @@ def main():
 
     if args.profile_step:
         barrier()
-        t0 = time.perf_counter(); st = head.render(args.spp_chunk, serial=not args.profile_overlapped); merge(head); barrier()
+        t0 = time.perf_counter(); st = head.render(args.spp_chunk); merge(head); barrier()
         if rank == 0:
-            print(json.dumps({"profile_step": args.workload, "spp": spp, "ms": round(1e3 * (time.perf_counter() - t0), 2),
+            print(json.dumps({"profile_step": args.workload, "spp": spp, "ms": round(1e3 * (time.perf_counter() - t0), 2), "closest_mrays_s": round(st["extend_rays"] / max(st["extend_seconds"], 1e-9) / 1e6), "any_mrays_s": round(st["occluded_rays"] / max(st["occluded_seconds"], 1e-9) / 1e6),
                               "rays": st["rays"] + st["shadow_rays"]}))
         if dist is not None:
             dist.destroy_process_group()
@@ -262,10 +260,6 @@ def main():
         """rank 0: counting passes (untimed) + the roofline object of k_trace<closest> for workload w"""
         st_c = w.render(count_work=True, count_traced=True)     # V (nodes fetched), T (primitive tests) of the rays the timed steps trace
         st_ref = w.render(count_work=True)                      # the reference's full ray set (what the CPU baseline traces)
-        # The timed steps overlap the independent traces of a bounce on three streams, so their per-kernel event times
-        # overlap too: the kernel's own duration comes from plain steps that keep every kernel on one stream
-        # (HPRT_RENDER_SERIAL), the mode tools/counters_passes.sh profiles.
-        stats = [w.render(args.spp_chunk, serial=True) for _ in range(max(1, len(stats)))]
         torch.cuda.synchronize(dev)
         ref_over_traced = (st_ref["rays"] + st_ref["shadow_rays"]) / max(1, st_c["rays"] + st_c["shadow_rays"])
         ext_rays = sum(s["extend_rays"] for s in stats); ext_sec = sum(s["extend_seconds"] for s in stats)
@@ -276,8 +270,7 @@ def main():
         achieved = ext_rays * bytes_per_ray / max(ext_sec, 1e-12) / 1e9
         avg_ms = 1e3 * ext_sec / max(1, ext_launches)
         roof = {
-            "bound": "hbm", "kernel": "k_trace<closest>", "timed_on": "serial steps (HPRT_RENDER_SERIAL): exclusive HIP-event time of the kernel's launches",
-            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "k_trace<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
             "what_frac_is": "algorithmic bytes (SURVEY §8(d) model) / kernel time / HBM peak; the BVH is served by L2/MALL, so this is not "
                             "an HBM utilisation (see hbm_counter_frac) and the kernel is limited by instruction issue on divergent lanes "

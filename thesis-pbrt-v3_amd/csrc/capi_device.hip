@@ -470,6 +470,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     HIP_TRY(upload(sc->textures, textures)); HIP_TRY(upload(sc->mipLevels, mipLevels)); HIP_TRY(upload(sc->texels, texels)); HIP_TRY(upload(sc->weightLut, weightLut));
     HIP_TRY(sc->counters.alloc(sizeof(DevCounters)));
     HIP_TRY(hipMemset(sc->counters.p, 0, sizeof(DevCounters)));
+    HIP_TRY(sc->deepStack.alloc((size_t)HPRT_DEEP_REGIONS * HPRT_SPILL_STACK * HPRT_DEEP_THREADS * sizeof(uint2)));
     HIP_TRY(sc->workCounter.alloc(1024));      // three queue-head counters, 256 bytes apart
     DevScene &dv = sc->dev;
     dv.pairs = sc->nodes.as<DevPair>(); dv.nPairs = (uint32_t)pairs.size();
@@ -479,11 +480,12 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     dv.shapes = sc->shapes.as<DevShape>(); dv.nShapes = d->n_shapes;
     dv.materials = sc->materials.as<DevMaterial>();
     dv.lights = sc->lights.as<DevLight>(); dv.nLights = d->n_lights;
-    dv.spheres = sc->spheres.as<DevSphere>();
+    dv.spheres = sc->spheres.as<DevSphere>(); dv.nSpheres = (uint32_t)spheres.size();
     dv.textures = d->n_textures ? sc->textures.as<DevTexture>() : nullptr; dv.mipLevels = sc->mipLevels.as<DevMipLevel>();
     dv.texels = sc->texels.as<float>(); dv.weightLut = sc->weightLut.as<float>();
     dv.instances = sc->instances.as<DevInstance>(); dv.nInstances = d->n_instances;
     dv.lightFunc = sc->lightFunc.as<float>(); dv.lightCdf = sc->lightCdf.as<float>(); dv.lightFuncInt = funcInt;
+    dv.deepStack = sc->deepStack.as<uint2>();
     dv.perms = sc->perms.as<uint16_t>(); dv.primes = sc->primes.as<int32_t>(); dv.primeSums = sc->primeSums.as<int32_t>();
     dv.primeMagic = sc->primeMagic.as<uint64_t>();
     // Scene::worldBound + Bounds3::BoundingSphere (core/scene.h:56-66, core/geometry.h:980-983)
@@ -700,10 +702,13 @@ struct BatchTimers { double extendMs = 0, occludedMs = 0; uint64_t extendLaunche
 //
 // Per bounce b:   trace(path b) -> bin -> shade x3 -> [counts to the host] -> trace(shadow b) | trace(MIS b) | trace(path b+1)
 //                 -> resolve(b) -> bin(b+1) ...
-// The three traces that follow a shading pass depend on nothing but that pass, so with `overlap` they run on three
-// streams: every persistent trace kernel ends with a tail of half-empty waves, and the other two fill it.  Radiance is
-// still added in the reference's order (resolve(b) before anything of bounce b+1 reads L).  Counting renders and
-// HPRT_RENDER_SERIAL keep everything on the caller's stream, where the HIP-event times of the kernels are exclusive.
+// The three traces that follow a shading pass depend on nothing but that pass.  With `overlap` (HPRT_RENDER_OVERLAP_TRACES,
+// opt-in) they run on three streams, the idea being that each fills the tails of the others' persistent kernels.  Measured
+// on MI355X (round 2): SLOWER — atrium 1024 spp 1064 -> 1119 ms, living room 455 -> 478 ms, killeroo-simple 90.6 -> 91.8 ms:
+// every persistent kernel is sized to fill the machine, so the second and third only get wave slots as the first one's
+// blocks drain, i.e. at its end, and the cross-stream waits add bubbles.  The default therefore keeps every kernel on the
+// caller's stream (where HIP-event times are exclusive); radiance is added in the reference's order either way
+// (resolve(b) before anything of bounce b+1 reads L).
 int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspace &w, const QueueSet &qa, const QueueSet &qb,
              const BinSet &bins, uint32_t s0, uint32_t nSlots, bool count, bool overlap, EventTimer &ev, BatchTimers *bt, HprtRenderStats *stats,
              uint32_t *pixelStats = nullptr) {
@@ -751,7 +756,7 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
             hipEvent_t a = ev.get(), b = ev.get();
             HIP_TRY(hipEventRecord(a, stShadow));
             HitStream none; none.a = nullptr; none.b = nullptr;
-            LaunchTrace(stShadow, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, w.vs.shadow, none, w.vs.occluded, ctr, wcShadow, rayStats);
+            LaunchTrace(stShadow, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, w.vs.shadow, none, w.vs.occluded, ctr, wcShadow, rayStats, overlap ? 1u : 0u);
             if (pixelStats) LaunchPixelStats(stShadow, rayStats, w.vs.pendBeta, cur.shadow, nullptr, nShadow, nShadow, rp.nPix, true, pixelStats);
             HIP_TRY(hipEventRecord(b, stShadow));
             evOcc.push_back({a, b}); bt->occludedRays += nShadow; ++bt->occludedLaunches;
@@ -761,7 +766,7 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         if (nMis) {
             hipEvent_t a = ev.get(), b = ev.get();
             HIP_TRY(hipEventRecord(a, stMis));
-            LaunchTrace(stMis, s->dev, false, count, cur.mis, nullptr, nMis, nMis, w.vs.mis, w.vs.misHit, nullptr, ctr, wcMis, rayStats);
+            LaunchTrace(stMis, s->dev, false, count, cur.mis, nullptr, nMis, nMis, w.vs.mis, w.vs.misHit, nullptr, ctr, wcMis, rayStats, overlap ? 2u : 0u);
             if (pixelStats) LaunchPixelStats(stMis, rayStats, w.vs.pendBeta, cur.mis, nullptr, nMis, nMis, rp.nPix, false, pixelStats);
             HIP_TRY(hipEventRecord(b, stMis));
             evExt.push_back({a, b}); bt->extendRays += nMis; ++bt->extendLaunches;
@@ -876,8 +881,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     rp.invSqrtSpp = 1 / std::sqrt((float)spp);      // ScaleDifferentials' factor, core/integrator.cpp:288-289
     const bool wantPixelStats = (desc->flags & HPRT_RENDER_PIXEL_STATS) != 0;
     const bool count = (desc->flags & HPRT_RENDER_COUNT_WORK) != 0 || wantPixelStats;
-    static const bool serialEnv = getenv("HPRT_SERIAL") != nullptr;
-    const bool overlap = !count && !(desc->flags & HPRT_RENDER_SERIAL) && !serialEnv;
+    const bool overlap = !count && (desc->flags & HPRT_RENDER_OVERLAP_TRACES) != 0;
     // a counting render traces exactly the reference's rays (its counters are the reference's) unless asked to count what a plain render traces
     rp.cullMis = (!count || (desc->flags & HPRT_RENDER_COUNT_TRACED) != 0) && !(desc->flags & HPRT_RENDER_TRACE_ALL) ? 1 : 0;
     uint32_t *pixelStats = nullptr;

@@ -77,10 +77,11 @@ struct DevScene {
     const DevMaterial *materials;
     const DevLight *lights; uint32_t nLights;
     const DevTexture *textures; const DevMipLevel *mipLevels; const float *texels; const float *weightLut;   // image textures; weightLut: MIPMap::weightLut[128]
-    const DevSphere *spheres;
+    const DevSphere *spheres; uint32_t nSpheres;
     const DevInstance *instances; uint32_t nInstances;
     const float *lightFunc, *lightCdf; float lightFuncInt;      // Distribution1D (core/sampling.h:55-109)
     float worldRadius;                                           // DistantLight::Preprocess
+    uint2 *deepStack;                                            // traversal stack entries beyond the LDS ones: [region][entry][grid thread]
     // Halton tables
     const uint16_t *perms; const int32_t *primes; const int32_t *primeSums; const uint64_t *primeMagic;
 };

@@ -28,6 +28,8 @@
 namespace hprt {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------
 // wave-level queue append: returns the position for lanes with pred, one atomic per wave
@@ -131,10 +133,10 @@ static TraceTune DefaultTraceTune(bool anyHit) {
     return t;
 }
 
-// Bounds3::IntersectP(ray, invDir, dirIsNeg) (core/geometry.h:1754-1780) split into its
-// tMax-independent part (returned) and the entry distance for the `tMin < ray.tMax` part.
-// Branch-free: the reference's early returns only skip work, they do not change the values
-// that the later comparisons see.
+// Bounds3::IntersectP(ray, invDir, dirIsNeg) (core/geometry.h:1754-1780) split into its tMax-independent part (returned)
+// and the entry distance for the `tMin < ray.tMax` part.  Branch-free: the reference's early returns only skip work,
+// they do not change the values that the later comparisons see.  (One child at a time: the form the kernels with the
+// quadric code use — the packed form below needs registers that their 128 do not have.)
 __device__ __forceinline__ bool slab_test(float lox, float hix, float loy, float hiy, float loz, float hiz, vec3 ro, vec3 invDir,
                                           bool negX, bool negY, bool negZ, float robust, float *tEntry) {
     float tMin = ((negX ? hix : lox) - ro.x) * invDir.x;
@@ -155,6 +157,37 @@ __device__ __forceinline__ bool slab_test(float lox, float hix, float loy, float
     return ok && (tMax > 0);
 }
 
+// Bounds3::IntersectP(ray, invDir, dirIsNeg) (core/geometry.h:1754-1780) for BOTH children of a pair at once, split into
+// its tMax-independent part (returned per child) and the entry distances for the `tMin < ray.tMax` part.  n* hold the
+// bounds the reference selects with dirIsNeg for tMin (pMin, or pMax where the ray runs backwards), f* those for tMax,
+// as {child 0, child 1}: the arithmetic runs as packed two-float operations (v_pk_add_f32 / v_pk_mul_f32: one IEEE
+// rounding per component and operation, no fusing), the comparisons and selects per child.  Branch-free: the
+// reference's early returns only skip work, they do not change the values that the later comparisons see.
+__device__ __forceinline__ void slab_test_pair(f32x2 nx, f32x2 fx, f32x2 ny, f32x2 fy, f32x2 nz, f32x2 fz, float rox, float roy, float roz,
+                                               float ivx, float ivy, float ivz, float robust, bool *s0, bool *s1, float *t0, float *t1) {
+    // (scalars, not vec3: hipcc otherwise builds the {y, z} operand pair through a scratch store and reload of the struct)
+    f32x2 tMin = (nx - rox) * ivx;
+    f32x2 tMax = (fx - rox) * ivx;
+    const f32x2 tyMin = (ny - roy) * ivy;
+    f32x2 tyMax = (fy - roy) * ivy;
+    tMax = tMax * robust; tyMax = tyMax * robust;
+    const f32x2 tzMin = (nz - roz) * ivz;
+    f32x2 tzMax = (fz - roz) * ivz;
+    tzMax = tzMax * robust;
+    bool ok0 = !(tMin.x > tyMax.x || tyMin.x > tMax.x), ok1 = !(tMin.y > tyMax.y || tyMin.y > tMax.y);
+    if (tyMin.x > tMin.x) tMin.x = tyMin.x;
+    if (tyMin.y > tMin.y) tMin.y = tyMin.y;
+    if (tyMax.x < tMax.x) tMax.x = tyMax.x;
+    if (tyMax.y < tMax.y) tMax.y = tyMax.y;
+    ok0 = ok0 && !(tMin.x > tzMax.x || tzMin.x > tMax.x); ok1 = ok1 && !(tMin.y > tzMax.y || tzMin.y > tMax.y);
+    if (tzMin.x > tMin.x) tMin.x = tzMin.x;
+    if (tzMin.y > tMin.y) tMin.y = tzMin.y;
+    if (tzMax.x < tMax.x) tMax.x = tzMax.x;
+    if (tzMax.y < tMax.y) tMax.y = tzMax.y;
+    *t0 = tMin.x; *t1 = tMin.y;
+    *s0 = ok0 && (tMax.x > 0); *s1 = ok1 && (tMax.y > 0);
+}
+
 // Diagnostics (HPRT_TRACE_PROFILE=1, tools/trace_profile.py): per-phase cycles and lane occupancy,
 // summed over all waves.  [0] total [1] refill [2] pair phase [3] primitive phase [4] quadric
 // batches [5] pair iterations [6] pair lanes [7] primitive iterations [8] primitive lanes
@@ -163,11 +196,13 @@ __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31
 
 // MODE 0: plain; 1: work counters (HprtRenderStats); 2: phase profile (diagnostics only).
 // INST: the scene has object instances (two-level walk); without them that code and its registers are compiled out.
-template <bool ANY_HIT, int MODE, bool INST>
+// QUAD: the scene has quadrics (spheres).  Their interval-arithmetic test is a call of 99 VGPRs that every value the walk
+// keeps must sit above; triangle-only scenes (the Sponza-class and living-room workloads) get the kernel without it.
+template <bool ANY_HIT, int MODE, bool INST, bool QUAD>
 __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ,
                                                             DevCounters *counters, uint4 *rayStats, uint32_t *workCounter, uint32_t chunk,
-                                                            TraceTune tune) {
+                                                            TraceTune tune, uint32_t deepRegion) {
     constexpr bool COUNT = MODE == 1, PROF = MODE == 2;
     // An any-hit ray's answer does not depend on the order of the walk (its tMax never shrinks, every primitive test is
     // independent of the others), so the plain any-hit kernel visits children in storage order and skips the re-test of
@@ -202,7 +237,10 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
     vec3 ro, invDir;
     float rayTMax = 0.f;
     RayShear shear; shear.k0 = shear.k1 = false; shear.Sx = shear.Sy = shear.Sz = 0.f;
-    bool negX = false, negY = false, negZ = false;
+    // dirIsNeg of the reference (accelerators/bvh.cpp:358), as lane masks for the bound selects and as bits (bit a = invDir[a] < 0)
+    // for the near-child decision by split axis
+    bool ngX = false, ngY = false, ngZ = false;
+    uint32_t negMask = 0u;
     int sp = 0, cur = REF_NONE;
     int32_t prim = -1; float hb0 = 0.f, hb1 = 0.f, hb2 = 0.f;
     // A parked quadric waits for the batched slow phase (wait = 1; waitInfo = sphere index | bit 31 "last primitive
@@ -213,7 +251,14 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
     bool instHit = false;                 // a hit was recorded inside the instance being walked
     uint32_t instPrim = 0u;               // top-level ordered index of that instance's primitive | bit 31 "last of its leaf"
     float savedTMax = 0.f;                // world tMax at the moment the instance was entered
-    volatile uint32_t spillRef[HPRT_SPILL_STACK], spillT[HPRT_SPILL_STACK];   // volatile: keeps the rare scratch path out of the LDS one
+    // Stack entries beyond the LDS ones live in a per-scene HBM area, [entry][thread of the grid] (rare: no ray of the measured
+    // scenes, BVH depth up to 26, ever had more than 16 pending siblings).  (Private arrays for them made hipcc address scratch
+    // through flat pointers, and its gfx950 back end rejects the null checks of those casts in some instantiations.)
+    // (volatile: keeps hipcc from folding the LDS and the HBM access into one access through a generic pointer)
+    // (the address is formed where it is used: the pointer would otherwise hold two registers for the whole walk)
+    auto deepSlot = [&](int entry) -> volatile unsigned long long * {
+        return (volatile unsigned long long *)sc.deepStack + ((size_t)deepRegion * HPRT_SPILL_STACK + (size_t)(entry - HPRT_LDS_STACK)) * HPRT_DEEP_THREADS + (blockIdx.x * HPRT_TRACE_BLOCK + threadIdx.x);
+    };
     bool moreWork = n > 0 && sc.nPairs > 0;
 
     // nodesToVisit[--toVisitOffset] + the tMax-dependent part of the bounds test (see above)
@@ -221,7 +266,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
         while (sp > 0) {
             --sp;
             uint2 e;
-            if (sp < HPRT_LDS_STACK) e = ldsStack[sp * HPRT_TRACE_BLOCK]; else e = make_uint2(spillRef[sp - HPRT_LDS_STACK], spillT[sp - HPRT_LDS_STACK]);
+            if (sp < HPRT_LDS_STACK) e = ldsStack[sp * HPRT_TRACE_BLOCK]; else { const unsigned long long w = *deepSlot(sp); e = make_uint2((uint32_t)w, (uint32_t)(w >> 32)); }
             if (INST && (int)e.x == REF_EXIT) { savedTMax = __uint_as_float(e.y); return REF_EXIT; }     // the instance's walk is over
             if (COUNT) ++cnt.fetched;
             // (an any-hit ray's tMax never shrinks: what was pushed with tMin < tMax still passes)
@@ -279,7 +324,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                         const vec3 rd(rb.x, rb.y, rb.z);
                         rayTMax = ra.w;
                         invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
-                        negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
+                                                ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
+                        if (!QUAD) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
                         shear = ray_shear(rd);
                         sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
                         wait = 0u; inst = -1; hitInst = -1; instHit = false;
@@ -307,20 +353,36 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                 if (__ballot(trav) == 0ull) break;
                 if (PROF) { pf[5] += 1; pf[6] += __popcll(__ballot(trav)); }
                 if (trav) {
-                    const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(pairRsrc, cur * 64, 0, 0);        // x: {lo0, lo1, hi0, hi1}
-                    const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(pairRsrc, cur * 64 + 16, 0, 0);   // y
-                    const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(pairRsrc, cur * 64 + 32, 0, 0);   // z
-                    const u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(pairRsrc, cur * 64 + 48, 0, 0);   // {ref0, ref1, meta, -}
+                    // One pair = four 16-byte words: the x, y and z planes {lo0, lo1, hi0, hi1} and {ref0, ref1, meta, -}: four requests,
+                    // issued together.  (Fetching the bounds in near/far order with six 8-byte requests at sign-dependent offsets
+                    // saves the twelve selects below and was measured 15-20 % SLOWER: the step is bound by the texture-address /
+                    // L1 pipeline as much as by the VALU, and that pipeline works per request, not per byte.)
+                    const uint32_t base = (uint32_t)cur * 64u;
+                    const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(pairRsrc, base, 0, 0);
+                    const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(pairRsrc, base + 16u, 0, 0);
+                    const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(pairRsrc, base + 32u, 0, 0);
+                    const u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(pairRsrc, base + 48u, 0, 0);
+                    // dirIsNeg picks, per axis, the bounds that give tMin ("near") and tMax ("far"), as {child 0, child 1}
                     float t0, t1;
-                    const bool s0 = slab_test(__uint_as_float(q0.x), __uint_as_float(q0.z), __uint_as_float(q1.x), __uint_as_float(q1.z),
-                                              __uint_as_float(q2.x), __uint_as_float(q2.z), ro, invDir, negX, negY, negZ, robust, &t0);
-                    const bool s1 = slab_test(__uint_as_float(q0.y), __uint_as_float(q0.w), __uint_as_float(q1.y), __uint_as_float(q1.w),
-                                              __uint_as_float(q2.y), __uint_as_float(q2.w), ro, invDir, negX, negY, negZ, robust, &t1);
+                    bool s0, s1;
+                    if (QUAD) {
+                        s0 = slab_test(__uint_as_float(q0.x), __uint_as_float(q0.z), __uint_as_float(q1.x), __uint_as_float(q1.z),
+                                       __uint_as_float(q2.x), __uint_as_float(q2.z), ro, invDir, ngX, ngY, ngZ, robust, &t0);
+                        s1 = slab_test(__uint_as_float(q0.y), __uint_as_float(q0.w), __uint_as_float(q1.y), __uint_as_float(q1.w),
+                                       __uint_as_float(q2.y), __uint_as_float(q2.w), ro, invDir, ngX, ngY, ngZ, robust, &t1);
+                    } else {
+                        u32x2 rnx, rfx, rny, rfy, rnz, rfz;
+                        rnx.x = ngX ? q0.z : q0.x; rnx.y = ngX ? q0.w : q0.y; rfx.x = ngX ? q0.x : q0.z; rfx.y = ngX ? q0.y : q0.w;
+                        rny.x = ngY ? q1.z : q1.x; rny.y = ngY ? q1.w : q1.y; rfy.x = ngY ? q1.x : q1.z; rfy.y = ngY ? q1.y : q1.w;
+                        rnz.x = ngZ ? q2.z : q2.x; rnz.y = ngZ ? q2.w : q2.y; rfz.x = ngZ ? q2.x : q2.z; rfz.y = ngZ ? q2.y : q2.w;
+                        slab_test_pair(__builtin_bit_cast(f32x2, rnx), __builtin_bit_cast(f32x2, rfx), __builtin_bit_cast(f32x2, rny), __builtin_bit_cast(f32x2, rfy),
+                                       __builtin_bit_cast(f32x2, rnz), __builtin_bit_cast(f32x2, rfz), ro.x, ro.y, ro.z, invDir.x, invDir.y, invDir.z, robust, &s0, &s1, &t0, &t1);
+                    }
                     const uint32_t meta = q3.z;
                     const uint32_t axis = meta & 3u;
                     const bool single = (meta & PAIR_SINGLE) != 0u;
                     // second child first when the ray is negative along the split axis (bvh.cpp:381-388)
-                    const bool isNeg = FREE_ORDER ? false : (axis == 0 ? negX : (axis == 1 ? negY : negZ));
+                    const bool isNeg = FREE_ORDER ? false : QUAD ? (axis == 0 ? ngX : (axis == 1 ? ngY : ngZ)) : ((negMask >> axis) & 1u) != 0u;
                     const int refN = (int)(isNeg ? q3.y : q3.x), refF = (int)(isNeg ? q3.x : q3.y);
                     const float tN = isNeg ? t1 : t0, tF = isNeg ? t0 : t1;
                     const bool hitN = (isNeg ? s1 : s0) && tN < rayTMax;
@@ -332,7 +394,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                             const uint2 e = make_uint2((uint32_t)refF, __float_as_uint(slabF ? tF : HPRT_INF));
                             if (PROF) { ++pfPush; if (sp >= HPRT_LDS_STACK) ++pfSpill; }
                             if (sp < HPRT_LDS_STACK) { ldsStack[sp * HPRT_TRACE_BLOCK] = e; ++sp; }
-                            else if (sp < HPRT_LDS_STACK + HPRT_SPILL_STACK) { spillRef[sp - HPRT_LDS_STACK] = e.x; spillT[sp - HPRT_LDS_STACK] = e.y; ++sp; }
+                            else if (sp < HPRT_LDS_STACK + HPRT_SPILL_STACK) { *deepSlot(sp) = (unsigned long long)e.x | ((unsigned long long)e.y << 32); ++sp; }
                         }
                     } else {
                         const bool hitF = slabF && tF < rayTMax;
@@ -364,7 +426,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                         ro = vec3(worldRay[0], worldRay[HPRT_TRACE_BLOCK], worldRay[2 * HPRT_TRACE_BLOCK]);
                         const vec3 rd(worldRay[3 * HPRT_TRACE_BLOCK], worldRay[4 * HPRT_TRACE_BLOCK], worldRay[5 * HPRT_TRACE_BLOCK]);
                         invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
-                        negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
+                                                ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
+                        if (!QUAD) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
                         shear = ray_shear(rd);
                         rayTMax = worldT;
                         inst = -1; instHit = false;
@@ -413,14 +476,15 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                             }
                             const uint2 e = make_uint2((uint32_t)REF_EXIT, __float_as_uint(rayTMax));
                             if (sp < HPRT_LDS_STACK) ldsStack[sp * HPRT_TRACE_BLOCK] = e;
-                            else if (sp < HPRT_LDS_STACK + HPRT_SPILL_STACK) { spillRef[sp - HPRT_LDS_STACK] = e.x; spillT[sp - HPRT_LDS_STACK] = e.y; }
+                            else if (sp < HPRT_LDS_STACK + HPRT_SPILL_STACK) *deepSlot(sp) = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
                             ++sp;       // a full stack cannot take the sentinel: such depths are outside what the reference supports either (64 entries)
                             ro = o2; rayTMax = tm;
                             invDir = vec3(1 / d2.x, 1 / d2.y, 1 / d2.z);
-                            negX = invDir.x < 0; negY = invDir.y < 0; negZ = invDir.z < 0;
+                                                    ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
+                        if (!QUAD) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
                             shear = ray_shear(d2);
                             cur = in.root;
-                        } else {
+                        } else if (QUAD) {
                             // a quadric: the cheap exact pre-test (dev_intersect.h) settles most of them here; the rest wait for
                             // the batched interval-arithmetic test
                             bool maybe = true;
@@ -437,6 +501,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                     }
                     continue;
                 }
+                if (!QUAD) break;
                 const bool slow = active && wait != 0u;
                 const int nWait = __popcll(__ballot(slow));
                 if (nWait == 0) break;
@@ -1057,11 +1122,11 @@ static inline uint32_t blocks_for(size_t n, uint32_t bs) { return (uint32_t)((n 
 
 void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
                  uint32_t countImm, uint32_t gridItems, const RayStream &rays, const HitStream &hits, uint8_t *occ,
-                 DevCounters *counters, uint32_t *workCounter, uint4 *rayStats) {
+                 DevCounters *counters, uint32_t *workCounter, uint4 *rayStats, uint32_t deepRegion) {
     if (gridItems == 0) return;
     (void)hipMemsetAsync(workCounter, 0, sizeof(uint32_t), st);
     // persistent waves: enough blocks to fill 256 CUs at this kernel's occupancy, never more than the rays need
-    const uint32_t maxBlocks = 256u * 5u * (256u / HPRT_TRACE_BLOCK);
+    const uint32_t maxBlocks = HPRT_DEEP_THREADS / HPRT_TRACE_BLOCK;      // 256 CUs x 5 workgroups of 256 threads
     dim3 grid(std::min(blocks_for(gridItems, HPRT_TRACE_BLOCK), maxBlocks)), block(HPRT_TRACE_BLOCK);
     // rays per queue-head atomic: large launches take 512 at a time, small ones keep every wave busy
     const uint32_t nWaves = grid.x * (HPRT_TRACE_BLOCK / 64);
@@ -1076,9 +1141,11 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     static const bool tuneFromEnv = getenv("HPRT_TRACE_TUNE") != nullptr;
     if (!anyHit && !tuneFromEnv && sc.nPairs > 100000u) tune.stepLimit = 10;
     static const bool profile = getenv("HPRT_TRACE_PROFILE") != nullptr;
-    const bool inst = sc.nInstances != 0u;
-#define HPRT_TRACE_LAUNCH(A, M, I) hipLaunchKernelGGL((k_trace<A, M, I>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, rayStats, workCounter, chunk, tune)
-#define HPRT_TRACE_PICK(A, M) do { if (inst) HPRT_TRACE_LAUNCH(A, M, true); else HPRT_TRACE_LAUNCH(A, M, false); } while (0)
+    const bool inst = sc.nInstances != 0u, quad = sc.nSpheres != 0u;
+#define HPRT_TRACE_LAUNCH(A, M, I, Q) hipLaunchKernelGGL((k_trace<A, M, I, Q>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, rayStats, workCounter, chunk, tune, deepRegion)
+    // (the profiling variant exists with the quadric code only)
+#define HPRT_TRACE_PICK(A, M) do { if (inst) { if (quad || M == 2) HPRT_TRACE_LAUNCH(A, M, true, true); else HPRT_TRACE_LAUNCH(A, M, true, (M == 2)); } \
+                                   else { if (quad || M == 2) HPRT_TRACE_LAUNCH(A, M, false, true); else HPRT_TRACE_LAUNCH(A, M, false, (M == 2)); } } while (0)
     if (anyHit) {
         if (count) HPRT_TRACE_PICK(true, 1); else if (profile) HPRT_TRACE_PICK(true, 2); else HPRT_TRACE_PICK(true, 0);
     } else {
