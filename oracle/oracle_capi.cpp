@@ -270,6 +270,21 @@ int orc_selftest_reintersect(int nTriangles, int nRaysPerTriangle, int *nTested)
 int orc_selftest_radical_inverse() { return SelfTestRadicalInverse(); }
 int orc_selftest_sphere_pretest(int nRays, int *nFull, int *nMaybe) { return SelfTestSpherePretest(nRays, nFull, nMaybe); }
 int orc_selftest_scrambled_radical_inverse() { return SelfTestScrambledRadicalInverse(); }
+int orc_selftest_sphere_reintersect(int nSpheres, int nRays, int *nTested) { return SelfTestSphereReintersect(nSpheres, nRays, nTested); }
+int orc_selftest_next_float() { return SelfTestNextFloat(); }
+int orc_selftest_efloat(int iters) { return SelfTestEFloat(iters); }
+int orc_selftest_distribution1d() { return SelfTestDistribution1D(); }
+// inputs of the reference's property tests for the batched device queries (tests/test_gpu_reference_unit_tests.py)
+void orc_watertight_case(int nIter, float *P, int *idx, float *o, float *d, float *tBrute) { WatertightCase(nIter, P, idx, o, d, tBrute); }
+// params: radius, zMin, zMax, thetaMin, thetaMax, phiMax (as Sphere holds them); first: o, d, tMax; returns 1 if the first ray hits
+int orc_sphere_reintersect_case(int seed, int partial, int nRays, float *params, float *first, float *tFirst, float *rays, int *failures) {
+    Sphere s; Ray r; Float t = 0; int f = 0;
+    const bool hit = SphereReintersectCase(seed, partial != 0, nRays, &s, &r, &t, rays, &f);
+    params[0] = s.radius; params[1] = s.zMin; params[2] = s.zMax; params[3] = s.thetaMin; params[4] = s.thetaMax; params[5] = s.phiMax;
+    first[0] = r.o.x; first[1] = r.o.y; first[2] = r.o.z; first[3] = r.d.x; first[4] = r.d.y; first[5] = r.d.z; first[6] = r.tMax;
+    *tFirst = t; *failures = f;
+    return hit ? 1 : 0;
+}
 
 // detmath probes
 float orc_det_sinf(float x) { return (float)det::sin_d((double)x); }

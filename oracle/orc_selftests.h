@@ -10,10 +10,11 @@
 
 namespace orc {
 
-inline int SelfTestWatertight(int nRays) {
+// The jittered-sphere mesh of Triangle.Watertight (src/tests/shapes.cpp:28-92): 16 x 16 vertices, 420 triangles
+inline void MakeWatertightMesh(Mesh &mesh) {
     RNG rng(12111);
     const int nTheta = 16, nPhi = 16;
-    Mesh mesh; mesh.hasN = mesh.hasUV = mesh.hasS = false;
+    mesh.hasN = mesh.hasUV = mesh.hasS = false;
     std::vector<V3> &vertices = mesh.p;
     for (int t = 0; t < nTheta; ++t) {
         Float theta = Pi * (Float)t / (Float)(nTheta - 1);
@@ -40,6 +41,22 @@ inline int SelfTestWatertight(int nRays) {
         }
     for (int p = 0; p < nPhi - 1; ++p) { indices.push_back(offset(nTheta - 1, 0)); indices.push_back(offset(nTheta - 2, p)); indices.push_back(offset(nTheta - 2, p + 1)); }
     mesh.nTris = (uint32_t)(indices.size() / 3); mesh.nVerts = (uint32_t)vertices.size();
+}
+// The two rays of iteration i of that test (:94-128): from a random point within radius 0.5 in a random direction, then
+// straight at a random vertex
+inline void WatertightRays(const Mesh &mesh, int i, Ray *a, Ray *b) {
+    RNG rr(i);
+    P2 u; u.x = rr.UniformFloat(); u.y = rr.UniformFloat();
+    V3 p = V3(0, 0, 0) + Float(0.5) * UniformSampleSphere(u);
+    u.x = rr.UniformFloat(); u.y = rr.UniformFloat();
+    *a = Ray(p, UniformSampleSphere(u));
+    V3 pVertex = mesh.p[rr.UniformUInt32((uint32_t)mesh.p.size())];
+    *b = Ray(p, pVertex - p);
+}
+
+inline int SelfTestWatertight(int nRays) {
+    Mesh mesh;
+    MakeWatertightMesh(mesh);
     int failures = 0;
     Counters ctr;
     auto countHits = [&](const Ray &r) {
@@ -53,17 +70,39 @@ inline int SelfTestWatertight(int nRays) {
         return nHits;
     };
     for (int i = 0; i < nRays; ++i) {
-        RNG rr(i);
-        P2 u; u.x = rr.UniformFloat(); u.y = rr.UniformFloat();
-        V3 p = V3(0, 0, 0) + Float(0.5) * UniformSampleSphere(u);
-        u.x = rr.UniformFloat(); u.y = rr.UniformFloat();
-        Ray r(p, UniformSampleSphere(u));
-        if (countHits(r) < 1) ++failures;
-        V3 pVertex = vertices[rr.UniformUInt32((uint32_t)vertices.size())];
-        r.d = pVertex - r.o;
-        if (countHits(r) < 1) ++failures;
+        Ray a, b;
+        WatertightRays(mesh, i, &a, &b);
+        if (countHits(a) < 1) ++failures;
+        if (countHits(b) < 1) ++failures;
     }
     return failures;
+}
+// The same rays for a batched closest-hit query (the GPU test sends them through hprt_intersect): rays 2i and 2i + 1 of
+// iteration i, and the closest hit distance over all triangles by brute force (tMax shrinking as hits are accepted: the
+// minimum whatever the order), -1 where nothing is hit.
+inline void WatertightCase(int nIter, float *P, int *idx, float *o, float *d, float *tBrute) {
+    Mesh mesh;
+    MakeWatertightMesh(mesh);
+    if (P) for (size_t i = 0; i < mesh.p.size(); ++i) { P[3 * i] = mesh.p[i].x; P[3 * i + 1] = mesh.p[i].y; P[3 * i + 2] = mesh.p[i].z; }
+    if (idx) for (size_t i = 0; i < mesh.idx.size(); ++i) idx[i] = mesh.idx[i];
+    Counters ctr;
+    for (int i = 0; i < nIter; ++i) {
+        Ray r[2];
+        WatertightRays(mesh, i, &r[0], &r[1]);
+        for (int k = 0; k < 2; ++k) {
+            const size_t j = 2 * (size_t)i + k;
+            o[3 * j] = r[k].o.x; o[3 * j + 1] = r[k].o.y; o[3 * j + 2] = r[k].o.z;
+            d[3 * j] = r[k].d.x; d[3 * j + 1] = r[k].d.y; d[3 * j + 2] = r[k].d.z;
+            Ray rr(r[k].o, r[k].d, Infinity);
+            bool any = false;
+            for (uint32_t t = 0; t < mesh.nTris; ++t) {
+                TriRef tr{&mesh, &mesh.idx[3 * t], false};
+                Float tHit; SurfaceInteraction isect;
+                if (TriangleIntersect(tr, rr, &tHit, &isect, ctr)) { rr.tMax = tHit; any = true; }
+            }
+            tBrute[j] = any ? rr.tMax : -1.f;
+        }
+    }
 }
 
 inline Float pExp(RNG &rng, Float e = 8.) { Float logu = Lerp(rng.UniformFloat(), -e, e); return std::pow((Float)10, logu); }
@@ -196,6 +235,176 @@ inline int SelfTestSpherePretest(int nRays, int *nFull, int *nMaybe) {
     }
     *nFull = full; *nMaybe = maybe;
     return violations;
+}
+
+// ---- FullSphere.Reintersect / PartialSphere.Reintersect (src/tests/shapes.cpp:374-425, 427-441, 481-500) ----
+// One case = one random sphere, one ray that hits it, and 2 * nRays rays leaving the hit point on the outer side (SpawnRay
+// in a random direction of the normal's hemisphere, SpawnRayTo a random point of that hemisphere): none may hit the sphere
+// again, neither in IntersectP nor in Intersect.  rays (may be null): 7 floats per ray {o, d, tMax}.  Returns false when the
+// first ray misses (the reference test then skips the case).
+inline bool SphereReintersectCase(int seed, bool partial, int nRays, Sphere *sphere, Ray *first, Float *tFirst, float *rays, int *failures) {
+    RNG rng(seed);
+    const Float radius = pExp(rng, 4);
+    Float zMin = -radius, zMax = radius, phiMaxDeg = 360;
+    if (partial) {
+        zMin = rng.UniformFloat() < 0.5 ? -radius : Lerp(rng.UniformFloat(), -radius, radius);
+        zMax = rng.UniformFloat() < 0.5 ? radius : Lerp(rng.UniformFloat(), -radius, radius);
+        phiMaxDeg = rng.UniformFloat() < 0.5 ? 360. : rng.UniformFloat() * 360.;
+    }
+    Sphere s;      // Sphere::Sphere, shapes/sphere.h:50-59
+    Xf id = XfTranslate(V3(0, 0, 0));
+    s.o2w = id.m; s.w2o = id.mInv;
+    s.radius = radius;
+    s.zMin = Clamp(smin(zMin, zMax), -radius, radius);
+    s.zMax = Clamp(smax(zMin, zMax), -radius, radius);
+    s.thetaMin = std::acos(Clamp(smin(zMin, zMax) / radius, -1, 1));
+    s.thetaMax = std::acos(Clamp(smax(zMin, zMax) / radius, -1, 1));
+    s.phiMax = Radians(Clamp(phiMaxDeg, 0, 360));
+    *sphere = s;
+    // TestReintersectConvex
+    V3 o; for (int c = 0; c < 3; ++c) o[c] = pExp(rng);
+    const V3 bmin(-radius, -radius, s.zMin), bmax(radius, radius, s.zMax);      // Sphere::ObjectBound under the identity
+    V3 t; for (int c = 0; c < 3; ++c) t[c] = rng.UniformFloat();
+    V3 p2(Lerp(t.x, bmin.x, bmax.x), Lerp(t.y, bmin.y, bmax.y), Lerp(t.z, bmin.z, bmax.z));
+    Ray r(o, p2 - o);
+    if (rng.UniformFloat() < .5) r.d = Normalize(r.d);
+    *first = r;
+    Counters ctr;
+    SurfaceInteraction isect; Float tHit;
+    if (!SphereIntersect(s, false, r, &tHit, &isect, ctr)) return false;
+    *tFirst = tHit;
+    int fails = 0;
+    auto emit = [&](int j, const Ray &q) {
+        if (rays) { float *w = rays + 7 * (size_t)j; w[0] = q.o.x; w[1] = q.o.y; w[2] = q.o.z; w[3] = q.d.x; w[4] = q.d.y; w[5] = q.d.z; w[6] = q.tMax; }
+        if (SphereIntersectP(s, q, ctr)) ++fails;
+        Ray q2(q.o, q.d, q.tMax);
+        SurfaceInteraction s2; Float t2;
+        if (SphereIntersect(s, false, q2, &t2, &s2, ctr)) ++fails;
+    };
+    for (int j = 0; j < nRays; ++j) {
+        P2 u; u.x = rng.UniformFloat(); u.y = rng.UniformFloat();
+        V3 w = UniformSampleSphere(u);
+        w = Faceforward(w, isect.n);
+        emit(2 * j, SpawnRay(isect.p, isect.pError, isect.n, w));
+        V3 q; for (int c = 0; c < 3; ++c) q[c] = pExp(rng);
+        w = q - isect.p;
+        w = Faceforward(w, isect.n);
+        q = isect.p + w;
+        // Interaction::SpawnRayTo(const Point3f &), core/interaction.h:68-72
+        emit(2 * j + 1, Ray(OffsetRayOrigin(isect.p, isect.pError, isect.n, q - isect.p), q - isect.p, 1 - ShadowEpsilon));
+    }
+    *failures = fails;
+    return true;
+}
+inline int SelfTestSphereReintersect(int nSpheres, int nRays, int *nTested) {
+    int failures = 0, tested = 0;
+    for (int partial = 0; partial < 2; ++partial)
+        for (int i = 0; i < nSpheres; ++i) {
+            Sphere s; Ray first; Float t; int f = 0;
+            if (!SphereReintersectCase(i, partial != 0, nRays, &s, &first, &t, nullptr, &f)) continue;
+            ++tested; failures += f;
+        }
+    if (nTested) *nTested = tested;
+    return failures;
+}
+
+// ---- FloatingPoint.NextUpDownFloat (src/tests/fp_tests.cpp:29-47) ----
+inline int SelfTestNextFloat() {
+    int failures = 0;
+    if (!(NextFloatUp(-0.f) > 0.f)) ++failures;
+    if (!(NextFloatDown(0.f) < 0.f)) ++failures;
+    if (!(NextFloatUp((float)Infinity) == (float)Infinity)) ++failures;
+    if (!(NextFloatDown((float)Infinity) < (float)Infinity)) ++failures;
+    if (!(NextFloatDown(-(float)Infinity) == -(float)Infinity)) ++failures;
+    if (!(NextFloatUp(-(float)Infinity) > -(float)Infinity)) ++failures;
+    RNG rng;
+    for (int i = 0; i < 100000; ++i) {
+        float f;
+        do { uint32_t b = rng.UniformUInt32(); memcpy(&f, &b, 4); } while (std::isnan(f));
+        if (std::isinf(f)) continue;
+        if (std::nextafter(f, (float)Infinity) != NextFloatUp(f)) ++failures;
+        if (std::nextafter(f, -(float)Infinity) != NextFloatDown(f)) ++failures;
+    }
+    return failures;
+}
+
+// ---- EFloat.Add / Sub / Mul / Div (src/tests/fp_tests.cpp:107-262): the interval of the result contains the result of the
+// precise values.  (Abs and Sqrt are not on the path: Sphere::Intersect uses +, -, *, / and the double-precision Quadratic.) ----
+inline EFloat SelfTestGetEFloat(RNG &rng, Float minExp = -6., Float maxExp = 6.) {
+    Float logu = Lerp(rng.UniformFloat(), minExp, maxExp);
+    Float val = std::pow((Float)10, logu);
+    Float err = 0;
+    switch (rng.UniformUInt32(4)) {
+    case 0: break;
+    case 1: { uint32_t ulpError = rng.UniformUInt32(1024); uint32_t b; memcpy(&b, &val, 4); b += ulpError; Float offset; memcpy(&offset, &b, 4); err = std::abs(offset - val); break; }
+    case 2: { uint32_t ulpError = rng.UniformUInt32(1024 * 1024); uint32_t b; memcpy(&b, &val, 4); b += ulpError; Float offset; memcpy(&offset, &b, 4); err = std::abs(offset - val); break; }
+    case 3: err = (4 * rng.UniformFloat()) * std::abs(val);
+    }
+    Float sign = rng.UniformFloat() < .5 ? -1. : 1.;
+    return EFloat(sign * val, err);
+}
+inline double SelfTestGetPrecise(const EFloat &ef, RNG &rng) {
+    switch (rng.UniformUInt32(3)) {
+    case 0: return ef.low;
+    case 1: return ef.high;
+    case 2: {
+        Float t = rng.UniformFloat();
+        double p = (1 - t) * ef.low + t * ef.high;
+        if (p > ef.high) p = ef.high;
+        if (p < ef.low) p = ef.low;
+        return p;
+    }
+    }
+    return ef.v;
+}
+inline int SelfTestEFloat(int iters) {
+    int failures = 0;
+    for (int op = 0; op < 4; ++op)
+        for (int trial = 0; trial < iters; ++trial) {
+            RNG rng(trial);
+            EFloat ef[2]; ef[0] = SelfTestGetEFloat(rng); ef[1] = SelfTestGetEFloat(rng);
+            double precise[2]; precise[0] = SelfTestGetPrecise(ef[0], rng); precise[1] = SelfTestGetPrecise(ef[1], rng);
+            EFloat r; float pr;
+            if (op == 0) { r = ef[0] + ef[1]; pr = precise[0] + precise[1]; }
+            else if (op == 1) { r = ef[0] - ef[1]; pr = precise[0] - precise[1]; }
+            else if (op == 2) { r = ef[0] * ef[1]; pr = precise[0] * precise[1]; }
+            else {
+                // (err = high - low of the EFloat: GetAbsoluteError, core/efloat.h:98)
+                if ((double)ef[1].low * (double)ef[1].high < 0. || (ef[1].high - ef[1].low) > .25 * std::abs(ef[1].low)) continue;
+                r = ef[0] / ef[1]; pr = precise[0] / precise[1];
+            }
+            if (!(pr >= r.low)) ++failures;
+            if (!(pr <= r.high)) ++failures;
+        }
+    return failures;
+}
+
+// ---- Distribution1D.Discrete (src/tests/sampling.cpp:231-282), the part the path uses (SampleDiscrete with its pdf) ----
+inline int SelfTestDistribution1D() {
+    int failures = 0;
+    Float func[4] = {0, 1., 0., 3.};
+    Distribution1D dist; dist.Init(func, 4);
+    if (dist.Count() != 4) ++failures;
+    auto discretePdf = [&](int i) { return dist.func[i] / (dist.funcInt * dist.Count()); };      // core/sampling.h:97-100
+    if (discretePdf(0) != 0 || discretePdf(1) != .25f || discretePdf(2) != 0 || discretePdf(3) != .75f) ++failures;
+    Float pdf;
+    const Float us[7] = {0.f, 0.125f, .24999f, .250001f, 0.625f, OneMinusEpsilon, 1.f};
+    const int want[7] = {1, 1, 1, 3, 3, 3, 3};
+    for (int k = 0; k < 7; ++k) {
+        if (dist.SampleDiscrete(us[k], &pdf) != want[k]) ++failures;
+        if (pdf != (want[k] == 1 ? 0.25f : 0.75f)) ++failures;
+    }
+    Float u = .25, uMax = .25;
+    for (int i = 0; i < 20; ++i) { u = NextFloatDown(u); uMax = NextFloatUp(uMax); }
+    for (; u < uMax; u = NextFloatUp(u)) {
+        int interval = dist.SampleDiscrete(u, &pdf);
+        if (interval == 3) break;
+        if (interval != 1) ++failures;
+    }
+    if (!(u < uMax)) ++failures;
+    for (; u <= uMax; u = NextFloatUp(u))
+        if (dist.SampleDiscrete(u, &pdf) != 3) ++failures;
+    return failures;
 }
 
 }  // namespace orc

@@ -1,0 +1,66 @@
+"""The reference's one ANALYTIC answer for this path: the furnace scenes of src/tests/analytic_scenes.cpp.
+
+A unit sphere seen from its centre, matte Kd = 0.5 on the inside (reverse orientation), lit either by a point light of
+intensity pi at the centre (scene 1, :68-98) or by itself as a DiffuseAreaLight of Le = 0.5 (scene 3, :135-165): with
+global illumination every pixel's radiance is 1 (0.5 + 0.25 + ...).  The reference renders them with
+PathIntegrator(maxdepth 8), Halton-256, a 10x10 film, the box filter and a 45-degree perspective camera (:289-306) and
+asserts that the mean over all pixels and channels is within 0.02 of 1.0 (CheckSceneAverage, :54-66).  The same scenes,
+written as the .pbrt text that builds exactly those objects through the front-end, are held to the same bound over the
+oracle (CPU test) and over the HIP path, which must also equal the oracle's film bit for bit (GPU test).  Scene 3 shades
+points that lie INSIDE their own emitter (Sphere::Sample's uniform-area branch, shapes/sphere.cpp:236-252), the path the
+material-specialised shading kernels hand over to the generic one.  Scene 2 (four point lights) needs the spatial light
+distribution and scene 4 UberMaterial: both outside the hot-path scope."""
+import numpy as np
+import pytest
+
+HEAD = """Camera "perspective" "float fov" [45]
+Film "image" "integer xresolution" [10] "integer yresolution" [10]
+Sampler "halton" "integer pixelsamples" [256]
+Integrator "path" "integer maxdepth" [8]
+WorldBegin
+"""
+SCENES = {
+    # PointLight(Transform(), nullptr, Spectrum(Pi)): float(pi) = 3.14159274
+    "sphere_point_light": HEAD + 'LightSource "point" "color I" [3.1415927 3.1415927 3.1415927]\nMaterial "matte" "color Kd" [.5 .5 .5]\n'
+                                 'ReverseOrientation\nShape "sphere" "float radius" [1]\nWorldEnd\n',
+    "sphere_area_light": HEAD + 'Material "matte" "color Kd" [.5 .5 .5]\nAreaLightSource "diffuse" "color L" [.5 .5 .5]\n'
+                                'ReverseOrientation\nShape "sphere" "float radius" [1]\nWorldEnd\n',
+}
+DELTA = 0.02      # analytic_scenes.cpp:59
+
+
+def _bake(hprt, tmp_path, name):
+    p = tmp_path / (name + ".pbrt")
+    p.write_text(SCENES[name])
+    model = hprt.Model.parse(str(p))
+    assert model.warnings() == []
+    o = model.options
+    assert (o.xres, o.yres, o.spp, o.max_depth) == (10, 10, 256, 8) and list(o.screen_window) == [-1.0, 1.0, -1.0, 1.0]
+    baked = str(tmp_path / (name + ".hprt"))
+    model.save(baked)
+    return model, baked
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_oracle_furnace_mean(hprt, orc, tmp_path, name):
+    _, baked = _bake(hprt, tmp_path, name)
+    rgb, _, c, _, _ = orc.OracleScene(baked).render(threads=4)
+    assert rgb.shape == (10, 10, 3) and c["camera_rays"] == 100 * 256
+    assert abs(float(rgb.mean(dtype=np.float64)) - 1.0) < DELTA, float(rgb.mean())
+    assert 0.9 < rgb.min() and rgb.max() < 1.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_device_furnace_equals_oracle(hprt, orc, tmp_path, name):
+    model, baked = _bake(hprt, tmp_path, name)
+    rgb0, film0, c0, _, _ = orc.OracleScene(baked).render(threads=4)
+    scene = hprt.Scene(model, hprt.Bvh(model))
+    film1, st = scene.render(count_work=True)
+    assert np.array_equal(film0.view(np.uint32), film1.view(np.uint32))
+    film2, _ = scene.render()
+    assert np.array_equal(film0.view(np.uint32), film2.view(np.uint32))
+    rgb1 = hprt.film_resolve(film1, model.options.film_scale)
+    assert np.array_equal(rgb0.view(np.uint32), rgb1.view(np.uint32))
+    assert abs(float(rgb1.mean(dtype=np.float64)) - 1.0) < DELTA
+    assert st["rays"] == c0["rays"] and st["shadow_rays"] == c0["shadow_rays"] and st["sphere_tests"] == c0["sphere_tests"]

@@ -177,3 +177,29 @@ def test_detmath_accuracy(orc):
             assert abs(a - np.arctan2(np.float64(yv), np.float64(xv))) < 3e-7
     for v in np.linspace(-1, 1, 201):
         assert abs(orc.lib.orc_det_acosf(C.c_float(float(v))) - np.arccos(v)) < 4e-7
+
+
+def test_float_tolerance_between_deterministic_and_glibc_math(killeroo_oracle, orc):
+    """What "per-pixel L-inf < 1e-4 vs the reference" can mean for this path.  The device equals the oracle bit for bit in
+    its deterministic-math mode; the reference calls glibc's sinf/cosf/atan2f/acosf, which the oracle's libm mode follows.
+    BASELINE.json's config[0] (killeroo-simple, 700x700, 64 spp) rendered in both modes, final linear RGB compared per
+    pixel: almost every pixel agrees to ~1e-7, a few hundred differ by more than 1e-4 because ONE of their 64 samples
+    took a different path (a last-bit difference in a sampled direction flips a hit / miss decision somewhere along the
+    path: the two renders are two equally valid roundings of the same estimator, not a bias).  DESIGN.md §5 quotes the
+    numbers this test prints; the bounds asserted here are loose versions of them."""
+    killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=64)
+    try:
+        a = killeroo_oracle.render(spp=64, threads=0)[0]
+        orc.lib.orc_set_libm(1)
+        b = killeroo_oracle.render(spp=64, threads=0)[0]
+    finally:
+        orc.lib.orc_set_libm(0)
+        killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64)).max(axis=2)
+    rel = d / np.maximum(np.abs(a).max(axis=2), 1e-3)
+    n_abs, n_rel = int((d > 1e-4).sum()), int((rel > 1e-4).sum())
+    print("\nconfig[0] det vs glibc math, 64 spp: L-inf %.3g (abs), pixels > 1e-4: %d abs / %d rel of %d, mean |d| %.3g, median |d| %.3g, "
+          "image mean %.4f" % (d.max(), n_abs, n_rel, d.size, d.mean(), np.median(d), a.mean()))
+    assert np.median(d) < 1e-6 and d.mean() < 1e-4
+    assert n_abs < 0.02 * d.size          # a per-cent-level minority of pixels carries a divergent sample
+    assert abs(float(a.mean()) - float(b.mean())) < 1e-3 * float(a.mean())      # no bias

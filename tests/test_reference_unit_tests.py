@@ -1,0 +1,108 @@
+"""The reference's own unit tests for this path, restated in full.
+
+CPU part: over the oracle's functions (oracle/orc_selftests.h) and over the product's host/device-shared math
+(csrc/hprt_math.h through the hprt_debug_host_selftest hook).  GPU part: the rays of the two geometric property tests go
+through the C ABI's batched Aggregate calls (hprt_intersect / hprt_occluded) on scenes that the test fills into an
+HprtSceneDesc itself — borrowed numpy pointers, BVH from hprt_bvh_build_from_bounds — and hands to hprt_scene_create, the
+way a BVHAccel-shaped adapter inside pbrt would.
+
+  Triangle.Watertight            src/tests/shapes.cpp:28-129     all 100,000 iterations (200,000 rays)
+  FullSphere/PartialSphere.Reintersect   :374-441, 481-500        100 + 100 spheres x 20,000 rays leaving the hit point
+  Distribution1D.Discrete        src/tests/sampling.cpp:231-282
+  FloatingPoint.NextUpDownFloat  src/tests/fp_tests.cpp:29-47
+  EFloat.Add/Sub/Mul/Div         src/tests/fp_tests.cpp:107-262   1,000,000 trials each
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_oracle_geometric_property_tests(orc):
+    assert orc.lib.orc_selftest_watertight(100000) == 0
+    n = C.c_int()
+    assert orc.lib.orc_selftest_sphere_reintersect(100, 10000, C.byref(n)) == 0
+    assert n.value > 60          # "we should usually (but not always) find an intersection"
+
+
+def test_oracle_numeric_unit_tests(orc):
+    assert orc.lib.orc_selftest_next_float() == 0
+    assert orc.lib.orc_selftest_efloat(1000000) == 0
+    assert orc.lib.orc_selftest_distribution1d() == 0
+
+
+def test_product_host_math_unit_tests(hprt):
+    f = (C.c_int * 2)(7, 7)
+    assert hprt.lib.hprt_debug_host_selftest(f) == 0
+    assert list(f) == [0, 0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _one_shape_scene(hprt, shape, bmin, bmax):
+    """hprt_scene_create from a description filled here: one shape, one matte material, no lights."""
+    bvh = hprt.Bvh.from_bounds(bmin, bmax)
+    nodes, order = bvh.arrays()
+    mat = hprt.MaterialDesc(); mat.type = 0; mat.Kd[:] = [.5, .5, .5]; mat.kd_texture = mat.ks_texture = -1
+    desc = hprt.SceneDesc()
+    desc.nodes = nodes.ctypes.data; desc.n_nodes = nodes.shape[0]
+    desc.prim_order = order.ctypes.data; desc.n_prims = order.shape[0]
+    shapes = (hprt.ShapeDesc * 1)(shape); mats = (hprt.MaterialDesc * 1)(mat)
+    desc.shapes = shapes; desc.n_shapes = 1
+    desc.materials = mats; desc.n_materials = 1
+    scene = hprt.Scene.from_desc(desc)
+    return scene, nodes, order
+
+
+@pytest.mark.gpu
+def test_triangle_watertight_through_hprt_intersect(hprt, orc):
+    n_iter = 100000
+    P = np.zeros((256, 3), np.float32); idx = np.zeros((420, 3), np.int32)
+    o = np.zeros((2 * n_iter, 3), np.float32); d = np.zeros((2 * n_iter, 3), np.float32); t_brute = np.zeros(2 * n_iter, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    orc.lib.orc_watertight_case.argtypes = [C.c_int] + [C.c_void_p] * 5
+    orc.lib.orc_watertight_case(n_iter, p(P), p(idx), p(o), p(d), p(t_brute))
+    assert (t_brute > 0).all()                                   # the oracle itself: every ray hits (EXPECT_GE(nHits, 1))
+    tri = P[idx]                                                  # Triangle::WorldBound: Union of the three vertices
+    sh = hprt.ShapeDesc(); sh.kind = 0; sh.material = 0; sh.area_light = -1
+    sh.n_tris = 420; sh.n_verts = 256; sh.indices = idx.ctypes.data; sh.P = P.ctypes.data
+    scene, nodes, order = _one_shape_scene(hprt, sh, tri.min(axis=1), tri.max(axis=1))
+    t, prim, bary = scene.intersect(o, d, np.full(2 * n_iter, np.inf, np.float32))
+    assert (prim >= 0).all(), "%d of %d rays slipped through the mesh" % (int((prim < 0).sum()), 2 * n_iter)
+    # the BVH walk finds the same closest distance as testing every triangle
+    assert np.array_equal(t.view(np.uint32), t_brute.view(np.uint32))
+    occ = scene.occluded(o, d, np.full(2 * n_iter, np.inf, np.float32))
+    assert occ.all()
+    del scene
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partial", [0, 1])
+def test_sphere_reintersect_through_the_c_abi(hprt, orc, partial):
+    n_rays = 10000
+    orc.lib.orc_sphere_reintersect_case.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    tested = 0
+    for seed in range(100):
+        params = np.zeros(6, np.float32); first = np.zeros(7, np.float32); t_first = np.zeros(1, np.float32)
+        rays = np.zeros((2 * n_rays, 7), np.float32); fails = np.zeros(1, np.int32)
+        hit = orc.lib.orc_sphere_reintersect_case(seed, partial, n_rays, p(params), p(first), p(t_first), p(rays), p(fails))
+        radius, z_min, z_max = float(params[0]), float(params[1]), float(params[2])
+        sh = hprt.ShapeDesc(); sh.kind = 1; sh.material = 0; sh.area_light = -1
+        ident = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+        sh.object_to_world[:] = ident; sh.world_to_object[:] = ident
+        sh.radius, sh.z_min, sh.z_max, sh.theta_min, sh.theta_max, sh.phi_max = [float(v) for v in params]
+        # Sphere::ObjectBound (shapes/sphere.cpp:44-47) under the identity transform
+        scene, _, _ = _one_shape_scene(hprt, sh, np.array([[-radius, -radius, z_min]], np.float32), np.array([[radius, radius, z_max]], np.float32))
+        t, prim, _ = scene.intersect(first[None, 0:3], first[None, 3:6], first[6:7])
+        assert (prim[0] >= 0) == bool(hit)
+        if hit:
+            assert t[0].view(np.uint32) == t_first[0].view(np.uint32)
+            assert fails[0] == 0
+            tested += 1
+            o = np.ascontiguousarray(rays[:, 0:3]); d = np.ascontiguousarray(rays[:, 3:6]); tm = np.ascontiguousarray(rays[:, 6])
+            occ = scene.occluded(o, d, tm)
+            assert not occ.any(), "sphere %d: %d spawned rays are occluded by the sphere they leave" % (seed, int(occ.sum()))
+            _, prim2, _ = scene.intersect(o, d, tm)
+            assert (prim2 < 0).all()
+        del scene
+    assert tested > 30

@@ -83,6 +83,36 @@ class RenderStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+# ---- HprtSceneDesc and its parts (include/hprt.h): what a pbrt-side adapter fills from the primitives it was given ----
+class ShapeDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("material", C.c_int32), ("area_light", C.c_int32),
+                ("reverse_orientation", C.c_int32), ("transform_swaps_handedness", C.c_int32),
+                ("n_tris", C.c_uint32), ("n_verts", C.c_uint32),
+                ("indices", C.c_void_p), ("P", C.c_void_p), ("N", C.c_void_p), ("UV", C.c_void_p), ("S", C.c_void_p),
+                ("object_to_world", C.c_float * 16), ("world_to_object", C.c_float * 16),
+                ("radius", C.c_float), ("z_min", C.c_float), ("z_max", C.c_float), ("theta_min", C.c_float), ("theta_max", C.c_float),
+                ("phi_max", C.c_float)]
+
+
+class MaterialDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("Kd", C.c_float * 3), ("sigma", C.c_float), ("Ks", C.c_float * 3), ("roughness", C.c_float),
+                ("remap_roughness", C.c_int32), ("kd_texture", C.c_int32), ("ks_texture", C.c_int32)]
+
+
+class LightDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("pos", C.c_float * 3), ("I", C.c_float * 3), ("shape", C.c_int32), ("two_sided", C.c_int32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_uint32), ("prim_order", C.c_void_p), ("n_prims", C.c_uint32),
+                ("shapes", C.POINTER(ShapeDesc)), ("n_shapes", C.c_uint32),
+                ("materials", C.POINTER(MaterialDesc)), ("n_materials", C.c_uint32),
+                ("lights", C.POINTER(LightDesc)), ("n_lights", C.c_uint32), ("light_strategy", C.c_int32),
+                ("textures", C.c_void_p), ("n_textures", C.c_uint32),
+                ("objects", C.c_void_p), ("n_objects", C.c_uint32), ("instances", C.c_void_p), ("n_instances", C.c_uint32),
+                ("top", C.c_void_p), ("n_top", C.c_uint32)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("hprt: %s is missing — run `python thesis-pbrt-v3_amd/build.py` (hipcc, gfx950). "
@@ -273,6 +303,17 @@ class Scene:
         _check(lib.hprt_scene_create_from_model(model._h, bvh._h, device, C.byref(h)))
         self._h = h
         self._model = model
+
+    @staticmethod
+    def from_desc(desc, device=-1):
+        """hprt_scene_create on a caller-filled SceneDesc (borrowed host pointers; the library copies everything to HBM) —
+        the entry a BVHAccel-shaped adapter inside pbrt uses."""
+        h = C.c_void_p()
+        _check(lib.hprt_scene_create(C.byref(desc), device, C.byref(h)))
+        sc = Scene.__new__(Scene)
+        sc._h = h
+        sc._model = None
+        return sc
 
     def intersect(self, o, d, tmax, count=False):
         o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)

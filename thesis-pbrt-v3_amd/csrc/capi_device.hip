@@ -387,13 +387,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     // UniformLightDistribution (core/lightdistrib.cpp:68-75) as a Distribution1D (core/sampling.h:57-70)
     std::vector<float> func(std::max<uint32_t>(1, d->n_lights), 1.f), cdf(d->n_lights + 1, 0.f);
     float funcInt = 0.f;
-    if (d->n_lights) {
-        int n = (int)d->n_lights;
-        for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / n;
-        funcInt = cdf[n];
-        if (funcInt == 0) for (int i = 1; i < n + 1; ++i) cdf[i] = float(i) / float(n);
-        else for (int i = 1; i < n + 1; ++i) cdf[i] /= funcInt;
-    }
+    if (d->n_lights) dist1d_build(func.data(), (int)d->n_lights, cdf.data(), &funcInt);
     // Halton tables + 64-bit division magics
     const std::vector<uint16_t> &perms = HaltonPermutations();
     // ---- child-pair layout of the BVHs (device/dev_scene.h): one run of pairs per aggregate ----

@@ -2,6 +2,9 @@
 // BVH build, Halton tables, film resolve, PFM writer.  No HIP calls here; the
 // device half lives in capi_device.hip.
 #include <algorithm>
+#include <cmath>
+#include <limits>
+#include <vector>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -11,6 +14,7 @@
 #include "halton_tables.h"
 #include "hprt_internal.h"
 #include "scene_model.h"
+#include "hprt_math.h"
 
 using namespace hprt;
 
@@ -250,6 +254,61 @@ int hprt_film_records_merge(float *xyzw, size_t n_pixels, HprtFilmRecord *rec, s
         float *px = xyzw + 4 * (size_t)rec[i].dest_pixel;
         px[0] += rec[i].xyz[0]; px[1] += rec[i].xyz[1]; px[2] += rec[i].xyz[2]; px[3] += rec[i].weight;
     }
+    return HPRT_OK;
+}
+
+// Diagnostics hook (not part of include/hprt.h): the reference's unit tests for the host/device-shared math of this path,
+// run over the product's own functions (hprt_math.h) on the host:
+//   failures[0]  FloatingPoint.NextUpDownFloat   src/tests/fp_tests.cpp:29-47    next_up / next_down
+//   failures[1]  Distribution1D.Discrete          src/tests/sampling.cpp:231-282  dist1d_build / dist1d_sample_discrete
+__attribute__((visibility("default"))) int hprt_debug_host_selftest(int failures[2]) {
+    if (!failures) return HPRT_E_INVALID;
+    const float inf = std::numeric_limits<float>::infinity();
+    int f = 0;
+    if (!(next_up(-0.f) > 0.f)) ++f;
+    if (!(next_down(0.f) < 0.f)) ++f;
+    if (!(next_up(inf) == inf)) ++f;
+    if (!(next_down(inf) < inf)) ++f;
+    if (!(next_down(-inf) == -inf)) ++f;
+    if (!(next_up(-inf) > -inf)) ++f;
+    // the default-seeded PCG32 stream of the reference's test (core/rng.h:61-62, 86-95)
+    uint64_t state = 0x853c49e6748fea9bULL; const uint64_t inc = 0xda3e39cb94b95bdbULL;
+    auto next32 = [&]() {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u);
+        return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+    };
+    for (int i = 0; i < 100000; ++i) {
+        float v;
+        do { v = u2f(next32()); } while (std::isnan(v));
+        if (std::isinf(v)) continue;
+        if (std::nextafter(v, inf) != next_up(v)) ++f;
+        if (std::nextafter(v, -inf) != next_down(v)) ++f;
+    }
+    failures[0] = f;
+    f = 0;
+    const float func[4] = {0, 1.f, 0.f, 3.f};
+    float cdf[5], funcInt;
+    dist1d_build(func, 4, cdf, &funcInt);
+    float pdf;
+    const float us[7] = {0.f, 0.125f, .24999f, .250001f, 0.625f, 0x1.fffffep-1f, 1.f};
+    const int want[7] = {1, 1, 1, 3, 3, 3, 3};
+    for (int k = 0; k < 7; ++k) {
+        if (dist1d_sample_discrete(cdf, func, funcInt, 4, us[k], &pdf) != want[k]) ++f;
+        if (pdf != (want[k] == 1 ? 0.25f : 0.75f)) ++f;
+    }
+    float u = .25f, uMax = .25f;
+    for (int i = 0; i < 20; ++i) { u = next_down(u); uMax = next_up(uMax); }
+    for (; u < uMax; u = next_up(u)) {
+        int interval = dist1d_sample_discrete(cdf, func, funcInt, 4, u, &pdf);
+        if (interval == 3) break;
+        if (interval != 1) ++f;
+    }
+    if (!(u < uMax)) ++f;
+    for (; u <= uMax; u = next_up(u))
+        if (dist1d_sample_discrete(cdf, func, funcInt, 4, u, &pdf) != 3) ++f;
+    failures[1] = f;
     return HPRT_OK;
 }
 

@@ -726,17 +726,7 @@ __device__ __forceinline__ float light_pdf(const DevScene &sc, const DevLight &l
 }
 // Distribution1D::SampleDiscrete (core/sampling.h:86-96) with FindInterval (core/pbrt.h:403-415)
 __device__ __forceinline__ int light_pick(const DevScene &sc, float u, float *pdf) {
-    int size = (int)sc.nLights + 1;
-    int first = 0, len = size;
-    while (len > 0) {
-        int half = len >> 1, middle = first + half;
-        if (sc.lightCdf[middle] <= u) { first = middle + 1; len -= half + 1; }
-        else len = half;
-    }
-    int offset = first - 1;
-    if (offset < 0) offset = 0; else if (offset > size - 2) offset = size - 2;
-    *pdf = (sc.lightFuncInt > 0) ? sc.lightFunc[offset] / (sc.lightFuncInt * (int)sc.nLights) : 0;
-    return offset;
+    return dist1d_sample_discrete(sc.lightCdf, sc.lightFunc, sc.lightFuncInt, (int)sc.nLights, u, pdf);
 }
 __device__ __forceinline__ float power_heuristic(float fPdf, float gPdf) {   // core/sampling.h:171-174, nf = ng = 1
     float f = 1 * fPdf, g = 1 * gPdf;

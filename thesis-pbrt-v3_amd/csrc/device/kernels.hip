@@ -1139,7 +1139,7 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     // closest hits in large scenes run longer interior stretches between leaves (57 nodes per ray in the living room,
     // 20 in killeroo-simple): a longer pair phase pays there (+2-3 % on the living room and the atrium, -1 % on killeroo)
     static const bool tuneFromEnv = getenv("HPRT_TRACE_TUNE") != nullptr;
-    if (!anyHit && !tuneFromEnv && sc.nPairs > 100000u) tune.stepLimit = 10;
+    if (!anyHit && !tuneFromEnv && sc.nPairs > 100000u) { tune.parkLimit = 32; tune.stepLimit = 14; tune.primMin = 12; }      // (round-2 sweep, tools/sweep_tune.sh: atrium +3.6 %, living room +-0)
     static const bool profile = getenv("HPRT_TRACE_PROFILE") != nullptr;
     const bool inst = sc.nInstances != 0u, quad = sc.nSpheres != 0u;
 #define HPRT_TRACE_LAUNCH(A, M, I, Q) hipLaunchKernelGGL((k_trace<A, M, I, Q>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, rayStats, workCounter, chunk, tune, deepRegion)

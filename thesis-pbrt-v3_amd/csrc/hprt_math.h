@@ -62,6 +62,29 @@ HPRT_HD float next_down(float v) {
     return u2f(ui);
 }
 
+// Distribution1D (core/sampling.h:55-109), the part the light pick of UniformSampleOneLight uses: the constructor's cdf
+// (host) and SampleDiscrete with FindInterval (core/pbrt.h:403-415) and its pdf (host and device).
+inline void dist1d_build(const float *func, int n, float *cdf, float *funcInt) {
+    cdf[0] = 0;
+    for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / n;
+    *funcInt = cdf[n];
+    if (*funcInt == 0) for (int i = 1; i < n + 1; ++i) cdf[i] = float(i) / float(n);
+    else for (int i = 1; i < n + 1; ++i) cdf[i] /= *funcInt;
+}
+HPRT_HD int dist1d_sample_discrete(const float *cdf, const float *func, float funcInt, int n, float u, float *pdf) {
+    int size = n + 1;
+    int first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    int offset = first - 1;
+    if (offset < 0) offset = 0; else if (offset > size - 2) offset = size - 2;
+    *pdf = (funcInt > 0) ? func[offset] / (funcInt * n) : 0;
+    return offset;
+}
+
 struct vec3 {
     float x, y, z;
     HPRT_HD vec3() : x(0.f), y(0.f), z(0.f) {}
