@@ -255,10 +255,6 @@ typedef struct HprtRenderDesc {
  * (FilmTile pixels outside the tile's own 16x16 block, core/film.cpp:98-103) are not merged into the film but kept as
  * HprtFilmRecords, so that the gather can merge the records of ALL ranks into each pixel in source-tile order. */
 #define HPRT_RENDER_EXPORT_FOREIGN 16
-/* Experimental: run the shadow-ray trace, the MIS-ray trace and the next bounce's path trace that follow a shading pass
- * on three HIP streams instead of one after the other on the caller's stream.  Same film; measured slower on MI355X
- * (dead ends), so it is opt-in.  extend_seconds / occluded_seconds then overlap each other. */
-#define HPRT_RENDER_OVERLAP_TRACES 32
 
 typedef struct HprtRenderStats {
     uint64_t camera_rays;          /* nCameraRays, core/integrator.cpp:48,293 */
@@ -272,7 +268,6 @@ typedef struct HprtRenderStats {
     double extend_seconds, occluded_seconds;  /* HIP-event time inside the traversal kernels */
     uint64_t extend_launches, occluded_launches;
     uint64_t extend_rays, occluded_rays;
-    uint64_t traces_overlapped;    /* 1: the traces ran on concurrent streams, the *_seconds above overlap each other */
 } HprtRenderStats;
 
 /* Renders into the scene's film.  d_film_xyzw, if not NULL, is a caller-owned

@@ -34,7 +34,6 @@ RENDER_PIXEL_STATS = 2
 RENDER_COUNT_TRACED = 4
 RENDER_TRACE_ALL = 8
 RENDER_EXPORT_FOREIGN = 16
-RENDER_OVERLAP_TRACES = 32
 COMM_ID_BYTES = 128
 # HprtFilmRecord: one cross-tile film contribution (include/hprt.h)
 FILM_RECORD = np.dtype([("dest_pixel", np.uint32), ("src_tile", np.uint32), ("xyz", np.float32, 3), ("weight", np.float32)])
@@ -76,8 +75,7 @@ class RenderStats(C.Structure):
         "camera_rays", "rays", "shadow_rays", "nodes_fetched", "nodes_fetched_p", "nodes_entered", "nodes_entered_p",
         "tri_tests", "tri_tests_p", "sphere_tests", "sphere_tests_p")] + [
         ("render_seconds", C.c_double), ("extend_seconds", C.c_double), ("occluded_seconds", C.c_double),
-        ("extend_launches", C.c_uint64), ("occluded_launches", C.c_uint64), ("extend_rays", C.c_uint64), ("occluded_rays", C.c_uint64),
-        ("traces_overlapped", C.c_uint64)]
+        ("extend_launches", C.c_uint64), ("occluded_launches", C.c_uint64), ("extend_rays", C.c_uint64), ("occluded_rays", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -351,7 +349,7 @@ class Scene:
         _check(lib.hprt_occluded_device(self._h, n, rays7_ptr, occ_ptr, stream))
 
     def render(self, opt=None, tile_begin=0, tile_end=0, tile_stride=1, spp_chunk=0, count_work=False, film_ptr=None,
-               stream=None, pixel_stats=False, count_traced=False, trace_all=False, export_foreign=False, overlap_traces=False):
+               stream=None, pixel_stats=False, count_traced=False, trace_all=False, export_foreign=False):
         """Render(): returns (film_xyzw [H,W,4] float32 or None when film_ptr is given, stats dict)."""
         opt = opt or self._model.options
         desc = RenderDesc()
@@ -361,7 +359,7 @@ class Scene:
         # count_traced / trace_all: see HPRT_RENDER_COUNT_TRACED / HPRT_RENDER_TRACE_ALL in include/hprt.h
         desc.flags = (RENDER_COUNT_WORK if count_work else 0) | (RENDER_PIXEL_STATS if pixel_stats else 0) | \
                      (RENDER_COUNT_TRACED if count_traced else 0) | (RENDER_TRACE_ALL if trace_all else 0) | \
-                     (RENDER_EXPORT_FOREIGN if export_foreign else 0) | (RENDER_OVERLAP_TRACES if overlap_traces else 0)      # export_foreign: see film_records() / Comm.film_gather()
+                     (RENDER_EXPORT_FOREIGN if export_foreign else 0)      # export_foreign: see film_records() / Comm.film_gather()
         self._film_shape = tuple(int(v) for v in (opt.film_bounds()[3] - opt.film_bounds()[1], opt.film_bounds()[2] - opt.film_bounds()[0]))
         st = RenderStats()
         _check(lib.hprt_render(self._h, C.byref(desc), film_ptr, stream, C.byref(st)))

@@ -464,8 +464,8 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     HIP_TRY(upload(sc->textures, textures)); HIP_TRY(upload(sc->mipLevels, mipLevels)); HIP_TRY(upload(sc->texels, texels)); HIP_TRY(upload(sc->weightLut, weightLut));
     HIP_TRY(sc->counters.alloc(sizeof(DevCounters)));
     HIP_TRY(hipMemset(sc->counters.p, 0, sizeof(DevCounters)));
-    HIP_TRY(sc->deepStack.alloc((size_t)HPRT_DEEP_REGIONS * HPRT_SPILL_STACK * HPRT_DEEP_THREADS * sizeof(uint2)));
-    HIP_TRY(sc->workCounter.alloc(1024));      // three queue-head counters, 256 bytes apart
+    HIP_TRY(sc->deepStack.alloc((size_t)HPRT_SPILL_STACK * HPRT_DEEP_THREADS * sizeof(uint2)));
+    HIP_TRY(sc->workCounter.alloc(256));
     DevScene &dv = sc->dev;
     dv.pairs = sc->nodes.as<DevPair>(); dv.nPairs = (uint32_t)pairs.size();
     dv.tris = sc->tris.as<float4>(); dv.nPrims = totalPrims;
@@ -696,25 +696,16 @@ struct BatchTimers { double extendMs = 0, occludedMs = 0; uint64_t extendLaunche
 //
 // Per bounce b:   trace(path b) -> bin -> shade x3 -> [counts to the host] -> trace(shadow b) | trace(MIS b) | trace(path b+1)
 //                 -> resolve(b) -> bin(b+1) ...
-// The three traces that follow a shading pass depend on nothing but that pass.  With `overlap` (HPRT_RENDER_OVERLAP_TRACES,
-// opt-in) they run on three streams, the idea being that each fills the tails of the others' persistent kernels.  Measured
-// on MI355X (round 2): SLOWER — atrium 1024 spp 1064 -> 1119 ms, living room 455 -> 478 ms, killeroo-simple 90.6 -> 91.8 ms:
-// every persistent kernel is sized to fill the machine, so the second and third only get wave slots as the first one's
-// blocks drain, i.e. at its end, and the cross-stream waits add bubbles.  The default therefore keeps every kernel on the
-// caller's stream (where HIP-event times are exclusive); radiance is added in the reference's order either way
-// (resolve(b) before anything of bounce b+1 reads L).
+// The three traces that follow a shading pass depend on nothing but that pass.  Running them on three HIP streams (so that
+// each fills the tails of the others' persistent kernels) was built and measured in round 2: SLOWER — atrium 1024 spp
+// 1064 -> 1119 ms, living room 455 -> 478 ms, killeroo-simple 90.6 -> 91.8 ms (every persistent kernel is sized to fill the
+// machine, so the second and third only get wave slots as the first one's blocks drain, and the cross-stream waits add
+// bubbles) — and removed again: every kernel runs on the caller's stream, where HIP-event times are exclusive.
 int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspace &w, const QueueSet &qa, const QueueSet &qb,
-             const BinSet &bins, uint32_t s0, uint32_t nSlots, bool count, bool overlap, EventTimer &ev, BatchTimers *bt, HprtRenderStats *stats,
+             const BinSet &bins, uint32_t s0, uint32_t nSlots, bool count, EventTimer &ev, BatchTimers *bt, HprtRenderStats *stats,
              uint32_t *pixelStats = nullptr) {
     uint4 *rayStats = pixelStats ? s->rayStats.as<uint4>() : nullptr;
-    if (count || pixelStats) overlap = false;
-    hipStream_t stShadow = st, stMis = st;
-    if (overlap) {
-        for (int k = 0; k < 2; ++k) if (!s->auxStream[k]) HIP_TRY(hipStreamCreateWithFlags(&s->auxStream[k], hipStreamNonBlocking));
-        stShadow = s->auxStream[0]; stMis = s->auxStream[1];
-    }
-    // one queue-head counter per stream (256 bytes apart)
-    uint32_t *wcPath = s->workCounter.as<uint32_t>(), *wcShadow = wcPath + 64, *wcMis = wcPath + 128;
+    uint32_t *wcPath = s->workCounter.as<uint32_t>();
     LaunchGenerate(st, s->dev, rp, w.path[0], s0, nSlots);
     const uint32_t *activeQ = nullptr; uint32_t active = nSlots;
     QueueSet q[2] = {qa, qb};
@@ -743,38 +734,32 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         for (int mode = 0; mode < 3; ++mode)
             LaunchShade(st, mode, s->dev, rp, in, w.hit, active, s0, out, w.vs, cur, bins, w.Lfinal, bounce == 0);
         HIP_TRY(hipMemcpyAsync(s->hostCounts + 4096, cur.nextCount, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));      // (the other streams may start now: everything they read is complete)
-        hipEvent_t evShadowEnd = nullptr, evMisEnd = nullptr;
+        HIP_TRY(hipStreamSynchronize(st));
         const uint32_t nNext = s->hostCounts[4096], nShadow = s->hostCounts[4096 + 64], nMis = s->hostCounts[4096 + 128], nResolve = s->hostCounts[4096 + 192];
         if (nShadow) {
             hipEvent_t a = ev.get(), b = ev.get();
-            HIP_TRY(hipEventRecord(a, stShadow));
+            HIP_TRY(hipEventRecord(a, st));
             HitStream none; none.a = nullptr; none.b = nullptr;
-            LaunchTrace(stShadow, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, w.vs.shadow, none, w.vs.occluded, ctr, wcShadow, rayStats, overlap ? 1u : 0u);
-            if (pixelStats) LaunchPixelStats(stShadow, rayStats, w.vs.pendBeta, cur.shadow, nullptr, nShadow, nShadow, rp.nPix, true, pixelStats);
-            HIP_TRY(hipEventRecord(b, stShadow));
+            LaunchTrace(st, s->dev, true, count, cur.shadow, nullptr, nShadow, nShadow, w.vs.shadow, none, w.vs.occluded, ctr, wcPath, rayStats);
+            if (pixelStats) LaunchPixelStats(st, rayStats, w.vs.pendBeta, cur.shadow, nullptr, nShadow, nShadow, rp.nPix, true, pixelStats);
+            HIP_TRY(hipEventRecord(b, st));
             evOcc.push_back({a, b}); bt->occludedRays += nShadow; ++bt->occludedLaunches;
             stats->shadow_rays += nShadow;
-            evShadowEnd = b;
         }
         if (nMis) {
             hipEvent_t a = ev.get(), b = ev.get();
-            HIP_TRY(hipEventRecord(a, stMis));
-            LaunchTrace(stMis, s->dev, false, count, cur.mis, nullptr, nMis, nMis, w.vs.mis, w.vs.misHit, nullptr, ctr, wcMis, rayStats, overlap ? 2u : 0u);
-            if (pixelStats) LaunchPixelStats(stMis, rayStats, w.vs.pendBeta, cur.mis, nullptr, nMis, nMis, rp.nPix, false, pixelStats);
-            HIP_TRY(hipEventRecord(b, stMis));
+            HIP_TRY(hipEventRecord(a, st));
+            LaunchTrace(st, s->dev, false, count, cur.mis, nullptr, nMis, nMis, w.vs.mis, w.vs.misHit, nullptr, ctr, wcPath, rayStats);
+            if (pixelStats) LaunchPixelStats(st, rayStats, w.vs.pendBeta, cur.mis, nullptr, nMis, nMis, rp.nPix, false, pixelStats);
+            HIP_TRY(hipEventRecord(b, st));
             evExt.push_back({a, b}); bt->extendRays += nMis; ++bt->extendLaunches;
             stats->rays += nMis;
-            evMisEnd = b;
         }
         activeQ = cur.next; active = nNext;
         // (maxDepth is bounded by CheckDepth, and no path outlives bounce maxDepth)
         if (active > 0 && bounce > rp.maxDepth) return SetError(HPRT_E_DEVICE, "internal error: paths are still active beyond maxdepth");
-        // the next bounce's path trace is enqueued BEFORE st waits for the shadow / MIS traces, so the three run together
-        if (active > 0) { int rc = tracePath(bounce + 1); if (rc != HPRT_OK) return rc; }
-        if (overlap && evShadowEnd) HIP_TRY(hipStreamWaitEvent(st, evShadowEnd, 0));
-        if (overlap && evMisEnd) HIP_TRY(hipStreamWaitEvent(st, evMisEnd, 0));
         if (nResolve) LaunchResolve(st, s->dev, w.vs, out.L, w.Lfinal, cur.resolve, cur.resolveCount, nResolve);
+        if (active > 0) { int rc = tracePath(bounce + 1); if (rc != HPRT_OK) return rc; }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
@@ -875,7 +860,6 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     rp.invSqrtSpp = 1 / std::sqrt((float)spp);      // ScaleDifferentials' factor, core/integrator.cpp:288-289
     const bool wantPixelStats = (desc->flags & HPRT_RENDER_PIXEL_STATS) != 0;
     const bool count = (desc->flags & HPRT_RENDER_COUNT_WORK) != 0 || wantPixelStats;
-    const bool overlap = !count && (desc->flags & HPRT_RENDER_OVERLAP_TRACES) != 0;
     // a counting render traces exactly the reference's rays (its counters are the reference's) unless asked to count what a plain render traces
     rp.cullMis = (!count || (desc->flags & HPRT_RENDER_COUNT_TRACED) != 0) && !(desc->flags & HPRT_RENDER_TRACE_ALL) ? 1 : 0;
     uint32_t *pixelStats = nullptr;
@@ -962,7 +946,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     EventTimer ev; BatchTimers bt;
     for (uint32_t s0 = 0; s0 < spp; s0 += chunk) {
         const uint32_t c = std::min(chunk, spp - s0), nSlots = c * nPix;
-        rc = RunBatch(s, st, rp, ps, qa, qb, bins, s0, nSlots, count, overlap, ev, &bt, stats, pixelStats);
+        rc = RunBatch(s, st, rp, ps, qa, qb, bins, s0, nSlots, count, ev, &bt, stats, pixelStats);
         if (rc != HPRT_OK) return rc;
         LaunchStoreRadiance(st, ps.Lfinal, LallR, LallG, LallB, nPix, s0, nSlots);
     }
@@ -988,7 +972,6 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     stats->extend_seconds = bt.extendMs * 1e-3; stats->occluded_seconds = bt.occludedMs * 1e-3;
     stats->extend_launches = bt.extendLaunches; stats->occluded_launches = bt.occludedLaunches;
     stats->extend_rays = bt.extendRays; stats->occluded_rays = bt.occludedRays;
-    stats->traces_overlapped = overlap ? 1 : 0;
     if (count) {
         DevCounters c;
         HIP_TRY(hipMemcpy(&c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
@@ -1046,7 +1029,7 @@ int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, c
     rp.maxDepth = opt->max_depth; rp.rrThreshold = opt->rr_threshold;
     rp.invSqrtSpp = 1 / std::sqrt((float)std::max(1, opt->spp)); rp.cullMis = 1;
     EventTimer ev; BatchTimers bt; HprtRenderStats stats; memset(&stats, 0, sizeof(stats));
-    rc = RunBatch(s, nullptr, rp, ps, qa, qb, bins, 0, (uint32_t)n, false, false, ev, &bt, &stats);
+    rc = RunBatch(s, nullptr, rp, ps, qa, qb, bins, 0, (uint32_t)n, false, ev, &bt, &stats);
     if (rc != HPRT_OK) return rc;
     float *LR = s->Lall.as<float>();
     LaunchStoreRadiance(nullptr, ps.Lfinal, LR, LR + n, LR + 2 * n, (uint32_t)n, 0, (uint32_t)n);

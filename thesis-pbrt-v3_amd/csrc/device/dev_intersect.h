@@ -206,7 +206,6 @@ __device__ __noinline__ bool sphere_test(const DevSphere &s, const DRay &r, DRay
 #define HPRT_SPILL_STACK 48
 // threads of the largest trace grid (256 CUs x 5 workgroups x 256 threads): stride of the deep-stack area, DevScene::deepStack
 #define HPRT_DEEP_THREADS 327680u
-#define HPRT_DEEP_REGIONS 3u        // one per concurrently running trace kernel (HPRT_RENDER_OVERLAP_TRACES)
 #ifndef HPRT_TRACE_BLOCK
 #define HPRT_TRACE_BLOCK 256
 #endif

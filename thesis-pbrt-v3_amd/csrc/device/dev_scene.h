@@ -81,7 +81,7 @@ struct DevScene {
     const DevInstance *instances; uint32_t nInstances;
     const float *lightFunc, *lightCdf; float lightFuncInt;      // Distribution1D (core/sampling.h:55-109)
     float worldRadius;                                           // DistantLight::Preprocess
-    uint2 *deepStack;                                            // traversal stack entries beyond the LDS ones: [region][entry][grid thread]
+    uint2 *deepStack;                                            // traversal stack entries beyond the LDS ones: [entry][grid thread]
     // Halton tables
     const uint16_t *perms; const int32_t *primes; const int32_t *primeSums; const uint64_t *primeMagic;
 };

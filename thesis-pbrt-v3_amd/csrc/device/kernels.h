@@ -72,7 +72,7 @@ struct FilmRecord { uint32_t dest, srcTile; float xyz[3]; float w; };
 
 void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
                  uint32_t countImm, uint32_t gridItems, const RayStream &rays, const HitStream &hits, uint8_t *occ,
-                 DevCounters *counters, uint32_t *workCounter, uint4 *rayStats = nullptr, uint32_t deepRegion = 0);
+                 DevCounters *counters, uint32_t *workCounter, uint4 *rayStats = nullptr);
 void LaunchPixelStats(hipStream_t st, const uint4 *rayStats, const float4 *ids, const uint32_t *queue, const uint32_t *countPtr,
                       uint32_t countImm, uint32_t gridItems, uint32_t nPix, bool anyHit, uint32_t *pix);
 void LaunchPixelStatsToFilm(hipStream_t st, const uint32_t *pix, const uint32_t *pixelXY, uint32_t nPix, uint32_t spp, int cx0, int cy0, int width,

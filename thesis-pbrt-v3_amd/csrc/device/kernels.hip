@@ -202,7 +202,7 @@ template <bool ANY_HIT, int MODE, bool INST, bool QUAD>
 __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ,
                                                             DevCounters *counters, uint4 *rayStats, uint32_t *workCounter, uint32_t chunk,
-                                                            TraceTune tune, uint32_t deepRegion) {
+                                                            TraceTune tune) {
     constexpr bool COUNT = MODE == 1, PROF = MODE == 2;
     // An any-hit ray's answer does not depend on the order of the walk (its tMax never shrinks, every primitive test is
     // independent of the others), so the plain any-hit kernel visits children in storage order and skips the re-test of
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
     // (volatile: keeps hipcc from folding the LDS and the HBM access into one access through a generic pointer)
     // (the address is formed where it is used: the pointer would otherwise hold two registers for the whole walk)
     auto deepSlot = [&](int entry) -> volatile unsigned long long * {
-        return (volatile unsigned long long *)sc.deepStack + ((size_t)deepRegion * HPRT_SPILL_STACK + (size_t)(entry - HPRT_LDS_STACK)) * HPRT_DEEP_THREADS + (blockIdx.x * HPRT_TRACE_BLOCK + threadIdx.x);
+        return (volatile unsigned long long *)sc.deepStack + (size_t)(entry - HPRT_LDS_STACK) * HPRT_DEEP_THREADS + (blockIdx.x * HPRT_TRACE_BLOCK + threadIdx.x);
     };
     bool moreWork = n > 0 && sc.nPairs > 0;
 
@@ -1122,7 +1122,7 @@ static inline uint32_t blocks_for(size_t n, uint32_t bs) { return (uint32_t)((n 
 
 void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
                  uint32_t countImm, uint32_t gridItems, const RayStream &rays, const HitStream &hits, uint8_t *occ,
-                 DevCounters *counters, uint32_t *workCounter, uint4 *rayStats, uint32_t deepRegion) {
+                 DevCounters *counters, uint32_t *workCounter, uint4 *rayStats) {
     if (gridItems == 0) return;
     (void)hipMemsetAsync(workCounter, 0, sizeof(uint32_t), st);
     // persistent waves: enough blocks to fill 256 CUs at this kernel's occupancy, never more than the rays need
@@ -1142,7 +1142,7 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     if (!anyHit && !tuneFromEnv && sc.nPairs > 100000u) { tune.parkLimit = 32; tune.stepLimit = 14; tune.primMin = 12; }      // (round-2 sweep, tools/sweep_tune.sh: atrium +3.6 %, living room +-0)
     static const bool profile = getenv("HPRT_TRACE_PROFILE") != nullptr;
     const bool inst = sc.nInstances != 0u, quad = sc.nSpheres != 0u;
-#define HPRT_TRACE_LAUNCH(A, M, I, Q) hipLaunchKernelGGL((k_trace<A, M, I, Q>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, rayStats, workCounter, chunk, tune, deepRegion)
+#define HPRT_TRACE_LAUNCH(A, M, I, Q) hipLaunchKernelGGL((k_trace<A, M, I, Q>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, rayStats, workCounter, chunk, tune)
     // (the profiling variant exists with the quadric code only)
 #define HPRT_TRACE_PICK(A, M) do { if (inst) { if (quad || M == 2) HPRT_TRACE_LAUNCH(A, M, true, true); else HPRT_TRACE_LAUNCH(A, M, true, (M == 2)); } \
                                    else { if (quad || M == 2) HPRT_TRACE_LAUNCH(A, M, false, true); else HPRT_TRACE_LAUNCH(A, M, false, (M == 2)); } } while (0)

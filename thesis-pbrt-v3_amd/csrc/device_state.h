@@ -56,9 +56,8 @@ struct HprtScene {
     // pixel, source tile), sorted by both; applied by hprt_film_gather on the root in the single-GPU order
     hprt::DevBuf foreignRecords, exGroupDest, exGroupTile; uint32_t nForeignRecords = 0; bool foreignExported = false;
     int filmW = 0, filmH = 0;
-    hipStream_t auxStream[2] = {nullptr, nullptr};    // shadow / MIS traces of a bounce run beside the next path trace (capi_device.hip: RunBatch)
     uint32_t *hostCounts = nullptr;                   // pinned
     size_t filmPixels = 0;
     uint32_t nPrims = 0;
-    ~HprtScene() { if (hostCounts) (void)hipHostFree(hostCounts); for (hipStream_t a : auxStream) if (a) (void)hipStreamDestroy(a); }
+    ~HprtScene() { if (hostCounts) (void)hipHostFree(hostCounts); }
 };
