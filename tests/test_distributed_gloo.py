@@ -1,11 +1,14 @@
-"""world_size-2 test of the tile-sharded Render + film gather on CPU (gloo).
+"""world_size-2 tests of the tile sharding + film merge on CPU (gloo).
 
-Each rank produces the film of ITS tiles (tiles r, r+2, ... of the 16x16 grid) and the
-films are summed onto rank 0 with thesis-pbrt-v3_amd/tiles.py::gather_film — the same
-helper bench.py uses over RCCL.  On this GPU-less box the per-rank film comes from the
-oracle's tile-subset render; the test proves the sharding + reduce reproduces the
-single-process film BIT FOR BIT, including pixels that receive box-filter samples from
-a neighbouring tile owned by the other rank."""
+What runs here, on a box without a GPU, is the SHARDING ARITHMETIC and the merge transport: each rank produces the film of
+its tiles (tiles r, r+2, ... of the 16x16 grid) and the films are merged onto rank 0 with thesis-pbrt-v3_amd/tiles.py.
+The per-rank films of the first test come from the ORACLE's tile-subset render (which merges its cross-tile contributions
+itself), so the product's `tile_begin/tile_stride` rendering and its exported cross-tile records are NOT exercised by
+it — those are covered on the GPU box: tests/test_gpu_parity.py renders the whole frame on 2, 3 and 4 ranks sharing the
+GPU (export_foreign + ordered record merge through this same gather_film) and through RCCL with the one rank a 1-GPU box
+allows; multi-GPU RCCL itself runs only in the driver's SCALE bench.  The second test drives the product's ordered merge
+of records (hprt_film_records_merge) through gloo with synthetic per-rank films, including a pixel that receives
+contributions from three other ranks."""
 import importlib
 import os
 import socket
@@ -77,3 +80,60 @@ def test_shard_covers_every_tile_once():
             sh = tiles.shard(r, world)
             seen += list(range(sh["tile_begin"], 1936, sh["tile_stride"]))
         assert sorted(seen) == list(range(1936))
+
+
+def _records_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    hprt = importlib.import_module("thesis-pbrt-v3_amd")
+    tiles = importlib.import_module("thesis-pbrt-v3_amd.tiles")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # 4 x 4 film, pixel p owned by rank p % world; every rank contributes one record to pixel 5 (owner: rank 1) and some to others
+    film = np.zeros((4, 4, 4), np.float32)
+    for p in range(16):
+        if p % world == rank:
+            film.reshape(-1, 4)[p] = [0.1 * (p + 1), 0.2 * (p + 1), 0.3 * (p + 1), 8.0]
+    rec = np.zeros(2, hprt.FILM_RECORD)
+    rec["dest_pixel"] = [5, (rank + 7) % 16]; rec["src_tile"] = [100 - rank, 3 * rank]
+    rec["xyz"] = [[1e-3 * (rank + 1), [1e8, 3.3, -1e8, 7.7][rank], 0.5], [0.25, 0.25, 0.25]]; rec["weight"] = [1, 2]
+    t = torch.from_numpy(film)
+    tiles.gather_film(t, dist, dst=0, records=rec)
+    if rank == 0:
+        np.save(out_path, t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ordered_record_merge_through_gloo(tmp_path, hprt):
+    """tiles.gather_film with records: reduce(SUM) of disjoint films + gather of every rank's cross-tile records + the
+    product's ordered merge on the root (per destination pixel in ascending source-tile order, whatever rank they came
+    from): float addition is not associative, so the expected film is built here in exactly that order."""
+    world = 4
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "merged.npy")
+    mp.spawn(_records_worker, args=(world, port, out), nprocs=world, join=True)
+    got = np.load(out)
+    want = np.zeros((16, 4), np.float32)
+    for p in range(16):
+        want[p] = np.array([0.1 * (p + 1), 0.2 * (p + 1), 0.3 * (p + 1), 8.0], np.float32)
+    recs = []
+    for rank in range(world):
+        recs.append((5, 100 - rank, [1e-3 * (rank + 1), [1e8, 3.3, -1e8, 7.7][rank], 0.5], 1.0))
+        recs.append(((rank + 7) % 16, 3 * rank, [0.25, 0.25, 0.25], 2.0))
+    for dest, tile, xyz, w in sorted(recs, key=lambda r: (r[0], r[1])):
+        want[dest, :3] = want[dest, :3] + np.array(xyz, np.float32)
+        want[dest, 3] = want[dest, 3] + np.float32(w)
+    assert np.array_equal(got.reshape(16, 4).view(np.uint32), want.view(np.uint32))
+    # and the order matters: the reverse order gives a different float in the large-magnitude channel
+    rev = np.zeros(4, np.float32); rev[:] = [0.6, 1.2, 1.8, 8.0]
+    for dest, tile, xyz, w in sorted([r for r in recs if r[0] == 5], key=lambda r: -r[1]):
+        rev[:3] = rev[:3] + np.array(xyz, np.float32)
+    assert not np.array_equal(rev[:3].view(np.uint32), want[5, :3].view(np.uint32))
+
+
+def test_bench_refuses_a_mislabelled_world_size():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "refusing" in r.stderr

@@ -526,3 +526,40 @@ def test_living_room_fixture_builds_the_same_bvh_on_both_sides(hprt, orc):
     assert np.array_equal(n1, n2) and np.array_equal(o1, o2)
     info = bvh.info()
     assert (info["nodes"], info["leaves"], info["max_depth"]) == (233709, 116855, 26)
+
+
+def test_corrupt_and_truncated_inputs_are_refused_not_fatal(hprt, tmp_path):
+    """No exception crosses the C ABI and no reader allocates for a size the file cannot hold: truncated and
+    corrupted .hprt / .ply inputs come back as error codes with a message."""
+    import struct
+    from conftest import KILLEROO
+    blob = open(KILLEROO, "rb").read()
+    cases = {"cut_header": blob[:60], "cut_mesh": blob[:len(blob) // 2], "bad_magic": b"XPRTSCN1" + blob[8:]}
+    for name, data in cases.items():
+        p = tmp_path / (name + ".hprt"); p.write_bytes(data)
+        with pytest.raises(hprt.HprtError) as e:
+            hprt.Model.load(str(p))
+        assert e.value.code in (hprt.E_IO, hprt.E_INVALID), name
+    # every 4-byte word of the header region replaced by 0x7fffffff in turn: each must be refused or load cleanly, never crash
+    for off in range(8, 400, 4):
+        data = bytearray(blob); data[off:off + 4] = struct.pack("<I", 0x7fffffff)
+        p = tmp_path / "fuzz.hprt"; p.write_bytes(bytes(data))
+        try:
+            m = hprt.Model.load(str(p))
+            del m
+        except hprt.HprtError as e:
+            assert e.code in (hprt.E_IO, hprt.E_INVALID)
+    # PLY: negative / absurd element counts, absurd face-list counts, truncation
+    def scene_with(ply_bytes):
+        (tmp_path / "m.ply").write_bytes(ply_bytes)
+        s = tmp_path / "s.pbrt"
+        s.write_text('Camera "perspective"\nWorldBegin\nShape "plymesh" "string filename" "m.ply"\nWorldEnd\n')
+        return str(s)
+    head = b"ply\nformat binary_little_endian 1.0\nelement vertex %s\nproperty float x\nproperty float y\nproperty float z\nelement face %s\nproperty list uchar int vertex_indices\nend_header\n"
+    good = head % (b"3", b"1") + struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + struct.pack("<B3i", 3, 0, 1, 2)
+    assert hprt.Model.parse(scene_with(good)).counts()["triangles"] == 1
+    for bad in (head % (b"-5", b"1") + good[-49:], head % (b"900000000000", b"1") + good[-49:], head % (b"3", b"1") + good[-49:-13],
+                head % (b"3", b"1") + struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + struct.pack("<B", 200),
+                head % (b"3", b"77777") + good[-49:]):
+        with pytest.raises(hprt.HprtError):
+            hprt.Model.parse(scene_with(bad))

@@ -68,11 +68,13 @@ def test_triangle_watertight_through_hprt_intersect(hprt, orc):
     scene, nodes, order = _one_shape_scene(hprt, sh, tri.min(axis=1), tri.max(axis=1))
     t, prim, bary = scene.intersect(o, d, np.full(2 * n_iter, np.inf, np.float32))
     assert (prim >= 0).all(), "%d of %d rays slipped through the mesh" % (int((prim < 0).sum()), 2 * n_iter)
-    # The BVH walk finds the closest distance of testing every triangle — up to one ulp at shared vertices: the triangles around a
-    # vertex report distances one ulp apart, and once the walk holds one of them, the node of a neighbour whose box entry distance
-    # rounds to >= that tMax is culled (tMin < ray.tMax, core/geometry.h:1779), as in the reference's BVHAccel.
+    # The BVH walk finds the closest distance of testing every triangle in index order — up to an ulp or two at shared vertices:
+    # the triangles around a vertex report distances an ulp apart, and which of them survives depends on the visiting order in
+    # both walks (a later candidate is compared through tScaled > tMax * det, shapes/triangle.cpp:259-262, and a node whose
+    # entry distance rounds to >= tMax is culled, core/geometry.h:1779) — the order-exact comparison against the oracle's BVH
+    # walk is test_gpu_parity.py's job.
     same = t.view(np.uint32) == t_brute.view(np.uint32)
-    assert same.mean() > 0.7 and (t >= t_brute).all() and (np.abs(t - t_brute) <= 1.2e-7 * t_brute).all(), (float(same.mean()), float(np.abs(t - t_brute).max()))
+    assert same.mean() > 0.7 and (np.abs(t - t_brute) <= 2.4e-7 * t_brute).all(), (float(same.mean()), float(np.abs(t - t_brute).max()))
     occ = scene.occluded(o, d, np.full(2 * n_iter, np.inf, np.float32))
     assert occ.all()
     del scene

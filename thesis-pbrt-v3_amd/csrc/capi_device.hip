@@ -178,11 +178,12 @@ void AddTilePixels(FrameSetup *f, int tile) {
 
 extern "C" {
 
-int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
+int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     if (!d || !out) return SetError(HPRT_E_INVALID, "hprt_scene_create: null argument");
     if ((d->n_nodes && !d->nodes) || (d->n_prims && !d->prim_order) || (d->n_shapes && !d->shapes) ||
         (d->n_materials && !d->materials) || (d->n_lights && !d->lights))
         return SetError(HPRT_E_INVALID, "hprt_scene_create: null array with non-zero count");
+    if (d->n_textures && !d->textures) return SetError(HPRT_E_INVALID, "hprt_scene_create: null texture array with non-zero count");
     if ((d->n_objects && !d->objects) || (d->n_instances && !d->instances) || (d->n_top && !d->top))
         return SetError(HPRT_E_INVALID, "hprt_scene_create: null instancing array with non-zero count");
     // ---- validate the description against what the kernels assume ----
@@ -494,9 +495,9 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) {
     HIP_TRY(hipHostMalloc((void **)&sc->hostCounts, (4096 + 256) * sizeof(uint32_t)));
     *out = guard.release();
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
-int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int device, HprtScene **out) {
+int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int device, HprtScene **out) try {
     if (!m || !b || !out) return SetError(HPRT_E_INVALID, "hprt_scene_create_from_model: null argument");
     const SceneModel &sm = m->sc;
     std::vector<HprtShapeDesc> shapes(sm.shapes.size());
@@ -574,7 +575,7 @@ int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int devic
     // a single light always gets the uniform distribution (core/lightdistrib.cpp:50-52)
     d.light_strategy = sm.lights.size() <= 1 ? 0 : sm.opt.lightStrategy;
     return hprt_scene_create(&d, device, out);
-}
+} catch (...) { return hprt::HandleException(); }
 
 void hprt_scene_destroy(HprtScene *s) {
     if (!s) return;
@@ -600,7 +601,7 @@ static int ApiStreams(HprtScene *s, size_t n, RayStream *rays, HitStream *hits) 
     return HPRT_OK;
 }
 
-int hprt_intersect_device(HprtScene *s, size_t n, const float *d_rays7, float *d_t, int32_t *d_prim, float *d_bary3, void *stream) {
+int hprt_intersect_device(HprtScene *s, size_t n, const float *d_rays7, float *d_t, int32_t *d_prim, float *d_bary3, void *stream) try {
     if (!s || (n && (!d_rays7 || !d_t || !d_prim))) return SetError(HPRT_E_INVALID, "hprt_intersect_device: null argument");
     if (n > 0x7ffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
     if (n == 0) return HPRT_OK;
@@ -614,8 +615,8 @@ int hprt_intersect_device(HprtScene *s, size_t n, const float *d_rays7, float *d
     LaunchUnpackHits(st, hits, (uint32_t)n, d_t, d_prim, d_bary3);
     HIP_TRY(hipGetLastError());
     return HPRT_OK;
-}
-int hprt_occluded_device(HprtScene *s, size_t n, const float *d_rays7, uint8_t *d_occ, void *stream) {
+} catch (...) { return hprt::HandleException(); }
+int hprt_occluded_device(HprtScene *s, size_t n, const float *d_rays7, uint8_t *d_occ, void *stream) try {
     if (!s || (n && (!d_rays7 || !d_occ))) return SetError(HPRT_E_INVALID, "hprt_occluded_device: null argument");
     if (n > 0x7ffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
     if (n == 0) return HPRT_OK;
@@ -629,7 +630,7 @@ int hprt_occluded_device(HprtScene *s, size_t n, const float *d_rays7, uint8_t *
     LaunchTrace(st, s->dev, true, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, rays, none, d_occ, nullptr, s->workCounter.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
 static int TraceHost(HprtScene *s, bool anyHit, size_t n, const float *o, const float *d, const float *tmax, float *t_out,
                      int32_t *prim_out, int32_t *inst_out, float *bary_out, uint8_t *occ_out, uint64_t counters[4]) {
@@ -673,16 +674,16 @@ static int TraceHost(HprtScene *s, bool anyHit, size_t n, const float *o, const 
     return HPRT_OK;
 }
 int hprt_intersect(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, float *t_out, int32_t *prim_out,
-                   float *bary_out, uint64_t counters[4]) {
+                   float *bary_out, uint64_t counters[4]) try {
     return TraceHost(s, false, n, o, d, tmax, t_out, prim_out, nullptr, bary_out, nullptr, counters);
-}
+} catch (...) { return hprt::HandleException(); }
 int hprt_intersect_instanced(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, float *t_out, int32_t *prim_out,
-                             int32_t *inst_out, float *bary_out, uint64_t counters[4]) {
+                             int32_t *inst_out, float *bary_out, uint64_t counters[4]) try {
     return TraceHost(s, false, n, o, d, tmax, t_out, prim_out, inst_out, bary_out, nullptr, counters);
-}
-int hprt_occluded(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, uint8_t *occ, uint64_t counters[4]) {
+} catch (...) { return hprt::HandleException(); }
+int hprt_occluded(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, uint8_t *occ, uint64_t counters[4]) try {
     return TraceHost(s, true, n, o, d, tmax, nullptr, nullptr, nullptr, nullptr, occ, counters);
-}
+} catch (...) { return hprt::HandleException(); }
 
 // ---------------------------------------------------------------------------
 // Render
@@ -794,7 +795,7 @@ struct ExtraEntry { uint32_t dest; uint32_t srcTile; uint32_t srcPos; uint32_t s
 
 }  // namespace
 
-int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, void *stream, HprtRenderStats *stats) {
+int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, void *stream, HprtRenderStats *stats) try {
     if (!s || !desc) return SetError(HPRT_E_INVALID, "hprt_render: null argument");
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
@@ -979,27 +980,27 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
         stats->nodes_fetched_p = c.nodesFetchedP; stats->nodes_entered_p = c.nodesEnteredP; stats->tri_tests_p = c.triTestsP; stats->sphere_tests_p = c.sphereTestsP;
     }
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
 // Pixel::stats of the last hprt_render with HPRT_RENDER_PIXEL_STATS (core/film.h:91): 7 values per film pixel
-int hprt_pixel_stats_read(HprtScene *s, uint64_t *out7, size_t n_pixels) {
+int hprt_pixel_stats_read(HprtScene *s, uint64_t *out7, size_t n_pixels) try {
     if (!s || !out7) return SetError(HPRT_E_INVALID, "hprt_pixel_stats_read: null argument");
     if (!s->pixelStatsValid) return SetError(HPRT_E_INVALID, "no per-pixel statistics: render with HPRT_RENDER_PIXEL_STATS first");
     if (n_pixels != s->filmPixels) return SetError(HPRT_E_INVALID, "hprt_pixel_stats_read: pixel count differs from the last render's film");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemcpy(out7, s->pixelStatsFilm.p, 7 * n_pixels * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return HPRT_OK;
-}
-int hprt_film_read(HprtScene *s, float *xyzw_out, size_t n_pixels) {
+} catch (...) { return hprt::HandleException(); }
+int hprt_film_read(HprtScene *s, float *xyzw_out, size_t n_pixels) try {
     if (!s || !xyzw_out) return SetError(HPRT_E_INVALID, "hprt_film_read: null argument");
     if (!s->film.p || n_pixels != s->filmPixels) return SetError(HPRT_E_INVALID, "hprt_film_read: no library-owned film of that size (render with d_film_xyzw == NULL first)");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemcpy(xyzw_out, s->film.p, 16 * n_pixels, hipMemcpyDeviceToHost));
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
 int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, const int32_t *px, const int32_t *py, const int64_t *sample,
-                         float *L_out) {
+                         float *L_out) try {
     if (!s || !opt || (n && (!px || !py || !sample || !L_out))) return SetError(HPRT_E_INVALID, "hprt_sample_radiance: null argument");
     if (n == 0) return HPRT_OK;
     if (n > (1u << 26)) return SetError(HPRT_E_INVALID, "hprt_sample_radiance: too many samples in one call");
@@ -1038,6 +1039,6 @@ int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, c
     HIP_TRY(hipMemcpy(planes.data(), LR, 12 * n, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; ++i) { L_out[3 * i] = planes[i]; L_out[3 * i + 1] = planes[n + i]; L_out[3 * i + 2] = planes[2 * n + i]; }
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
 }  // extern "C"

@@ -79,7 +79,7 @@ int CheckGatherable(const HprtScene *s, size_t nPixels) {
 
 extern "C" {
 
-int hprt_comm_unique_id(uint8_t id[HPRT_COMM_ID_BYTES]) {
+int hprt_comm_unique_id(uint8_t id[HPRT_COMM_ID_BYTES]) try {
     if (!id) return SetError(HPRT_E_INVALID, "hprt_comm_unique_id: null argument");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SetError(HPRT_E_NO_DEVICE, "no HIP device available (hprt has no CPU fallback)");
@@ -87,9 +87,9 @@ int hprt_comm_unique_id(uint8_t id[HPRT_COMM_ID_BYTES]) {
     NCCL_TRY(ncclGetUniqueId(&u));
     memcpy(id, &u, sizeof(u));
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
-int hprt_comm_create(const uint8_t id[HPRT_COMM_ID_BYTES], int rank, int n_ranks, int device, HprtComm **out) {
+int hprt_comm_create(const uint8_t id[HPRT_COMM_ID_BYTES], int rank, int n_ranks, int device, HprtComm **out) try {
     if (!id || !out) return SetError(HPRT_E_INVALID, "hprt_comm_create: null argument");
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return SetError(HPRT_E_INVALID, "hprt_comm_create: rank outside [0, n_ranks)");
     int n = 0;
@@ -106,9 +106,9 @@ int hprt_comm_create(const uint8_t id[HPRT_COMM_ID_BYTES], int rank, int n_ranks
     HIP_TRY(hipHostMalloc((void **)&c->hostCounts, ((size_t)n_ranks + 1) * sizeof(uint32_t)));
     *out = c.release();
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
-int hprt_comm_info(const HprtComm *c, int *rank, int *n_ranks, int *device) {
+int hprt_comm_info(const HprtComm *c, int *rank, int *n_ranks, int *device) try {
     if (!c) return SetError(HPRT_E_INVALID, "hprt_comm_info: null argument");
     // what the communicator itself reports, not what the caller passed in
     int r = -1, n = -1, d = -1;
@@ -119,7 +119,7 @@ int hprt_comm_info(const HprtComm *c, int *rank, int *n_ranks, int *device) {
     if (n_ranks) *n_ranks = n;
     if (device) *device = d;
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
 void hprt_comm_destroy(HprtComm *c) {
     if (!c) return;
@@ -127,7 +127,7 @@ void hprt_comm_destroy(HprtComm *c) {
     delete c;
 }
 
-int hprt_film_gather(HprtComm *c, HprtScene *s, float *d_film_xyzw, size_t n_pixels, int root, void *stream) {
+int hprt_film_gather(HprtComm *c, HprtScene *s, float *d_film_xyzw, size_t n_pixels, int root, void *stream) try {
     if (!c || !s) return SetError(HPRT_E_INVALID, "hprt_film_gather: null argument");
     if (root < 0 || root >= c->nRanks) return SetError(HPRT_E_INVALID, "hprt_film_gather: root outside the communicator");
     if (s->device != c->device) return SetError(HPRT_E_INVALID, "hprt_film_gather: scene and communicator live on different devices");
@@ -168,9 +168,9 @@ int hprt_film_gather(HprtComm *c, HprtScene *s, float *d_film_xyzw, size_t n_pix
     if (total) HIP_TRY(hipMemcpyAsync(rec.data(), c->staging.p, total * sizeof(FilmRecord), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return ApplyRecords(rec, film, n_pixels, c->staging, c->destBegin, st);
-}
+} catch (...) { return hprt::HandleException(); }
 
-int hprt_film_gather_local(HprtScene *const *per_gpu, float *const *d_films, int n, size_t n_pixels, int root) {
+int hprt_film_gather_local(HprtScene *const *per_gpu, float *const *d_films, int n, size_t n_pixels, int root) try {
     if (!per_gpu || n < 1 || root < 0 || root >= n) return SetError(HPRT_E_INVALID, "hprt_film_gather_local: bad argument");
     std::vector<int> devs(n);
     std::vector<float *> films(n);
@@ -213,9 +213,9 @@ int hprt_film_gather_local(HprtScene *const *per_gpu, float *const *d_films, int
     }
     HIP_TRY(hipSetDevice(devs[root]));
     return ApplyRecords(rec, films[root], n_pixels, cl->recBuf, cl->beginBuf, nullptr);
-}
+} catch (...) { return hprt::HandleException(); }
 
-int hprt_film_records_read(HprtScene *s, HprtFilmRecord *out, size_t capacity, size_t *n_records) {
+int hprt_film_records_read(HprtScene *s, HprtFilmRecord *out, size_t capacity, size_t *n_records) try {
     if (!s || !n_records) return SetError(HPRT_E_INVALID, "hprt_film_records_read: null argument");
     if (!s->foreignExported) return SetError(HPRT_E_INVALID, "hprt_film_records_read: the last render did not set HPRT_RENDER_EXPORT_FOREIGN");
     *n_records = s->nForeignRecords;
@@ -225,6 +225,6 @@ int hprt_film_records_read(HprtScene *s, HprtFilmRecord *out, size_t capacity, s
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, s->foreignRecords.p, (size_t)s->nForeignRecords * sizeof(FilmRecord), hipMemcpyDeviceToHost));
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
 }  // extern "C"

@@ -2,6 +2,8 @@
 // BVH build, Halton tables, film resolve, PFM writer.  No HIP calls here; the
 // device half lives in capi_device.hip.
 #include <algorithm>
+#include <new>
+#include <stdexcept>
 #include <cmath>
 #include <limits>
 #include <vector>
@@ -21,6 +23,14 @@ using namespace hprt;
 namespace hprt {
 thread_local std::string g_lastError;
 int SetError(int code, const std::string &msg) { g_lastError = msg; return code; }
+// No exception crosses the C ABI: every exported function that can allocate or parse is a function-try-block that ends here.
+int HandleException() {
+    try { throw; }
+    catch (const std::bad_alloc &) { return SetError(HPRT_E_INVALID, "out of memory (or a size in the input that cannot be real)"); }
+    catch (const std::length_error &e) { return SetError(HPRT_E_INVALID, std::string("a size in the input cannot be real: ") + e.what()); }
+    catch (const std::exception &e) { return SetError(HPRT_E_INVALID, std::string("unexpected exception: ") + e.what()); }
+    catch (...) { return SetError(HPRT_E_INVALID, "unexpected exception"); }
+}
 }  // namespace hprt
 
 extern "C" {
@@ -28,7 +38,7 @@ extern "C" {
 const char *hprt_last_error(void) { return g_lastError.c_str(); }
 const char *hprt_version(void) { return "hprt 0.1 gfx950 (HIP, wave64) host+device"; }
 
-int hprt_model_parse(const char *pbrt_path, const char *const *subst, int n_subst, HprtModel **out) {
+int hprt_model_parse(const char *pbrt_path, const char *const *subst, int n_subst, HprtModel **out) try {
     if (!pbrt_path || !out) return SetError(HPRT_E_INVALID, "hprt_model_parse: null argument");
     std::map<std::string, std::string> sm;
     sm["$acc"] = "\"bvh\"";
@@ -41,24 +51,24 @@ int hprt_model_parse(const char *pbrt_path, const char *const *subst, int n_subs
     if (m->sc.opt.sampler != "halton") m->sc.warnings.push_back("Sampler \"" + m->sc.opt.sampler + "\" is outside the hot-path scope; \"halton\" used");
     *out = m;
     return HPRT_OK;
-}
-int hprt_model_load(const char *baked_path, HprtModel **out) {
+} catch (...) { return hprt::HandleException(); }
+int hprt_model_load(const char *baked_path, HprtModel **out) try {
     if (!baked_path || !out) return SetError(HPRT_E_INVALID, "hprt_model_load: null argument");
     HprtModel *m = new HprtModel();
     std::string err;
     if (!LoadBakedScene(baked_path, &m->sc, &err)) { delete m; return SetError(HPRT_E_IO, err); }
     *out = m;
     return HPRT_OK;
-}
-int hprt_model_save(const HprtModel *m, const char *baked_path) {
+} catch (...) { return hprt::HandleException(); }
+int hprt_model_save(const HprtModel *m, const char *baked_path) try {
     if (!m || !baked_path) return SetError(HPRT_E_INVALID, "hprt_model_save: null argument");
     std::string err;
     if (!SaveBakedScene(m->sc, baked_path, &err)) return SetError(HPRT_E_IO, err);
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 void hprt_model_destroy(HprtModel *m) { delete m; }
 
-int hprt_model_get_options(const HprtModel *m, HprtRenderOptions *o) {
+int hprt_model_get_options(const HprtModel *m, HprtRenderOptions *o) try {
     if (!m || !o) return SetError(HPRT_E_INVALID, "hprt_model_get_options: null argument");
     const RenderOptions &p = m->sc.opt;
     o->xres = p.xres; o->yres = p.yres;
@@ -72,8 +82,8 @@ int hprt_model_get_options(const HprtModel *m, HprtRenderOptions *o) {
     o->max_depth = p.maxDepth; o->rr_threshold = p.rrThreshold; o->light_strategy = p.lightStrategy;
     o->max_node_prims = p.maxNodePrims; o->isect_cost = p.isectCost; o->trav_cost = p.travCost;
     return HPRT_OK;
-}
-int hprt_model_set_options(HprtModel *m, const HprtRenderOptions *o) {
+} catch (...) { return hprt::HandleException(); }
+int hprt_model_set_options(HprtModel *m, const HprtRenderOptions *o) try {
     if (!m || !o) return SetError(HPRT_E_INVALID, "hprt_model_set_options: null argument");
     if (o->xres <= 0 || o->yres <= 0 || o->spp <= 0) return SetError(HPRT_E_INVALID, "resolution and spp must be positive");
     RenderOptions &p = m->sc.opt;
@@ -88,30 +98,30 @@ int hprt_model_set_options(HprtModel *m, const HprtRenderOptions *o) {
     p.maxDepth = o->max_depth; p.rrThreshold = o->rr_threshold; p.lightStrategy = o->light_strategy;
     p.maxNodePrims = o->max_node_prims; p.isectCost = o->isect_cost; p.travCost = o->trav_cost;
     return HPRT_OK;
-}
-int hprt_model_counts(const HprtModel *m, uint64_t c[7]) {
+} catch (...) { return hprt::HandleException(); }
+int hprt_model_counts(const HprtModel *m, uint64_t c[7]) try {
     if (!m || !c) return SetError(HPRT_E_INVALID, "hprt_model_counts: null argument");
     uint64_t tris = 0, spheres = 0;
     for (const ShapeDesc &s : m->sc.shapes) { if (s.kind == kTriangleMesh) tris += s.mesh.nTris(); else ++spheres; }
     c[0] = m->sc.shapes.size(); c[1] = tris + spheres; c[2] = tris; c[3] = spheres;
     c[4] = m->sc.materials.size(); c[5] = m->sc.lights.size(); c[6] = m->sc.textures.size();
     return HPRT_OK;
-}
-int hprt_model_texture_info(const HprtModel *m, uint32_t texture, int32_t info[5], float *max_anisotropy) {
+} catch (...) { return hprt::HandleException(); }
+int hprt_model_texture_info(const HprtModel *m, uint32_t texture, int32_t info[5], float *max_anisotropy) try {
     if (!m || !info || texture >= m->sc.textures.size()) return SetError(HPRT_E_INVALID, "hprt_model_texture_info: bad argument");
     const TextureDesc &t = m->sc.textures[texture];
     info[0] = (int32_t)t.levels.size(); info[1] = t.trilinear; info[2] = t.wrap; info[3] = t.levels[0].w; info[4] = t.levels[0].h;
     if (max_anisotropy) *max_anisotropy = t.maxAniso;
     return HPRT_OK;
-}
-int hprt_model_texture_level(const HprtModel *m, uint32_t texture, uint32_t level, int32_t wh[2], float *rgb) {
+} catch (...) { return hprt::HandleException(); }
+int hprt_model_texture_level(const HprtModel *m, uint32_t texture, uint32_t level, int32_t wh[2], float *rgb) try {
     if (!m || !wh || texture >= m->sc.textures.size() || level >= m->sc.textures[texture].levels.size())
         return SetError(HPRT_E_INVALID, "hprt_model_texture_level: bad argument");
     const MipLevel &l = m->sc.textures[texture].levels[level];
     wh[0] = l.w; wh[1] = l.h;
     if (rgb) memcpy(rgb, l.rgb.data(), 4 * l.rgb.size());
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 const char *hprt_model_warnings(const HprtModel *m) {
     static thread_local std::string buf;
     buf.clear();
@@ -119,7 +129,7 @@ const char *hprt_model_warnings(const HprtModel *m) {
     return buf.c_str();
 }
 
-int hprt_bvh_build(const HprtModel *m, HprtBvh **out) {
+int hprt_bvh_build(const HprtModel *m, HprtBvh **out) try {
     if (!m || !out) return SetError(HPRT_E_INVALID, "hprt_bvh_build: null argument");
     std::vector<float> lo, hi;
     HprtBvh *b = new HprtBvh();
@@ -132,18 +142,18 @@ int hprt_bvh_build(const HprtModel *m, HprtBvh **out) {
     BuildBvh(lo.size() / 3, lo.data(), hi.data(), m->sc.opt.maxNodePrims, m->sc.opt.isectCost, m->sc.opt.travCost, &b->tree);
     *out = b;
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 int hprt_bvh_build_from_bounds(size_t n, const float *bmin, const float *bmax, int maxNodePrims, int isectCost, int travCost,
-                               HprtBvh **out) {
+                               HprtBvh **out) try {
     if (!out || (n && (!bmin || !bmax))) return SetError(HPRT_E_INVALID, "hprt_bvh_build_from_bounds: null argument");
     if (n > 0x7fffffffull) return SetError(HPRT_E_UNSUPPORTED, "more than 2^31 primitives");
     HprtBvh *b = new HprtBvh();
     BuildBvh(n, bmin, bmax, maxNodePrims, isectCost, travCost, &b->tree);
     *out = b;
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 void hprt_bvh_destroy(HprtBvh *b) { delete b; }
-int hprt_bvh_info(const HprtBvh *b, uint32_t info[4], float bounds6[6]) {
+int hprt_bvh_info(const HprtBvh *b, uint32_t info[4], float bounds6[6]) try {
     if (!b || !info) return SetError(HPRT_E_INVALID, "hprt_bvh_info: null argument");
     info[0] = (uint32_t)b->tree.nodes.size(); info[1] = (uint32_t)b->tree.primOrder.size();
     info[2] = (uint32_t)b->tree.nLeaves; info[3] = (uint32_t)b->tree.maxDepth;
@@ -152,15 +162,15 @@ int hprt_bvh_info(const HprtBvh *b, uint32_t info[4], float bounds6[6]) {
         else { memcpy(bounds6, b->tree.nodes[0].bmin, 12); memcpy(bounds6 + 3, b->tree.nodes[0].bmax, 12); }
     }
     return HPRT_OK;
-}
-int hprt_bvh_copy(const HprtBvh *b, void *nodes32, uint32_t *prim_order) {
+} catch (...) { return hprt::HandleException(); }
+int hprt_bvh_copy(const HprtBvh *b, void *nodes32, uint32_t *prim_order) try {
     if (!b) return SetError(HPRT_E_INVALID, "hprt_bvh_copy: null argument");
     if (nodes32 && !b->tree.nodes.empty()) memcpy(nodes32, b->tree.nodes.data(), b->tree.nodes.size() * sizeof(BvhNode));
     if (prim_order && !b->tree.primOrder.empty()) memcpy(prim_order, b->tree.primOrder.data(), b->tree.primOrder.size() * 4);
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
-int hprt_bvh_object_info(const HprtBvh *b, uint32_t object, uint32_t info[4], float bounds6[6]) {
+int hprt_bvh_object_info(const HprtBvh *b, uint32_t object, uint32_t info[4], float bounds6[6]) try {
     if (!b || !info || object >= b->objects.size()) return SetError(HPRT_E_INVALID, "hprt_bvh_object_info: bad argument");
     const BvhTree &t = b->objects[object];
     info[0] = (uint32_t)t.nodes.size(); info[1] = (uint32_t)t.primOrder.size(); info[2] = (uint32_t)t.nLeaves; info[3] = (uint32_t)t.maxDepth;
@@ -169,24 +179,24 @@ int hprt_bvh_object_info(const HprtBvh *b, uint32_t object, uint32_t info[4], fl
         else { memcpy(bounds6, t.nodes[0].bmin, 12); memcpy(bounds6 + 3, t.nodes[0].bmax, 12); }
     }
     return HPRT_OK;
-}
-int hprt_bvh_object_copy(const HprtBvh *b, uint32_t object, void *nodes32, uint32_t *prim_order) {
+} catch (...) { return hprt::HandleException(); }
+int hprt_bvh_object_copy(const HprtBvh *b, uint32_t object, void *nodes32, uint32_t *prim_order) try {
     if (!b || object >= b->objects.size()) return SetError(HPRT_E_INVALID, "hprt_bvh_object_copy: bad argument");
     const BvhTree &t = b->objects[object];
     if (nodes32 && !t.nodes.empty()) memcpy(nodes32, t.nodes.data(), t.nodes.size() * sizeof(BvhNode));
     if (prim_order && !t.primOrder.empty()) memcpy(prim_order, t.primOrder.data(), t.primOrder.size() * 4);
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
-int hprt_halton_permutations(uint16_t *out, size_t max_entries, size_t *n_entries) {
+int hprt_halton_permutations(uint16_t *out, size_t max_entries, size_t *n_entries) try {
     const std::vector<uint16_t> &p = HaltonPermutations();
     if (n_entries) *n_entries = p.size();
     if (out) memcpy(out, p.data(), 2 * (p.size() < max_entries ? p.size() : max_entries));
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
 // Film::WriteImage, core/film.cpp:266-303 (no splats)
-int hprt_film_resolve(const float *xyzw, size_t n, float scale, float *rgb) {
+int hprt_film_resolve(const float *xyzw, size_t n, float scale, float *rgb) try {
     if (!xyzw || !rgb) return SetError(HPRT_E_INVALID, "hprt_film_resolve: null argument");
     for (size_t i = 0; i < n; ++i) {
         const float *x = &xyzw[4 * i];
@@ -204,10 +214,10 @@ int hprt_film_resolve(const float *xyzw, size_t n, float scale, float *rgb) {
         o[0] *= scale; o[1] *= scale; o[2] *= scale;
     }
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
 // Film::WriteGeneralStatMatrix, core/film.cpp:189-210: "<file minus extension>-<name>.txt", one image row per line
-int hprt_write_pixel_stats(const char *prefix, const uint64_t *stats7, int width, int height) {
+int hprt_write_pixel_stats(const char *prefix, const uint64_t *stats7, int width, int height) try {
     if (!prefix || !stats7 || width <= 0 || height <= 0) return SetError(HPRT_E_INVALID, "hprt_write_pixel_stats: bad argument");
     // the matrices Film::WriteGeneralStats writes (core/film.cpp:170-187), with the index of the value in stats7 (-1: zero for a BVH render)
     static const struct { const char *name; int field; } kMatrices[] = {
@@ -229,10 +239,10 @@ int hprt_write_pixel_stats(const char *prefix, const uint64_t *stats7, int width
         if (!ok) return SetError(HPRT_E_IO, "write error on " + path);
     }
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
 // WritePFM, core/imageio.cpp:437+ : "PF", width height, scale -1 (little endian), rows bottom to top
-int hprt_write_pfm(const char *path, const float *rgb, int width, int height) {
+int hprt_write_pfm(const char *path, const float *rgb, int width, int height) try {
     if (!path || !rgb || width <= 0 || height <= 0) return SetError(HPRT_E_INVALID, "hprt_write_pfm: bad argument");
     FILE *fp = fopen(path, "wb");
     if (!fp) return SetError(HPRT_E_IO, std::string("cannot create ") + path);
@@ -240,11 +250,11 @@ int hprt_write_pfm(const char *path, const float *rgb, int width, int height) {
     for (int y = height - 1; y >= 0 && ok; --y) ok = fwrite(&rgb[3 * (size_t)y * width], sizeof(float), 3 * (size_t)width, fp) == 3 * (size_t)width;
     if (fclose(fp) != 0) ok = false;
     return ok ? HPRT_OK : SetError(HPRT_E_IO, std::string("write error on ") + path);
-}
+} catch (...) { return hprt::HandleException(); }
 
 // Film::MergeFilmTile's accumulation (core/film.cpp:124-131) for cross-tile records on a host copy of the film: per
 // destination pixel in ascending source-tile order, exactly as the single-GPU film kernels add them.
-int hprt_film_records_merge(float *xyzw, size_t n_pixels, HprtFilmRecord *rec, size_t n) {
+int hprt_film_records_merge(float *xyzw, size_t n_pixels, HprtFilmRecord *rec, size_t n) try {
     if (!xyzw || (n && !rec)) return SetError(HPRT_E_INVALID, "hprt_film_records_merge: null argument");
     std::sort(rec, rec + n, [](const HprtFilmRecord &a, const HprtFilmRecord &b) {
         return a.dest_pixel != b.dest_pixel ? a.dest_pixel < b.dest_pixel : a.src_tile < b.src_tile;
@@ -255,13 +265,13 @@ int hprt_film_records_merge(float *xyzw, size_t n_pixels, HprtFilmRecord *rec, s
         px[0] += rec[i].xyz[0]; px[1] += rec[i].xyz[1]; px[2] += rec[i].xyz[2]; px[3] += rec[i].weight;
     }
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
 // Diagnostics hook (not part of include/hprt.h): the reference's unit tests for the host/device-shared math of this path,
 // run over the product's own functions (hprt_math.h) on the host:
 //   failures[0]  FloatingPoint.NextUpDownFloat   src/tests/fp_tests.cpp:29-47    next_up / next_down
 //   failures[1]  Distribution1D.Discrete          src/tests/sampling.cpp:231-282  dist1d_build / dist1d_sample_discrete
-__attribute__((visibility("default"))) int hprt_debug_host_selftest(int failures[2]) {
+__attribute__((visibility("default"))) int hprt_debug_host_selftest(int failures[2]) try {
     if (!failures) return HPRT_E_INVALID;
     const float inf = std::numeric_limits<float>::infinity();
     int f = 0;
@@ -310,6 +320,6 @@ __attribute__((visibility("default"))) int hprt_debug_host_selftest(int failures
         if (dist1d_sample_discrete(cdf, func, funcInt, 4, u, &pdf) != 3) ++f;
     failures[1] = f;
     return HPRT_OK;
-}
+} catch (...) { return hprt::HandleException(); }
 
 }  // extern "C"

@@ -14,4 +14,5 @@ struct HprtBvh {
 namespace hprt {
 extern thread_local std::string g_lastError;
 int SetError(int code, const std::string &msg);
+int HandleException();      // maps the exception in flight to an HPRT_E_* code + message (capi_host.cpp)
 }  // namespace hprt

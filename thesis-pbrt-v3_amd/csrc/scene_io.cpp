@@ -102,6 +102,9 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
     if (!fp) { *err = "cannot open " + path; return false; }
     In in{fp};
     auto fail = [&](const char *m) { *err = path + ": " + m; fclose(fp); return false; };
+    // sizes read from the file are checked against what the file can still hold BEFORE anything is allocated for them
+    fseek(fp, 0, SEEK_END); const long fileSize = ftell(fp); fseek(fp, 0, SEEK_SET);
+    auto fits = [&](uint64_t bytes) { const long at = ftell(fp); return at >= 0 && fileSize >= at && bytes <= (uint64_t)(fileSize - at); };
     char magic[8]; in.raw(magic, 8);
     if (!in.ok || memcmp(magic, "HPRTSCN1", 8) != 0) return fail("not a baked hprt scene");
     const uint32_t version = in.u32();
@@ -120,6 +123,7 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
     p.maxNodePrims = in.i32(); p.isectCost = in.i32(); p.travCost = in.i32();
     uint32_t nMat = in.u32(), nShapes = in.u32(), nLights = in.u32();
     if (!in.ok || nMat > (1u << 24) || nShapes > (1u << 24) || nLights > (1u << 24)) return fail("truncated or corrupt header");
+    if (!fits(32ull * nMat + 20ull * nShapes + 36ull * nLights)) return fail("truncated or corrupt header (counts exceed the file)");
     sc->materials.resize(nMat);
     for (MaterialDesc &m : sc->materials) {
         m.type = in.i32(); in.raw(m.Kd, 12); m.sigma = in.f32(); in.raw(m.Ks, 12); m.roughness = in.f32(); m.remapRoughness = in.i32();
@@ -131,6 +135,7 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
         if (s.kind == kTriangleMesh) {
             uint32_t nt = in.u32(), nv = in.u32(), flags = in.u32();
             if (!in.ok || nt > (1u << 28) || nv > (1u << 28)) return fail("corrupt mesh header");
+            if (!fits(12ull * nt + 12ull * nv + ((flags & 1) ? 12ull * nv : 0) + ((flags & 2) ? 8ull * nv : 0) + ((flags & 4) ? 12ull * nv : 0))) return fail("truncated mesh");
             MeshData &m = s.mesh;
             m.indices.resize(3 * (size_t)nt); in.raw(m.indices.data(), 12 * (size_t)nt);
             m.P.resize(3 * (size_t)nv); in.raw(m.P.data(), 12 * (size_t)nv);
@@ -154,14 +159,14 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
         sc->nObjects = in.u32();
         for (ShapeDesc &s : sc->shapes) { s.object = in.i32(); if (s.object < -1 || s.object >= (int32_t)sc->nObjects) return fail("object index out of range"); }
         const uint32_t nInst = in.u32();
-        if (!in.ok || nInst > (1u << 28)) return fail("corrupt instance count");
+        if (!in.ok || nInst > (1u << 28) || !fits(132ull * nInst)) return fail("corrupt instance count");
         sc->instances.resize(nInst);
         for (InstanceDesc &i : sc->instances) {
             i.object = in.i32(); in.raw(i.instanceToWorld.m, 64); in.raw(i.worldToInstance.m, 64);
             if (i.object < 0 || i.object >= (int32_t)sc->nObjects) return fail("instance object out of range");
         }
         const uint32_t nTop = in.u32();
-        if (!in.ok || nTop > (1u << 28)) return fail("corrupt top-level list");
+        if (!in.ok || nTop > (1u << 28) || !fits(8ull * nTop)) return fail("corrupt top-level list");
         sc->top.resize(nTop);
         for (TopItem &t : sc->top) {
             t.kind = in.i32(); t.index = in.u32();
@@ -185,7 +190,7 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
             t.levels.resize(nl);
             for (MipLevel &l : t.levels) {
                 l.w = in.i32(); l.h = in.i32();
-                if (!in.ok || l.w <= 0 || l.h <= 0 || l.w > 65536 || l.h > 65536) return fail("corrupt texture level");
+                if (!in.ok || l.w <= 0 || l.h <= 0 || l.w > 65536 || l.h > 65536 || !fits(12ull * (uint64_t)l.w * (uint64_t)l.h)) return fail("corrupt texture level");
                 l.rgb.resize(3 * (size_t)l.w * l.h); in.raw(l.rgb.data(), 4 * l.rgb.size());
             }
         }
@@ -242,7 +247,11 @@ bool ReadPlyMesh(const std::string &path, std::vector<int> *idx, std::vector<flo
         else { int32_t v; memcpy(&v, b, 4); *out = v; }
         return true;
     };
+    const std::streampos dataPos = in.tellg();
+    in.seekg(0, std::ios::end); const long long fileSize = (long long)in.tellg(); in.seekg(dataPos);
     for (const Elem &e : elems) {
+        // an element cannot have more entries than the file has bytes: refuse before allocating for it
+        if (e.count < 0 || e.count > (1l << 28) || (long long)e.count > fileSize) { *err = path + ": PLY element count out of range"; return false; }
         if (e.name == "vertex") {
             int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, iu = -1, iv = -1;
             for (size_t k = 0; k < e.props.size(); ++k) {
@@ -267,6 +276,7 @@ bool ReadPlyMesh(const std::string &path, std::vector<int> *idx, std::vector<flo
                 for (const Prop &p : e.props) {
                     if (p.list) {
                         double c; if (!readScalar(p.countType, &c)) { *err = path + ": truncated face list"; return false; }
+                        if (!(c >= 0 && c <= 255)) { *err = path + ": PLY face with an impossible vertex count"; return false; }
                         int n = (int)c; std::vector<int> face(n);
                         for (int k = 0; k < n; ++k) { double v; if (!readScalar(p.type, &v)) { *err = path + ": truncated face list"; return false; } face[k] = (int)v; }
                         if (e.name == "face" && (p.name == "vertex_indices" || p.name == "vertex_index")) {
