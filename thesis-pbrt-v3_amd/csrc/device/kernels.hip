@@ -794,15 +794,22 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
             if (MODE == 0) { bsdf.hasS = false; bsdf.Rs = rgb(0.f); bsdf.alpha = 0.f; }   // matte: no microfacet lobe (matte.cpp:45-62)
             // ---- direct lighting (UniformSampleOneLight + EstimateDirect) ----
             if (bsdf_num(bsdf) > 0 && sc.nLights > 0) {
+                // The reference draws five sample values here (light pick, uLight, uScattering: core/integrator.cpp:96-104); a value
+                // that cannot influence anything is not evaluated, its dimension is consumed all the same: with a single light
+                // every pick value selects light 0 with pdf 1, and point / distant lights ignore uLight (lights/point.cpp:44-53,
+                // lights/distant.cpp:49-59) and never reach the BSDF-sampling branch (core/integrator.cpp:168).
                 float pickPdf;
-                const int lightNum = light_pick(sc, halton_dim(sc, rp.hal, index, dim, &hl), &pickPdf);
+                const int lightNum = light_pick(sc, sc.nLights > 1u ? halton_dim(sc, rp.hal, index, dim, &hl) : 0.f, &pickPdf);
                 dim += 1;
                 if (pickPdf != 0) {
-                    const float ul0 = halton_dim(sc, rp.hal, index, dim, &hl), ul1 = halton_dim(sc, rp.hal, index, dim + 1, &hl);
-                    const float us0 = halton_dim(sc, rp.hal, index, dim + 2, &hl), us1 = halton_dim(sc, rp.hal, index, dim + 3, &hl);
-                    dim += 4;
                     const DevLight light = sc.lights[lightNum];
                     const bool isDelta = light.type != 2;
+                    float ul0 = 0.f, ul1 = 0.f, us0 = 0.f, us1 = 0.f;
+                    if (!isDelta) {
+                        ul0 = halton_dim(sc, rp.hal, index, dim, &hl); ul1 = halton_dim(sc, rp.hal, index, dim + 1, &hl);
+                        us0 = halton_dim(sc, rp.hal, index, dim + 2, &hl); us1 = halton_dim(sc, rp.hal, index, dim + 3, &hl);
+                    }
+                    dim += 4;
                     vec3 wi;
                     float lightPdf = 0, scatteringPdf = 0;
                     DevIt it; it.p = si.p; it.pErr = si.pErr; it.n = si.n;

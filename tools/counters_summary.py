@@ -13,7 +13,7 @@ PEAK = 8000.0e9
 
 def short(name):
     n = name.split("(")[0].replace("void ", "").replace("hprt::", "").strip()
-    m = re.match(r"k_trace<(false|true), (\d), (false|true)>", n)
+    m = re.match(r"k_trace<(false|true), (\d), (false|true), (false|true)>", n)      # <any hit, mode, instancing, quadrics>
     if m:
         base = "k_trace<%s>" % ("any" if m.group(1) == "true" else "closest")
         return base + ("" if m.group(2) == "0" else "[mode %s]" % m.group(2)) + ("[inst]" if m.group(3) == "true" else "")
