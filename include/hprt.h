@@ -111,7 +111,9 @@ typedef struct HprtScene HprtScene;
 typedef struct HprtShapeDesc {       /* one Shape directive (core/api.cpp:1561-1651) */
     int32_t kind;                    /* 0 triangle mesh, 1 sphere */
     int32_t material;                /* index into materials */
-    int32_t area_light;              /* index into lights or -1 (GeometricPrimitive::areaLight) */
+    int32_t area_light;              /* index into lights or -1 (GeometricPrimitive::areaLight).  A mesh is n_tris Triangle shapes, each with
+                                      * a DiffuseAreaLight of its own (core/api.cpp:1609-1636): lights area_light .. area_light + n_tris - 1,
+                                      * in face order, each with .shape = this shape */
     int32_t reverse_orientation, transform_swaps_handedness; /* core/shape.h:79-80 */
     /* mesh: world-space arrays as TriangleMesh holds them (shapes/triangle.cpp:54-92) */
     uint32_t n_tris, n_verts;

@@ -37,6 +37,7 @@ struct SurfaceInteraction {
     struct { V3 n, dpdu, dpdv; } shading;
     int prim = -1;        // creation-order primitive number (within its aggregate)
     int shape = -1;
+    int tri = -1;         // triangle number within its mesh (-1: not a triangle): which DiffuseAreaLight an emissive mesh hit belongs to
     Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;      // ComputeDifferentials (core/interaction.cpp:103-149)
     int ordered = -1;     // ordered index of the hit primitive over all aggregates: top level first, then object 0, 1, ...
     int inst = -1;        // instance the hit went through (Scene::instances), -1: none
@@ -606,8 +607,10 @@ struct BVH {
             const Mesh &m = scene->meshes[sh.meshIndex];
             TriRef tr{&m, &m.idx[3 * pr.local], flip};
             if (!TriangleIntersect(tr, r, &tHit, isect, ctr)) return false;
+            isect->tri = pr.local;
         } else {
             if (!SphereIntersect(scene->spheres[sh.sphereIndex], flip, r, &tHit, isect, ctr)) return false;
+            isect->tri = -1;
         }
         r.tMax = tHit;
         isect->prim = (int)primNum;

@@ -348,10 +348,15 @@ struct Renderer {
 
     bool Setup(std::string *err) {
         if (scene.prm.filterType != 0) { *err = "only the box filter is in scope"; return false; }
-        for (const Light &l : scene.lights)
-            if (l.type == LIGHT_AREA && scene.shapes[l.shape].kind != SHAPE_SPHERE) {
-                *err = "area lights are supported on spheres only"; return false;
-            }
+        for (size_t li = 0; li < scene.lights.size(); ++li) {
+            const Light &l = scene.lights[li];
+            if (l.type != LIGHT_AREA) continue;
+            const ShapeRec &sh = scene.shapes[l.shape];
+            // a sphere's one light, or the per-triangle lights of an emissive mesh (consecutive, in face order)
+            const bool own = sh.kind == SHAPE_SPHERE ? sh.areaLight == (int)li
+                                                     : sh.areaLight >= 0 && (int)li >= sh.areaLight && (uint32_t)((int)li - sh.areaLight) < sh.nPrims;
+            if (!own) { *err = "area light and its shape do not reference each other"; return false; }
+        }
         objectBvh.resize(scene.objectPrims.size());
         uint32_t base = (uint32_t)scene.prims.size();
         for (size_t o = 0; o < objectBvh.size(); ++o) {
@@ -388,8 +393,15 @@ struct Renderer {
         return (l.twoSided || Dot(n, w) > 0) ? l.I : Spec(0.f);
     }
     // SurfaceInteraction::Le, core/interaction.cpp:151-154
+    // GeometricPrimitive::GetAreaLight of the hit primitive: a sphere's light, or the light of the hit TRIANGLE of an emissive
+    // mesh (every triangle is a Shape with a DiffuseAreaLight of its own, core/api.cpp:1609-1636; a mesh's lights are consecutive)
+    int AreaLightOf(const SurfaceInteraction &isect) const {
+        const ShapeRec &sh = scene.shapes[isect.shape];
+        if (sh.areaLight < 0) return -1;
+        return sh.kind == SHAPE_MESH ? sh.areaLight + isect.tri : sh.areaLight;
+    }
     Spec Le(const SurfaceInteraction &isect, const V3 &w) const {
-        int al = scene.shapes[isect.shape].areaLight;
+        int al = AreaLightOf(isect);
         return al >= 0 ? AreaL(scene.lights[al], isect.n, w) : Spec(0.f);
     }
     // Light::Sample_Li for the three light types
@@ -407,7 +419,12 @@ struct Renderer {
             return l.I;
         } else {                              // lights/diffuse.cpp:68-81
             const ShapeRec &sh = scene.shapes[l.shape];
-            Interaction pShape = SphereSample(scene.spheres[sh.sphereIndex], sh.reverseOrientation != 0, ref, u, pdf);
+            Interaction pShape;
+            if (sh.kind == SHAPE_MESH) {
+                const Mesh &m = scene.meshes[sh.meshIndex];
+                const int tri = (int)(&l - scene.lights.data()) - sh.areaLight;
+                pShape = TriangleSample(m, &m.idx[3 * tri], (sh.reverseOrientation != 0) ^ (sh.swapsHandedness != 0), ref, u, pdf);
+            } else pShape = SphereSample(scene.spheres[sh.sphereIndex], sh.reverseOrientation != 0, ref, u, pdf);
             if (*pdf == 0 || (pShape.p - ref.p).LengthSquared() == 0) { *pdf = 0; return 0.f; }
             *wi = Normalize(pShape.p - ref.p);
             *pLight = pShape;
@@ -418,6 +435,19 @@ struct Renderer {
     Float Pdf_Li(const Light &l, const Interaction &ref, const V3 &wi, Counters &ctr) const {
         if (l.type != LIGHT_AREA) return 0;
         const ShapeRec &sh = scene.shapes[l.shape];
+        if (sh.kind == SHAPE_MESH) {
+            // Shape::Pdf, core/shape.cpp:72-88, with Triangle::Intersect and Triangle::Area
+            const Mesh &m = scene.meshes[sh.meshIndex];
+            const int tri = (int)(&l - scene.lights.data()) - sh.areaLight;
+            Ray ray = SpawnRay(ref.p, ref.pError, ref.n, wi);
+            Float tHit; SurfaceInteraction isectLight;
+            TriRef tr{&m, &m.idx[3 * tri], (bool)((sh.reverseOrientation != 0) ^ (sh.swapsHandedness != 0))};
+            if (!TriangleIntersect(tr, ray, &tHit, &isectLight, ctr)) return 0;
+            const int *v = &m.idx[3 * tri];
+            Float pdf = DistanceSquared(ref.p, isectLight.p) / (AbsDot(isectLight.n, -wi) * TriangleArea(m.p[v[0]], m.p[v[1]], m.p[v[2]]));
+            if (std::isinf(pdf)) pdf = 0.f;
+            return pdf;
+        }
         const Sphere &s = scene.spheres[sh.sphereIndex];
         V3 pCenter = XfPoint(s.o2w, V3(0, 0, 0));
         V3 pOrigin = OffsetRayOrigin(ref.p, ref.pError, ref.n, pCenter - ref.p);
@@ -482,7 +512,7 @@ struct Renderer {
                 bool found = SceneIntersect(ray, &lightIsect, ctr);
                 Spec Li2(0.f);
                 if (found) {
-                    if (scene.shapes[lightIsect.shape].areaLight == lightNum) Li2 = Le(lightIsect, -wi);
+                    if (AreaLightOf(lightIsect) == lightNum) Li2 = Le(lightIsect, -wi);
                 }   // else light.Le(ray) == 0 for area lights (core/light.cpp:66)
                 if (!Li2.IsBlack()) Ld += f * Li2 * Spec(1.f) * weight / scatteringPdf;
             }

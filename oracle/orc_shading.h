@@ -454,4 +454,43 @@ inline Interaction SphereSample(const Sphere &s, bool reverseOrientation, const 
     return it;
 }
 
+// ---- triangle area lights: one DiffuseAreaLight per triangle of an emissive mesh (core/api.cpp:1609-1636) ----
+// UniformSampleTriangle, core/sampling.cpp:154-157
+inline P2 UniformSampleTriangle(const P2 &u) {
+    Float su0 = std::sqrt(u.x);
+    return P2(1 - su0, u.y * su0);
+}
+// Triangle::Area, shapes/triangle.cpp:576-582 (the literal 0.5 is a double)
+inline Float TriangleArea(const V3 &p0, const V3 &p1, const V3 &p2) {
+    return (Float)(0.5 * (double)Cross(p1 - p0, p2 - p0).Length());
+}
+// Triangle::Sample(u, pdf), shapes/triangle.cpp:596-621
+inline Interaction TriangleSampleArea(const Mesh &mesh, const int *v, bool flip, const P2 &u, Float *pdf) {
+    P2 b = UniformSampleTriangle(u);
+    const V3 &p0 = mesh.p[v[0]], &p1 = mesh.p[v[1]], &p2 = mesh.p[v[2]];
+    Interaction it;
+    it.p = b.x * p0 + b.y * p1 + (1 - b.x - b.y) * p2;
+    it.n = Normalize(Cross(p1 - p0, p2 - p0));
+    if (mesh.hasN) {
+        V3 ns(b.x * mesh.n[v[0]] + b.y * mesh.n[v[1]] + (1 - b.x - b.y) * mesh.n[v[2]]);
+        it.n = Faceforward(it.n, ns);
+    } else if (flip) it.n *= -1;
+    V3 pAbsSum = Abs(b.x * p0) + Abs(b.y * p1) + Abs((1 - b.x - b.y) * p2);
+    it.pError = gamma(6) * V3(pAbsSum.x, pAbsSum.y, pAbsSum.z);
+    *pdf = 1 / TriangleArea(p0, p1, p2);
+    return it;
+}
+// Shape::Sample(ref, u, pdf), core/shape.cpp:55-70
+inline Interaction TriangleSample(const Mesh &mesh, const int *v, bool flip, const Interaction &ref, const P2 &u, Float *pdf) {
+    Interaction intr = TriangleSampleArea(mesh, v, flip, u, pdf);
+    V3 wi = intr.p - ref.p;
+    if (wi.LengthSquared() == 0) *pdf = 0;
+    else {
+        wi = Normalize(wi);
+        *pdf *= DistanceSquared(ref.p, intr.p) / AbsDot(intr.n, -wi);
+        if (std::isinf(*pdf)) *pdf = 0.f;
+    }
+    return intr;
+}
+
 }  // namespace orc

@@ -26,6 +26,15 @@ SCENES = {
     "sphere_area_light": HEAD + 'Material "matte" "color Kd" [.5 .5 .5]\nAreaLightSource "diffuse" "color L" [.5 .5 .5]\n'
                                 'ReverseOrientation\nShape "sphere" "float radius" [1]\nWorldEnd\n',
 }
+# Not one of the reference's scenes, but the same analytic answer for the TRIANGLE emitters (one DiffuseAreaLight per triangle,
+# Triangle::Sample / Shape::Pdf, uniform light selection): a closed cube seen from inside, Kd = 0.5 and Le = 0.5 on its inner faces.
+# No reference-held output covers triangle emitters (parity unpinned against the reference): wrong areas, pdfs or MIS weights
+# would move this mean away from 1.
+SCENES["box_triangle_area_lights"] = (
+    HEAD.replace('"integer maxdepth" [8]', '"integer maxdepth" [8] "string lightsamplestrategy" "uniform"') +
+    'Material "matte" "color Kd" [.5 .5 .5]\nAreaLightSource "diffuse" "color L" [.5 .5 .5]\n'
+    'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3  4 6 5 4 7 6  0 4 5 0 5 1  1 5 6 1 6 2  2 6 7 2 7 3  3 7 4 3 4 0] '
+    '"point P" [-1 -1 -1  1 -1 -1  1 1 -1  -1 1 -1  -1 -1 1  1 -1 1  1 1 1  -1 1 1]\nWorldEnd\n')
 DELTA = 0.02      # analytic_scenes.cpp:59
 
 

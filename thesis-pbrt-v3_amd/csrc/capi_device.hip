@@ -79,8 +79,8 @@ struct Workspace {
     float4 *Lfinal;
 };
 // 16-byte words per stream index: 2 x (ray a,b + beta + L) + hit a + shadow a,b + mis a,b + misHit a
-// + pendLight/Mis/Beta + Lfinal; plus b2 (4 B), occluded (1 B) and alignment slack
-const size_t kPlaneBytesPerSlot = 16 * (2 * 4 + 1 + 2 + 2 + 1 + 3 + 1) + 8 + 1;
+// + pendLight/Mis/Beta + Lfinal; plus b2 + instance of the path hit and of the MIS hit (8 B each), occluded (1 B) and alignment slack
+const size_t kPlaneBytesPerSlot = 16 * (2 * 4 + 1 + 2 + 2 + 1 + 3 + 1) + 8 + 8 + 1;
 size_t PlaneBytes(size_t n) { return n * kPlaneBytesPerSlot + 32 * 256; }
 
 void CarvePlanes(char *base, size_t n, Workspace *w) {
@@ -89,7 +89,7 @@ void CarvePlanes(char *base, size_t n, Workspace *w) {
     for (int k = 0; k < 2; ++k) { rays(w->path[k].ray); w->path[k].beta = a.take<float4>(n); w->path[k].L = a.take<float4>(n); }
     w->hit.a = a.take<float4>(n); w->hit.b = a.take<float2>(n);
     rays(w->vs.shadow); w->vs.occluded = a.take<uint8_t>(n);
-    rays(w->vs.mis); w->vs.misHit.a = a.take<float4>(n); w->vs.misHit.b = nullptr;
+    rays(w->vs.mis); w->vs.misHit.a = a.take<float4>(n); w->vs.misHit.b = a.take<float2>(n);      // (b2: the emitter's shading normal at a triangle light)
     w->vs.pendLight = a.take<float4>(n); w->vs.pendMis = a.take<float4>(n); w->vs.pendBeta = a.take<float4>(n);
     w->Lfinal = a.take<float4>(n);
 }
@@ -198,7 +198,13 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
             if (sh.n_tris && (!sh.indices || !sh.P)) return SetError(HPRT_E_INVALID, "mesh without indices or positions");
             for (uint64_t i = 0; i < 3ull * sh.n_tris; ++i)
                 if (sh.indices[i] < 0 || (uint32_t)sh.indices[i] >= sh.n_verts) return SetError(HPRT_E_INVALID, "mesh vertex index out of range");
-            if (sh.area_light >= 0) return SetError(HPRT_E_UNSUPPORTED, "area lights on triangle meshes are outside the hot-path scope");
+            // an emissive mesh owns one light per triangle, consecutive and in face order (core/api.cpp:1609-1636)
+            if (sh.area_light >= 0) {
+                if ((uint64_t)sh.area_light + sh.n_tris > d->n_lights) return SetError(HPRT_E_INVALID, "emissive mesh: its per-triangle lights exceed the light table");
+                for (uint32_t t = 0; t < sh.n_tris; ++t)
+                    if (d->lights[sh.area_light + t].type != 2 || d->lights[sh.area_light + t].shape != (int32_t)s)
+                        return SetError(HPRT_E_INVALID, "emissive mesh: light area_light + t must be the diffuse area light of its triangle t");
+            }
             shapePrims[s] = sh.n_tris; vtxBase[s + 1] = vtxBase[s] + sh.n_verts;
         } else if (sh.kind == 1) {
             shapePrims[s] = 1; vtxBase[s + 1] = vtxBase[s]; ++nSpheres;
@@ -273,8 +279,13 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     for (uint32_t l = 0; l < d->n_lights; ++l) {
         const HprtLightDesc &L = d->lights[l];
         if (L.type < 0 || L.type > 2) return SetError(HPRT_E_INVALID, "unknown light type");
-        if (L.type == 2 && (L.shape < 0 || (uint32_t)L.shape >= d->n_shapes || d->shapes[L.shape].kind != 1))
-            return SetError(HPRT_E_UNSUPPORTED, "diffuse area lights are supported on spheres only");
+        if (L.type == 2) {
+            if (L.shape < 0 || (uint32_t)L.shape >= d->n_shapes) return SetError(HPRT_E_INVALID, "area light shape out of range");
+            const HprtShapeDesc &ls = d->shapes[L.shape];
+            const bool own = ls.kind == 1 ? ls.area_light == (int32_t)l
+                                          : ls.area_light >= 0 && (int32_t)l >= ls.area_light && (uint32_t)((int32_t)l - ls.area_light) < ls.n_tris;
+            if (!own) return SetError(HPRT_E_INVALID, "area light and its shape do not reference each other");
+        }
     }
     if (d->n_lights > 1 && d->light_strategy != 0)
         return SetError(HPRT_E_UNSUPPORTED, "with more than one light only lightsamplestrategy \"uniform\" is in scope (SURVEY.md §2)");
@@ -312,6 +323,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     std::vector<float4> tris(3 * (size_t)totalPrims);
     std::vector<uint32_t> primVtx(3 * (size_t)totalPrims, 0u);
     std::vector<float4> primN(3 * (size_t)totalPrims, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<int32_t> lightPrim(d->n_lights, -1);      // triangle lights: ordered index of their triangle
     for (size_t ai = 0; ai < aggs.size(); ++ai) {
         const Agg &g = aggs[ai];
         for (uint32_t oi = 0; oi < g.nPrims; ++oi) {
@@ -330,8 +342,11 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
                                                  sh.UV ? &sh.UV[2 * (size_t)v[0]] : nullptr, sh.UV ? &sh.UV[2 * (size_t)v[1]] : nullptr,
                                                  sh.UV ? &sh.UV[2 * (size_t)v[2]] : nullptr);
                     const HprtMaterialDesc &md = d->materials[sh.material];
-                    uint32_t tag = (bogus ? TAG_BOGUS : 0u) | (md.type == 1 ? TAG_PLASTIC : 0u) | (md.kd_texture >= 0 || md.ks_texture >= 0 ? TAG_GENERIC : 0u);
-                    r0 = make_float4(a[0], a[1], a[2], u2f(tag)); r1 = make_float4(b[0], b[1], b[2], u2f(s)); r2 = make_float4(c[0], c[1], c[2], u2f(0u));
+                    // a triangle of an emissive mesh: aux = 1 + its light, and TAG_GENERIC — the generic shading variant is the one that looks for Le
+                    const int32_t triLight = sh.area_light >= 0 ? sh.area_light + (int32_t)e.local : -1;
+                    if (triLight >= 0) lightPrim[triLight] = (int32_t)i;
+                    uint32_t tag = (bogus ? TAG_BOGUS : 0u) | (md.type == 1 ? TAG_PLASTIC : 0u) | (md.kd_texture >= 0 || md.ks_texture >= 0 || triLight >= 0 ? TAG_GENERIC : 0u);
+                    r0 = make_float4(a[0], a[1], a[2], u2f(tag)); r1 = make_float4(b[0], b[1], b[2], u2f(s)); r2 = make_float4(c[0], c[1], c[2], u2f((uint32_t)(triLight + 1)));
                     for (int k = 0; k < 3; ++k) {
                         primVtx[3 * i + k] = (uint32_t)(vtxBase[s] + (uint32_t)v[k]);
                         if (sh.N) { const float *nn = &sh.N[3 * (size_t)v[k]]; primN[3 * i + k] = make_float4(nn[0], nn[1], nn[2], 0.f); }
@@ -382,7 +397,11 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
         const HprtLightDesc &in = d->lights[l];
         DevLight &o = lights[l];
         o.type = in.type; memcpy(o.pos, in.pos, 12); memcpy(o.I, in.I, 12); o.shape = in.shape; o.twoSided = in.two_sided;
-        o.sphere = in.type == 2 ? sphereOfShape[in.shape] : -1;
+        const bool onMesh = in.type == 2 && d->shapes[in.shape].kind == 0;
+        if (onMesh && lightPrim[l] < 0) return SetError(HPRT_E_UNSUPPORTED, "emissive triangle outside the top-level aggregate (area lights are not supported with object instancing, core/api.cpp:1640)");
+        if (onMesh) o.type = 3;
+        o.prim = onMesh ? lightPrim[l] : -1;
+        o.sphere = in.type == 2 && !onMesh ? sphereOfShape[in.shape] : -1;
         o.shapeFlags = in.type == 2 ? shapes[in.shape].flags : 0u;
     }
     // UniformLightDistribution (core/lightdistrib.cpp:68-75) as a Distribution1D (core/sampling.h:57-70)

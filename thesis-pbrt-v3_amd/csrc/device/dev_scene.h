@@ -21,7 +21,8 @@
 //                                    shapes/triangle.cpp:309-316, IntersectP does not), bit 3
 //                                    "last primitive of its leaf" (ends the leaf loop of
 //                                    accelerators/bvh.cpp:370-373 without a count).
-//                                    For spheres aux = sphere index; kind 2 is an object
+//                                    For spheres aux = sphere index; for a triangle of an emissive mesh aux =
+//                                    1 + the index of its DiffuseAreaLight (0: not a light); kind 2 is an object
 //                                    instance (TransformedPrimitive) with aux = instance index.
 //                                    The primitives of all aggregates share this array: the top
 //                                    level first, then each object definition's.
@@ -61,7 +62,9 @@ struct DevMaterial { int32_t type; float Kd[3]; float Ks[3]; float alpha; int32_
 // ImageTexture + MIPMap (textures/imagemap.h, core/mipmap.h): levels are consecutive in mipLevels, texels hold 3 floats each
 struct DevMipLevel { uint32_t offset; int32_t w, h; };
 struct DevTexture { uint32_t firstLevel, nLevels; int32_t trilinear, wrap; float maxAniso, su, sv, du, dv; };
-struct DevLight { int32_t type; float pos[3]; float I[3]; int32_t shape; int32_t twoSided; int32_t sphere; uint32_t shapeFlags; };
+// type: 0 point, 1 distant, 2 diffuse area light on a sphere, 3 diffuse area light on ONE triangle (prim = its ordered index;
+// every triangle of an emissive mesh is a light of its own, core/api.cpp:1609-1636)
+struct DevLight { int32_t type; float pos[3]; float I[3]; int32_t shape; int32_t twoSided; int32_t sphere; uint32_t shapeFlags; int32_t prim; };
 struct DevSphere { mat4 o2w, w2o; float radius, zMin, zMax, thetaMin, thetaMax, phiMax; };
 // ObjectInstance: the wrapped aggregate's entry (pair index, or ~primitive when the object holds a
 // single primitive: no aggregate, no bounds test) and the static instance transform

@@ -682,8 +682,54 @@ __device__ __forceinline__ DevIt sphere_sample(const DevSphere &s, bool reverse,
 __device__ __forceinline__ rgb area_L(const DevLight &l, vec3 n, vec3 w) {   // lights/diffuse.h:56-58
     return (l.twoSided || dot(n, w) > 0) ? rgb(l.I[0], l.I[1], l.I[2]) : rgb(0.f);
 }
-// Light::Sample_Li (lights/point.cpp:44-53, distant.cpp:49-59, diffuse.cpp:68-81)
-template <bool INSIDE_POSSIBLE>
+// GeometricPrimitive::GetAreaLight of an ordered primitive: the sphere's light, or the light of this one triangle (aux - 1)
+__device__ __forceinline__ int prim_area_light(const DevScene &sc, int32_t prim) {
+    const uint32_t tag = __float_as_uint(sc.tris[3 * prim].w);
+    if ((tag & TAG_KIND_MASK) == 0u) return (int)__float_as_uint(sc.tris[3 * prim + 2].w) - 1;
+    return sc.shapes[__float_as_uint(sc.tris[3 * prim + 1].w)].areaLight;
+}
+// Triangle::Area, shapes/triangle.cpp:576-582 (0.5 is a double literal)
+__device__ __forceinline__ float triangle_area(vec3 p0, vec3 p1, vec3 p2) {
+    return (float)(0.5 * (double)length(cross(p1 - p0, p2 - p0)));
+}
+// Shape::Sample(ref, u, pdf) (core/shape.cpp:55-70) over Triangle::Sample(u, pdf) (shapes/triangle.cpp:596-621)
+__device__ __forceinline__ DevIt triangle_sample(const DevScene &sc, int32_t prim, const DevIt &ref, float u0, float u1, float *pdf) {
+    const float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
+    const vec3 p0(v0.x, v0.y, v0.z), p1(v1.x, v1.y, v1.z), p2(v2.x, v2.y, v2.z);
+    const DevShape sh = sc.shapes[__float_as_uint(v1.w)];
+    const float su0 = sqrtf(u0);                       // UniformSampleTriangle, core/sampling.cpp:154-157
+    const float b0 = 1 - su0, b1 = u1 * su0;
+    DevIt it;
+    it.p = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
+    it.n = normalize(cross(p1 - p0, p2 - p0));
+    if (sh.flags & SHAPE_HAS_N) {
+        const float4 m0 = sc.primN[3 * prim], m1 = sc.primN[3 * prim + 1], m2 = sc.primN[3 * prim + 2];
+        const vec3 ns = b0 * vec3(m0.x, m0.y, m0.z) + b1 * vec3(m1.x, m1.y, m1.z) + (1 - b0 - b1) * vec3(m2.x, m2.y, m2.z);
+        it.n = face_forward(it.n, ns);
+    } else if (sh.flags & SHAPE_FLIP) it.n = it.n * -1.f;
+    const vec3 pAbsSum = vabs(b0 * p0) + vabs(b1 * p1) + vabs((1 - b0 - b1) * p2);
+    it.pErr = gamma_n(6) * pAbsSum;
+    *pdf = 1 / triangle_area(p0, p1, p2);
+    vec3 wi = it.p - ref.p;
+    if (length2(wi) == 0) *pdf = 0;
+    else {
+        wi = normalize(wi);
+        *pdf *= dist2(ref.p, it.p) / absdot(it.n, -wi);
+        if (is_inf(*pdf)) *pdf = 0.f;
+    }
+    return it;
+}
+// Would Triangle::Intersect of light triangle `prim` accept this ray for SOME tMax?  (The test the traversal runs, with
+// tMax = infinity: a smaller tMax only rejects more.)  false => the triangle can never be the ray's closest hit.
+__device__ __forceinline__ bool triangle_may_hit(const DevScene &sc, int32_t prim, const DRay &r, float *b0, float *b1, float *b2, float *t) {
+    const float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
+    if (__float_as_uint(v0.w) & TAG_BOGUS) return false;      // Triangle::Intersect returns false on it (shapes/triangle.cpp:309-316)
+    const RayShear sh = ray_shear(r.d);
+    return tri_test(vec3(v0.x, v0.y, v0.z), vec3(v1.x, v1.y, v1.z), vec3(v2.x, v2.y, v2.z), r.o, r.tMax, sh, b0, b1, b2, t);
+}
+// Light::Sample_Li (lights/point.cpp:44-53, distant.cpp:49-59, diffuse.cpp:68-81).  GENERIC: the generic shading variant, the
+// only one that carries the code for shading points inside a sphere emitter and for triangle emitters.
+template <bool GENERIC>
 __device__ __forceinline__ rgb light_sample(const DevScene &sc, const DevLight &l, const DevIt &ref, float u0, float u1, vec3 *wi,
                                             float *pdf, DevIt *pLight) {
     vec3 lp(l.pos[0], l.pos[1], l.pos[2]);
@@ -698,20 +744,33 @@ __device__ __forceinline__ rgb light_sample(const DevScene &sc, const DevLight &
         pLight->p = ref.p + lp * (2 * sc.worldRadius); pLight->pErr = vec3(); pLight->n = vec3();
         return rgb(l.I[0], l.I[1], l.I[2]);
     }
-    DevIt ps = sphere_sample<INSIDE_POSSIBLE>(sc.spheres[l.sphere], (l.shapeFlags & SHAPE_REVERSE) != 0, ref, u0, u1, pdf);
+    DevIt ps;
+    if (GENERIC && l.type == 3) ps = triangle_sample(sc, l.prim, ref, u0, u1, pdf);
+    else ps = sphere_sample<GENERIC>(sc.spheres[l.sphere], (l.shapeFlags & SHAPE_REVERSE) != 0, ref, u0, u1, pdf);
     if (*pdf == 0 || length2(ps.p - ref.p) == 0) { *pdf = 0; return rgb(0.f); }
     *wi = normalize(ps.p - ref.p);
     *pLight = ps;
     return area_L(l, ps.n, -*wi);
 }
-// Light::Pdf_Li for area lights = Sphere::Pdf (shapes/sphere.cpp:294-306; inside case
+// Light::Pdf_Li for area lights = Sphere::Pdf (shapes/sphere.cpp:294-306; inside case and triangles:
 // Shape::Pdf, core/shape.cpp:72-88)
-template <bool INSIDE_POSSIBLE>
+template <bool GENERIC>
 __device__ __forceinline__ float light_pdf(const DevScene &sc, const DevLight &l, const DevIt &ref, vec3 wi) {
-    if (l.type != 2) return 0;
+    if (l.type < 2) return 0;
+    if (GENERIC && l.type == 3) {
+        DRay ray; ray.o = offset_ray_origin(ref.p, ref.pErr, ref.n, wi); ray.d = wi; ray.tMax = HPRT_INF;
+        float b0, b1, b2, t;
+        if (!triangle_may_hit(sc, l.prim, ray, &b0, &b1, &b2, &t)) return 0;
+        DevSI isl;
+        fill_triangle(sc, (uint32_t)l.prim, b0, b1, b2, wi, &isl);
+        const float4 v0 = sc.tris[3 * l.prim], v1 = sc.tris[3 * l.prim + 1], v2 = sc.tris[3 * l.prim + 2];
+        float pdf = dist2(ref.p, isl.p) / (absdot(isl.n, -wi) * triangle_area(vec3(v0.x, v0.y, v0.z), vec3(v1.x, v1.y, v1.z), vec3(v2.x, v2.y, v2.z)));
+        if (is_inf(pdf)) pdf = 0.f;
+        return pdf;
+    }
     const DevSphere &s = sc.spheres[l.sphere];
     vec3 pCenter = xf_point(s.o2w, vec3(0, 0, 0));
-    if (INSIDE_POSSIBLE && sphere_ref_inside(s, ref)) {
+    if (GENERIC && sphere_ref_inside(s, ref)) {
         DRay ray; ray.o = offset_ray_origin(ref.p, ref.pErr, ref.n, wi); ray.d = wi; ray.tMax = HPRT_INF;
         DevSI isl; float tHit;
         if (!fill_sphere(sc, l.shape, ray, &isl, &tHit)) return 0;

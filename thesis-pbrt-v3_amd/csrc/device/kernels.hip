@@ -751,9 +751,9 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                 if (texScene) { tg.dpdu = xf_vector(in.i2w, tg.dpdu); tg.dpdv = xf_vector(in.i2w, tg.dpdv); }
             }
             // emitted radiance at the first vertex (path.cpp:97-107; no specular lobes exist here).
-            // Triangle meshes carry no area lights in this build, so only the generic variant looks.
+            // Emissive triangles carry TAG_GENERIC (like quadrics), so only the generic variant looks.
             if (MODE == 2 && bounces == 0) {
-                const int al = sc.shapes[si.shape].areaLight;
+                const int al = prim_area_light(sc, prim);
                 if (al >= 0) {
                     rgb Le = area_L(sc.lights[al], si.n, -rayD);
                     rgb add = beta * Le;
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                 dim += 1;
                 if (pickPdf != 0) {
                     const DevLight light = sc.lights[lightNum];
-                    const bool isDelta = light.type != 2;
+                    const bool isDelta = light.type < 2;
                     float ul0 = 0.f, ul1 = 0.f, us0 = 0.f, us1 = 0.f;
                     if (!isDelta) {
                         ul0 = halton_dim(sc, rp.hal, index, dim, &hl); ul1 = halton_dim(sc, rp.hal, index, dim + 1, &hl);
@@ -817,7 +817,8 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                     // A shading point inside the emitter sphere needs the full quadric code
                     // (Sphere::Sample(u) + Shape::Pdf); nothing has been written yet, so the
                     // material-specialised variants hand such a vertex to the generic variant.
-                    if (MODE != 2 && !isDelta && sphere_ref_inside(sc.spheres[light.sphere], it)) defer = true;
+                    // (likewise a vertex lit by a triangle emitter: Triangle::Sample / Shape::Pdf live in the generic variant only)
+                    if (MODE != 2 && !isDelta && (light.type == 3 || sphere_ref_inside(sc.spheres[light.sphere], it))) defer = true;
                     if (!defer) {
                     rgb Li = light_sample<MODE == 2>(sc, light, it, ul0, ul1, &wi, &lightPdf, &pl);
                     rgb pendLight(0.f), pendMis(0.f);
@@ -848,7 +849,10 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                             // not traced.  (Counting renders trace it anyway unless told otherwise: the reference counts it.)
                             const vec3 o = offset_ray_origin(si.p, si.pErr, si.n, wi);
                             DRay mr; mr.o = o; mr.d = wi; mr.tMax = HPRT_INF;
-                            if (!rp.cullMis || sphere_may_hit(sc.spheres[light.sphere], mr)) {
+                            // (triangle emitters: the traversal's own triangle test on the emitter with tMax = infinity)
+                            float tb0, tb1, tb2, tt;
+                            if (!rp.cullMis || (MODE == 2 && light.type == 3 ? triangle_may_hit(sc, light.prim, mr, &tb0, &tb1, &tb2, &tt)
+                                                                              : sphere_may_hit(sc.spheres[light.sphere], mr))) {
                                 const float lp = light_pdf<MODE == 2>(sc, light, it, wi);
                                 if (lp != 0) {     // "if (lightPdf == 0) return Ld;" keeps the light-sampling term only
                                     const float w = power_heuristic(scatteringPdf, lp);
@@ -949,19 +953,18 @@ __global__ __launch_bounds__(256) void k_resolve(DevScene sc, VertexStreams vs, 
     rgb Ld(0.f);
     if ((info & 0x40000000u) && !vs.occluded[j]) Ld = Ld + rgb(pl.x, pl.y, pl.z);
     if (info & 0x80000000u) {
-        const int32_t prim = hit_prim(__float_as_int(vs.misHit.a[j].y));
-        if (prim >= 0) {
-            const int shapeId = (int)__float_as_uint(sc.tris[3 * prim + 1].w);
-            if (sc.shapes[shapeId].areaLight == lightNum) {
-                // lightIsect.Le(-wi): the normal of the emitter at the hit (sphere emitters)
-                const float4 ma = vs.mis.a[j], mb = vs.mis.b[j];
-                DRay r; r.o = vec3(ma.x, ma.y, ma.z); r.d = vec3(mb.x, mb.y, mb.z); r.tMax = HPRT_INF;
-                DevSI li; float tt;
-                if (fill_sphere(sc, shapeId, r, &li, &tt)) {
-                    const DevLight light = sc.lights[lightNum];
-                    if (light.twoSided || dot(li.n, -r.d) > 0) Ld = Ld + rgb(pm.x, pm.y, pm.z);
-                }
-            }
+        const float4 mh = vs.misHit.a[j];
+        const int32_t prim = hit_prim(__float_as_int(mh.y));
+        if (prim >= 0 && prim_area_light(sc, prim) == lightNum) {
+            // lightIsect.Le(-wi): the emitter's normal at the hit
+            const float4 ma = vs.mis.a[j], mb = vs.mis.b[j];
+            DRay r; r.o = vec3(ma.x, ma.y, ma.z); r.d = vec3(mb.x, mb.y, mb.z); r.tMax = HPRT_INF;
+            const DevLight light = sc.lights[lightNum];
+            DevSI li;
+            bool filled;
+            if (light.type == 3) { fill_triangle(sc, (uint32_t)prim, mh.z, mh.w, vs.misHit.b[j].x, r.d, &li); filled = true; }
+            else { float tt; filled = fill_sphere(sc, (int)__float_as_uint(sc.tris[3 * prim + 1].w), r, &li, &tt); }
+            if (filled && (light.twoSided || dot(li.n, -r.d) > 0)) Ld = Ld + rgb(pm.x, pm.y, pm.z);
         }
     }
     rgb add = rgb(pb.x, pb.y, pb.z) * (Ld / pickPdf);

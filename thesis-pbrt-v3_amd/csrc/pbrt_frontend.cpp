@@ -277,6 +277,19 @@ struct Frontend {
         return id;
     }
 
+    // MakeAreaLight, core/api.cpp:782-788 + CreateDiffuseAreaLight, lights/diffuse.cpp:113-125
+    LightDesc makeAreaLight() {
+        if (gs.areaLight != "area" && gs.areaLight != "diffuse") warn("area light \"" + gs.areaLight + "\" unknown; treated as diffuse");
+        LightDesc l; memset(&l, 0, sizeof(l));
+        l.type = kDiffuseAreaLight;
+        float L[3] = {1, 1, 1}, scv[3] = {1, 1, 1};
+        gs.areaLightParams.rgb3("L", L);
+        gs.areaLightParams.rgb3("scale", scv);
+        for (int i = 0; i < 3; ++i) l.I[i] = L[i] * scv[i];
+        l.twoSided = gs.areaLightParams.oneBool("twosided", false) ? 1 : 0;
+        return l;
+    }
+
     // ---- shapes (core/api.cpp:1561-1651) ------------------------------------
     bool addMeshShape(const ParamList &params, std::vector<int> &idx, std::vector<float> &P, std::vector<float> &N,
                       std::vector<float> &UV, std::vector<float> &S) {
@@ -310,8 +323,16 @@ struct Frontend {
             }
         }
         if (UV.size() >= 2 * nv) sh.mesh.UV.assign(UV.begin(), UV.begin() + 2 * nv);
-        if (!gs.areaLight.empty())
-            warn("area lights on triangle meshes are outside the hot-path scope (one DiffuseAreaLight per triangle); ignored");
+        if (!gs.areaLight.empty() && currentObject >= 0)
+            warn("Area lights not supported with object instancing (core/api.cpp:1640); the shape is kept without emission");
+        else if (!gs.areaLight.empty() && !idx.empty()) {
+            // pbrtShape creates one Triangle shape per face and one DiffuseAreaLight per shape, appended to the scene's lights
+            // in face order (core/api.cpp:1609-1636): the mesh owns the consecutive lights areaLight .. areaLight + nTris - 1
+            LightDesc l = makeAreaLight();
+            l.shape = (int)sc->shapes.size();
+            sh.areaLight = (int)sc->lights.size();
+            for (size_t t = 0; t < idx.size() / 3; ++t) sc->lights.push_back(l);
+        }
         pushShape(std::move(sh));
         return true;
     }
@@ -374,14 +395,7 @@ struct Frontend {
             if (!gs.areaLight.empty() && currentObject >= 0)
                 warn("Area lights not supported with object instancing (core/api.cpp:1640); the shape is kept without emission");
             else if (!gs.areaLight.empty()) {   // MakeAreaLight, core/api.cpp:782-788 + lights/diffuse.cpp:113-125
-                if (gs.areaLight != "area" && gs.areaLight != "diffuse") warn("area light \"" + gs.areaLight + "\" unknown; treated as diffuse");
-                LightDesc l; memset(&l, 0, sizeof(l));
-                l.type = kDiffuseAreaLight;
-                float L[3] = {1, 1, 1}, scv[3] = {1, 1, 1};
-                gs.areaLightParams.rgb3("L", L);
-                gs.areaLightParams.rgb3("scale", scv);
-                for (int i = 0; i < 3; ++i) l.I[i] = L[i] * scv[i];
-                l.twoSided = gs.areaLightParams.oneBool("twosided", false) ? 1 : 0;
+                LightDesc l = makeAreaLight();
                 l.shape = (int)sc->shapes.size();
                 sh.areaLight = (int)sc->lights.size();
                 sc->lights.push_back(l);
