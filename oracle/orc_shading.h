@@ -150,15 +150,31 @@ struct TRDist {
 
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16,
        BSDF_ALL = 31 };
-enum { BXDF_LAMBERT = 0, BXDF_MICROFACET = 1 };
+enum { BXDF_LAMBERT = 0, BXDF_MICROFACET = 1, BXDF_SPECULAR_REFLECTION = 2, BXDF_OREN_NAYAR = 3 };
 
 struct BxDF {
     int kind; int type;
     Spec R;
     TRDist dist;   // microfacet only; Fresnel is FresnelDielectric(1.5, 1) (plastic.cpp:56)
+    Float A = 1, B = 0;   // OrenNayar (core/reflection.h:414-420)
     bool MatchesFlags(int t) const { return (type & t) == type; }
     Spec f(const V3 &wo, const V3 &wi) const {
         if (kind == BXDF_LAMBERT) return R * InvPi;       // reflection.cpp:178-180
+        if (kind == BXDF_SPECULAR_REFLECTION) return Spec(0.f);      // reflection.h:199-201
+        if (kind == BXDF_OREN_NAYAR) {                    // reflection.cpp:197-219
+            Float sinThetaI = SinTheta(wi), sinThetaO = SinTheta(wo);
+            Float maxCos = 0;
+            if (sinThetaI > 1e-4 && sinThetaO > 1e-4) {
+                Float sinPhiI = SinPhi(wi), cosPhiI = CosPhi(wi);
+                Float sinPhiO = SinPhi(wo), cosPhiO = CosPhi(wo);
+                Float dCos = cosPhiI * cosPhiO + sinPhiI * sinPhiO;
+                maxCos = smax((Float)0, dCos);
+            }
+            Float sinAlpha, tanBeta;
+            if (AbsCosTheta(wi) > AbsCosTheta(wo)) { sinAlpha = sinThetaO; tanBeta = sinThetaI / AbsCosTheta(wi); }
+            else { sinAlpha = sinThetaI; tanBeta = sinThetaO / AbsCosTheta(wo); }
+            return R * InvPi * (A + B * maxCos * sinAlpha * tanBeta);
+        }
         // reflection.cpp:226-236
         Float cosThetaO = AbsCosTheta(wo), cosThetaI = AbsCosTheta(wi);
         V3 wh = wi + wo;
@@ -169,13 +185,19 @@ struct BxDF {
         return R * dist.D(wh) * dist.G(wo, wi) * F / (4 * cosThetaI * cosThetaO);
     }
     Float Pdf(const V3 &wo, const V3 &wi) const {
-        if (kind == BXDF_LAMBERT) return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * InvPi : 0;   // :387-389
+        if (kind == BXDF_SPECULAR_REFLECTION) return 0;                                          // reflection.h:204
+        if (kind == BXDF_LAMBERT || kind == BXDF_OREN_NAYAR) return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * InvPi : 0;   // :387-389
         if (!SameHemisphere(wo, wi)) return 0;                                                   // :416-420
         V3 wh = Normalize(wo + wi);
         return dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
     }
     Spec Sample_f(const V3 &wo, V3 *wi, const P2 &u, Float *pdf) const {
-        if (kind == BXDF_LAMBERT) {                        // :378-385
+        if (kind == BXDF_SPECULAR_REFLECTION) {            // :136-143, FresnelNoOp::Evaluate == Spectrum(1.)
+            *wi = V3(-wo.x, -wo.y, wo.z);
+            *pdf = 1;
+            return Spec(1.f) * R / AbsCosTheta(*wi);
+        }
+        if (kind == BXDF_LAMBERT || kind == BXDF_OREN_NAYAR) {      // :378-385
             *wi = CosineSampleHemisphere(u);
             if (wo.z < 0) wi->z *= -1;
             *pdf = Pdf(wo, *wi);
@@ -359,17 +381,32 @@ inline Spec EvalImageTexture(const Texture &tx, const SurfaceInteraction &si) {
     return MipLookup(tx, st, dstdx, dstdy);
 }
 
-// materials/matte.cpp:45-62, materials/plastic.cpp:45-70 (constant or image textures;
-// sigma != 0 (OrenNayar) is outside the hot-path scope)
+// materials/matte.cpp:45-62 (Lambert or OrenNayar), materials/plastic.cpp:45-70, materials/mirror.cpp:44-56 (constant or
+// image textures on Kd / Ks)
 inline void ComputeScatteringFunctions(const Scene &scene, const Material &m, const SurfaceInteraction &si, BSDF *bsdf) {
     bsdf->Init(si);
     const Spec Kd = m.KdTex >= 0 ? EvalImageTexture(scene.textures[m.KdTex], si) : Spec(m.Kd[0], m.Kd[1], m.Kd[2]);
     const Spec Ks = m.KsTex >= 0 ? EvalImageTexture(scene.textures[m.KsTex], si) : Spec(m.Ks[0], m.Ks[1], m.Ks[2]);
-    if (m.type == MAT_MATTE) {
+    if (m.type == MAT_MIRROR) {      // materials/mirror.cpp:44-56 (Kr in Ks)
+        Spec R = Ks.Clamp();
+        if (!R.IsBlack()) {
+            BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+            b.kind = BXDF_SPECULAR_REFLECTION; b.type = BSDF_REFLECTION | BSDF_SPECULAR; b.R = R;
+        }
+    } else if (m.type == MAT_MATTE) {
         Spec r = Kd.Clamp();
+        Float sig = Clamp(m.sigma, 0, 90);
         if (!r.IsBlack()) {
             BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
-            b.kind = BXDF_LAMBERT; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.R = r;
+            b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.R = r;
+            if (sig == 0) b.kind = BXDF_LAMBERT;
+            else {      // OrenNayar::OrenNayar, core/reflection.h:414-420
+                b.kind = BXDF_OREN_NAYAR;
+                Float sigma = Radians(sig);
+                Float sigma2 = sigma * sigma;
+                b.A = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                b.B = 0.45f * sigma2 / (sigma2 + 0.09f);
+            }
         }
     } else {
         Spec kd = Kd.Clamp();

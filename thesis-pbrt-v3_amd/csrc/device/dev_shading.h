@@ -315,6 +315,9 @@ struct DevBsdf {
     rgb Rd, Rs;            // Lambertian reflectance (lobe 0 when present), microfacet reflectance (the following lobe)
     float alpha;           // Trowbridge-Reitz alpha of the microfacet lobe
     bool hasD, hasS;
+    bool hasR;             // a SpecularReflection lobe with FresnelNoOp (mirror): the BSDF's only lobe when present
+    rgb Rr;
+    bool oren; float orenA, orenB;      // the diffuse lobe is OrenNayar, not LambertianReflection
 };
 __device__ __forceinline__ float cos_theta(vec3 w) { return w.z; }
 __device__ __forceinline__ float cos2_theta(vec3 w) { return w.z * w.z; }
@@ -404,7 +407,21 @@ __device__ __forceinline__ vec3 tr_sample_wh(float a, vec3 wo, float u0, float u
 }
 
 // LambertianReflection (core/reflection.cpp:178-180) with BxDF::Sample_f / BxDF::Pdf (:378-389)
-__device__ __forceinline__ rgb lambert_f(const DevBsdf &b) { return b.Rd * HPRT_INV_PI; }
+// (or OrenNayar::f, core/reflection.cpp:197-219, when the matte material has sigma != 0)
+__device__ __forceinline__ rgb lambert_f(const DevBsdf &b, vec3 wo, vec3 wi) {
+    if (!b.oren) return b.Rd * HPRT_INV_PI;
+    const float sinThetaI = sin_theta(wi), sinThetaO = sin_theta(wo);
+    float maxCos = 0;
+    if ((double)sinThetaI > 1e-4 && (double)sinThetaO > 1e-4) {
+        const float sinPhiI = sin_phi(wi), cosPhiI = cos_phi(wi), sinPhiO = sin_phi(wo), cosPhiO = cos_phi(wo);
+        const float dCos = cosPhiI * cosPhiO + sinPhiI * sinPhiO;
+        maxCos = sel_max(0.f, dCos);
+    }
+    float sinAlpha, tanBeta;
+    if (abs_cos_theta(wi) > abs_cos_theta(wo)) { sinAlpha = sinThetaO; tanBeta = sinThetaI / abs_cos_theta(wi); }
+    else { sinAlpha = sinThetaI; tanBeta = sinThetaO / abs_cos_theta(wo); }
+    return b.Rd * HPRT_INV_PI * (b.orenA + b.orenB * maxCos * sinAlpha * tanBeta);
+}
 __device__ __forceinline__ float lambert_pdf(vec3 wo, vec3 wi) { return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * HPRT_INV_PI : 0; }
 // MicrofacetReflection::f / Pdf (core/reflection.cpp:226-236, 416-420), FresnelDielectric(1.5, 1)
 __device__ __forceinline__ rgb mf_f(const DevBsdf &b, vec3 wo, vec3 wi) {
@@ -541,9 +558,15 @@ __device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, D
     b->ss = normalize(si.sdpdu);
     b->ts = cross(b->ns, b->ss);
     b->alpha = 0; b->hasD = false; b->hasS = false; b->Rd = rgb(0.f); b->Rs = rgb(0.f);
+    b->hasR = false; b->Rr = rgb(0.f); b->oren = false; b->orenA = 1.f; b->orenB = 0.f;
     const DevMaterial m = sc.materials[sc.shapes[si.shape].material];
+    if (m.type == 2) {      // MirrorMaterial, materials/mirror.cpp:44-56
+        rgb kr = clamp0(ksOverride ? *ksOverride : rgb(m.Ks[0], m.Ks[1], m.Ks[2]));
+        if (!is_black(kr)) { b->hasR = true; b->Rr = kr; }
+        return;
+    }
     rgb kd = clamp0(kdOverride ? *kdOverride : rgb(m.Kd[0], m.Kd[1], m.Kd[2]));
-    if (!is_black(kd)) { b->hasD = true; b->Rd = kd; }
+    if (!is_black(kd)) { b->hasD = true; b->Rd = kd; if (m.oren) { b->oren = true; b->orenA = m.orenA; b->orenB = m.orenB; } }
     if (m.type == 1) {
         rgb ks = clamp0(ksOverride ? *ksOverride : rgb(m.Ks[0], m.Ks[1], m.Ks[2]));
         if (!is_black(ks)) { b->hasS = true; b->Rs = ks; b->alpha = m.alpha; }
@@ -564,7 +587,7 @@ __device__ __forceinline__ rgb bsdf_f(const DevBsdf &b, vec3 woW, vec3 wiW) {
     if (wo.z == 0) return rgb(0.f);
     bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
     rgb f(0.f);
-    if (b.hasD && reflect) f = f + lambert_f(b);
+    if (b.hasD && reflect) f = f + lambert_f(b, wo, wi);
     if (b.hasS && reflect) f = f + mf_f(b, wo, wi);
     return f;
 }
@@ -582,6 +605,17 @@ __device__ __forceinline__ float bsdf_pdf(const DevBsdf &b, vec3 woW, vec3 wiW) 
 // BSDF::Sample_f, core/reflection.cpp:703-762.  *pdf keeps its incoming value on the
 // "wo.z == 0" early return, as in the reference.
 __device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW, float u0, float u1, float *pdf, int *sampledType) {
+    if (b.hasR) {
+        // the one lobe is SpecularReflection (core/reflection.cpp:136-143; FresnelNoOp::Evaluate == Spectrum(1.)): BSDF::Sample_f
+        // returns its value as sampled, with its pdf of 1 (:744-760 skip specular lobes)
+        const vec3 wo = to_local(b, woW);
+        if (wo.z == 0) return rgb(0.f);
+        const vec3 wi(-wo.x, -wo.y, wo.z);
+        *pdf = 1;
+        *sampledType = BX_REFLECTION | BX_SPECULAR;
+        *wiW = to_world(b, wi);
+        return rgb(1.f) * b.Rr / abs_cos_theta(wi);
+    }
     const int matching = bsdf_num(b);
     if (matching == 0) { *pdf = 0; *sampledType = 0; return rgb(0.f); }
     const int comp = sel_min((int)floorf(u0 * matching), matching - 1);
@@ -608,7 +642,7 @@ __device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW
     if (matching > 1) *pdf /= matching;
     bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
     rgb f(0.f);
-    if (b.hasD && reflect) f = f + lambert_f(b);
+    if (b.hasD && reflect) f = f + lambert_f(b, wo, wi);
     if (b.hasS && reflect) f = f + mf_f(b, wo, wi);
     return f;
 }

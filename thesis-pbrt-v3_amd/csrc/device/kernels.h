@@ -16,7 +16,7 @@ namespace hprt {
 struct RayStream { float4 *a, *b; };                 // a = {o.xyz, tMax}   b = {d.xyz, aux}
 struct HitStream { float4 *a; float2 *b; };           // a = {t, prim, b0, b1}   b = {b2, instance or -1}; b may be null
 struct PathStream {
-    RayStream ray;          // current path segment; ray.b.w = sampler dimension (bits 0-15) | bounces (bits 16-31)
+    RayStream ray;          // current path segment; ray.b.w = sampler dimension (bits 0-15) | bounces (bits 16-30) | the segment left a specular lobe (bit 31)
     float4 *beta;           // {beta.rgb, path id}   path id = sampleInBatch * nPix + pixel
     float4 *L;              // {L.rgb, 1 if the path continues after this vertex else 0}
 };

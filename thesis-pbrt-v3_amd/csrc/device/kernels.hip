@@ -632,7 +632,8 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
                 // triangles reached directly go to the material-specialised variants; quadrics and hits inside
                 // object instances (surface interaction transformed back to world space) to the generic one
                 const bool generic = ((uint32_t)word & HIT_GENERIC) != 0u;
-                if (bounces >= maxDepth) { if (bounces == 0 && generic) bin[k] = 2; }   // only an emitter hit by a camera ray matters
+                // at the depth limit only an emitter matters, hit by a camera ray or through a specular bounce (path.cpp:97-110)
+                if (bounces >= maxDepth) { if (generic && (bounces == 0 || (__float_as_uint(in.ray.b[slot[k]].w) >> 31))) bin[k] = 2; }
                 else if (generic) bin[k] = 2;
                 else bin[k] = ((uint32_t)word & HIT_PLASTIC) ? 1 : 0;
             }
@@ -700,7 +701,8 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
         const float4 L4 = firstBounce ? make_float4(0.f, 0.f, 0.f, 1.f) : in.L[slot];
         const uint32_t st = __float_as_uint(rayB.w);
         int dim = (int)(st & 0xffffu);
-        const int bounces = (int)(st >> 16);
+        const int bounces = (int)((st >> 16) & 0x7fffu);
+        const bool specularBounce = (st >> 31) != 0u;      // the segment left a specular lobe (integrators/path.cpp:160)
         const uint32_t pathId = __float_as_uint(beta4.w);
         const uint32_t pix = pathId % rp.nPix, sIdx = pathId / rp.nPix;
         const uint64_t index = (uint64_t)rp.pixelOffset[pix] + (uint64_t)(s0 + sIdx) * (uint64_t)rp.hal.sampleStride;
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
             }
             // emitted radiance at the first vertex (path.cpp:97-107; no specular lobes exist here).
             // Emissive triangles carry TAG_GENERIC (like quadrics), so only the generic variant looks.
-            if (MODE == 2 && bounces == 0) {
+            if (MODE == 2 && (bounces == 0 || specularBounce)) {
                 const int al = prim_area_light(sc, prim);
                 if (al >= 0) {
                     rgb Le = area_L(sc.lights[al], si.n, -rayD);
@@ -792,6 +794,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
             }
             bsdf_init(sc, si, &bsdf, useKd ? &kdTex : nullptr, useKs ? &ksTex : nullptr);
             if (MODE == 0) { bsdf.hasS = false; bsdf.Rs = rgb(0.f); bsdf.alpha = 0.f; }   // matte: no microfacet lobe (matte.cpp:45-62)
+            if (MODE != 2) { bsdf.hasR = false; bsdf.oren = false; }      // mirrors and OrenNayar surfaces are shaded by the generic variant
             // ---- direct lighting (UniformSampleOneLight + EstimateDirect) ----
             if (bsdf_num(bsdf) > 0 && sc.nLights > 0) {
                 // The reference draws five sample values here (light pick, uLight, uScattering: core/integrator.cpp:96-104); a value
@@ -900,10 +903,11 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                 // The reference also traces the segment that leaves the path's last vertex (bounces == maxDepth) and then
                 // stops without using its hit: no emission is added after a non-specular bounce (path.cpp:97-110).  A plain
                 // render does not trace that ray; a counting render does, the reference counts it.
-                if (rp.cullMis && bounces + 1 >= rp.maxDepth) alive = false;
+                // (after a specular bounce the emitted radiance of that hit IS added, path.cpp:97: the segment is traced)
+                if (rp.cullMis && bounces + 1 >= rp.maxDepth && !(flags & BX_SPECULAR)) alive = false;
                 if (alive) {
                     out.ray.a[j] = make_float4(o.x, o.y, o.z, HPRT_INF);
-                    out.ray.b[j] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((uint32_t)dim | ((uint32_t)(bounces + 1) << 16)));
+                    out.ray.b[j] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((uint32_t)dim | ((uint32_t)(bounces + 1) << 16) | ((flags & BX_SPECULAR) ? 0x80000000u : 0u)));
                     out.beta[j] = make_float4(beta.r, beta.g, beta.b, beta4.w);
                     wantNext = true;
                 }

@@ -258,15 +258,17 @@ struct Frontend {
             const Param *rp = geom.find("remaproughness", "bool"); if (!rp) rp = mp->find("remaproughness", "bool");
             if (rp && rp->bools.size() == 1) remap = rp->bools[0];
             m.remapRoughness = remap ? 1 : 0;
+        } else if (name == "mirror") {      // CreateMirrorMaterial, materials/mirror.cpp:58-64
+            const float dk[3] = {0.9f, 0.9f, 0.9f};
+            m.type = kMirror;
+            spectrumParam(geom, *mp, "Kr", dk, m.Ks, &m.KsTex);
         } else {
             if (name != "matte" && name != "" && name != "none")
                 warn("material \"" + name + "\" is outside the hot-path scope; rendered as matte (SURVEY.md §2)");
             const float dk[3] = {0.5f, 0.5f, 0.5f};
             m.type = kMatte;
             spectrumParam(geom, *mp, "Kd", dk, m.Kd, &m.KdTex);
-            m.sigma = floatParam(geom, *mp, "sigma", 0.f);
-            if (m.sigma != 0.f) warn("matte sigma != 0 (OrenNayar) is outside the hot-path scope; sigma forced to 0");
-            m.sigma = 0.f;
+            m.sigma = floatParam(geom, *mp, "sigma", 0.f);      // != 0: OrenNayar (materials/matte.cpp:55-61)
         }
         std::string key((const char *)&m, sizeof(m));
         auto it = materialCache.find(key);

@@ -11,7 +11,7 @@
 
 namespace hprt {
 
-enum MaterialType { kMatte = 0, kPlastic = 1 };
+enum MaterialType { kMatte = 0, kPlastic = 1, kMirror = 2 };      // mirror: Kr travels in Ks
 enum LightType { kPointLight = 0, kDistantLight = 1, kDiffuseAreaLight = 2 };
 enum ShapeKind { kTriangleMesh = 0, kSphere = 1 };
 enum LightStrategy { kUniform = 0, kPower = 1, kSpatial = 2 };
