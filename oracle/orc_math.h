@@ -305,6 +305,8 @@ struct Spec {
     // spectrum.h:181-193: true division per channel
     Spec operator/(Float a) const { return Spec(c[0] / a, c[1] / a, c[2] / a); }
     Spec &operator/=(Float a) { c[0] /= a; c[1] /= a; c[2] /= a; return *this; }
+    Spec operator-(const Spec &s) const { return Spec(c[0] - s.c[0], c[1] - s.c[1], c[2] - s.c[2]); }      // spectrum.h:110-117
+    Spec operator/(const Spec &s) const { return Spec(c[0] / s.c[0], c[1] / s.c[1], c[2] / s.c[2]); }      // spectrum.h:118-126
     bool IsBlack() const { return c[0] == 0 && c[1] == 0 && c[2] == 0; }
     bool HasNaNs() const { return std::isnan(c[0]) || std::isnan(c[1]) || std::isnan(c[2]); }
     Float MaxComponentValue() const { Float m = c[0]; for (int i = 1; i < 3; ++i) m = smax(m, c[i]); return m; }

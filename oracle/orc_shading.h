@@ -150,17 +150,51 @@ struct TRDist {
 
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16,
        BSDF_ALL = 31 };
-enum { BXDF_LAMBERT = 0, BXDF_MICROFACET = 1, BXDF_SPECULAR_REFLECTION = 2, BXDF_OREN_NAYAR = 3 };
+enum { BXDF_LAMBERT = 0, BXDF_MICROFACET = 1, BXDF_SPECULAR_REFLECTION = 2, BXDF_OREN_NAYAR = 3, BXDF_FRESNEL_BLEND = 4,
+       BXDF_MICROFACET_CONDUCTOR = 5 };
+
+inline Spec SqrtS(const Spec &s) { return Spec(std::sqrt(s.c[0]), std::sqrt(s.c[1]), std::sqrt(s.c[2])); }
+// FrConductor, core/reflection.cpp:70-95
+inline Spec FrConductor(Float cosThetaI, const Spec &etai, const Spec &etat, const Spec &k) {
+    cosThetaI = Clamp(cosThetaI, -1, 1);
+    Spec eta = etat / etai;
+    Spec etak = k / etai;
+    Float cosThetaI2 = cosThetaI * cosThetaI;
+    Float sinThetaI2 = (Float)(1. - (double)cosThetaI2);
+    Spec eta2 = eta * eta;
+    Spec etak2 = etak * etak;
+    Spec t0 = eta2 - etak2 - Spec(sinThetaI2);
+    Spec a2plusb2 = SqrtS(t0 * t0 + 4 * eta2 * etak2);
+    Spec t1 = a2plusb2 + Spec(cosThetaI2);
+    Spec a = SqrtS(0.5f * (a2plusb2 + t0));
+    Spec t2 = (Float)2 * cosThetaI * a;
+    Spec Rs = (t1 - t2) / (t1 + t2);
+    Spec t3 = cosThetaI2 * a2plusb2 + Spec(sinThetaI2 * sinThetaI2);
+    Spec t4 = t2 * sinThetaI2;
+    Spec Rp = Rs * (t3 - t4) / (t3 + t4);
+    return (Float)0.5 * (Rp + Rs);
+}
 
 struct BxDF {
     int kind; int type;
     Spec R;
     TRDist dist;   // microfacet only; Fresnel is FresnelDielectric(1.5, 1) (plastic.cpp:56)
     Float A = 1, B = 0;   // OrenNayar (core/reflection.h:414-420)
+    Spec S, K;            // FresnelBlend: S = Rs; conductor microfacet: S = eta, K = k
     bool MatchesFlags(int t) const { return (type & t) == type; }
     Spec f(const V3 &wo, const V3 &wi) const {
         if (kind == BXDF_LAMBERT) return R * InvPi;       // reflection.cpp:178-180
         if (kind == BXDF_SPECULAR_REFLECTION) return Spec(0.f);      // reflection.h:199-201
+        if (kind == BXDF_FRESNEL_BLEND) {                 // reflection.cpp:285-298; R = Rd, S = Rs
+            auto pow5 = [](Float v) { return (v * v) * (v * v) * v; };
+            Spec diffuse = (28.f / (23.f * Pi)) * R * (Spec(1.f) - S) * (1 - pow5(1 - .5f * AbsCosTheta(wi))) * (1 - pow5(1 - .5f * AbsCosTheta(wo)));
+            V3 wh = wi + wo;
+            if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0);
+            wh = Normalize(wh);
+            Spec schlick = S + pow5(1 - Dot(wi, wh)) * (Spec(1.) - S);      // SchlickFresnel, reflection.h:485-488
+            Spec specular = dist.D(wh) / (4 * AbsDot(wi, wh) * smax(AbsCosTheta(wi), AbsCosTheta(wo))) * schlick;
+            return diffuse + specular;
+        }
         if (kind == BXDF_OREN_NAYAR) {                    // reflection.cpp:197-219
             Float sinThetaI = SinTheta(wi), sinThetaO = SinTheta(wo);
             Float maxCos = 0;
@@ -181,12 +215,19 @@ struct BxDF {
         if (cosThetaI == 0 || cosThetaO == 0) return Spec(0.);
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0.);
         wh = Normalize(wh);
-        Spec F(FrDielectric(Dot(wi, wh), 1.5f, 1.f));
+        // FresnelDielectric(1.5, 1) (plastic) or FresnelConductor(1, eta = S, k = K) (metal: Evaluate takes |cos|, reflection.cpp:118-120)
+        Spec F = kind == BXDF_MICROFACET_CONDUCTOR ? FrConductor(std::abs(Dot(wi, wh)), Spec(1.), S, K) : Spec(FrDielectric(Dot(wi, wh), 1.5f, 1.f));
         return R * dist.D(wh) * dist.G(wo, wi) * F / (4 * cosThetaI * cosThetaO);
     }
     Float Pdf(const V3 &wo, const V3 &wi) const {
         if (kind == BXDF_SPECULAR_REFLECTION) return 0;                                          // reflection.h:204
         if (kind == BXDF_LAMBERT || kind == BXDF_OREN_NAYAR) return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * InvPi : 0;   // :387-389
+        if (kind == BXDF_FRESNEL_BLEND) {                                                        // :470-475
+            if (!SameHemisphere(wo, wi)) return 0;
+            V3 wh = Normalize(wo + wi);
+            Float pdf_wh = dist.Pdf(wo, wh);
+            return .5f * (AbsCosTheta(wi) * InvPi + pdf_wh / (4 * Dot(wo, wh)));
+        }
         if (!SameHemisphere(wo, wi)) return 0;                                                   // :416-420
         V3 wh = Normalize(wo + wi);
         return dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
@@ -196,6 +237,21 @@ struct BxDF {
             *wi = V3(-wo.x, -wo.y, wo.z);
             *pdf = 1;
             return Spec(1.f) * R / AbsCosTheta(*wi);
+        }
+        if (kind == BXDF_FRESNEL_BLEND) {                  // :450-468
+            P2 uu = u;
+            if (uu.x < .5) {
+                uu.x = smin(2 * uu.x, OneMinusEpsilon);
+                *wi = CosineSampleHemisphere(uu);
+                if (wo.z < 0) wi->z *= -1;
+            } else {
+                uu.x = smin(2 * (uu.x - .5f), OneMinusEpsilon);
+                V3 wh = dist.Sample_wh(wo, uu);
+                *wi = Reflect(wo, wh);
+                if (!SameHemisphere(wo, *wi)) return Spec(0.f);
+            }
+            *pdf = Pdf(wo, *wi);
+            return f(wo, *wi);
         }
         if (kind == BXDF_LAMBERT || kind == BXDF_OREN_NAYAR) {      // :378-385
             *wi = CosineSampleHemisphere(u);
@@ -408,6 +464,22 @@ inline void ComputeScatteringFunctions(const Scene &scene, const Material &m, co
                 b.B = 0.45f * sigma2 / (sigma2 + 0.09f);
             }
         }
+    } else if (m.type == MAT_SUBSTRATE) {      // materials/substrate.cpp:44-65 (roughness = uroughness, sigma = vroughness)
+        Spec d = Kd.Clamp(), sp = Ks.Clamp();
+        Float roughu = m.roughness, roughv = m.sigma;
+        if (!d.IsBlack() || !sp.IsBlack()) {
+            if (m.remap) { roughu = RoughnessToAlpha(roughu); roughv = RoughnessToAlpha(roughv); }
+            BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+            b.kind = BXDF_FRESNEL_BLEND; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.R = d; b.S = sp;
+            b.dist.alphax = roughu; b.dist.alphay = roughv;
+        }
+    } else if (m.type == MAT_METAL) {          // materials/metal.cpp:59-79 (Kd = eta, Ks = k; no Clamp)
+        Float uRough = m.roughness, vRough = m.sigma;
+        if (m.remap) { uRough = RoughnessToAlpha(uRough); vRough = RoughnessToAlpha(vRough); }
+        BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+        b.kind = BXDF_MICROFACET_CONDUCTOR; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.R = Spec(1.);
+        b.S = Spec(m.Kd[0], m.Kd[1], m.Kd[2]); b.K = Spec(m.Ks[0], m.Ks[1], m.Ks[2]);
+        b.dist.alphax = uRough; b.dist.alphay = vRough;
     } else {
         Spec kd = Kd.Clamp();
         if (!kd.IsBlack()) {

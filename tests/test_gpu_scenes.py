@@ -114,6 +114,14 @@ CASES = {
     "mirror_at_the_depth_limit": _scene(SPHERE_LIGHT + MATTE + 'Shape "trianglemesh" ' + FLOOR + '\nMaterial "mirror"\nShape "trianglemesh" ' + BUMPY + "\n", maxdepth=1, spp=8),
     "mirror_only_point_light": _scene('LightSource "point" "point from" [1 -2 4] "color I" [30 30 30]\nMaterial "mirror"\nShape "trianglemesh" ' + BUMPY + "\n" + MATTE +
                                       'Shape "trianglemesh" ' + FLOOR + "\n", maxdepth=3),
+    # ---- substrate (FresnelBlend, anisotropic Trowbridge-Reitz) and metal (conductor microfacet, FrConductor) ----
+    "substrate_and_metal": _scene(SPHERE_LIGHT + 'LightSource "point" "point from" [-2 -2 3] "color I" [5 5 7]\n'
+                                  'Material "substrate" "color Kd" [.5 .3 .2] "color Ks" [.04 .04 .04] "float uroughness" [.15] "float vroughness" [.05] "bool remaproughness" "false"\n'
+                                  'Shape "trianglemesh" ' + FLOOR + '\nMaterial "metal" "rgb eta" [1.65746 0.880369 0.521229] "rgb k" [9.223869 6.269523 4.837001] '
+                                  '"bool remaproughness" "false" "float uroughness" [.02] "float vroughness" [.08]\nShape "trianglemesh" ' + BUMPY +
+                                  '\nAttributeBegin\nMaterial "substrate"\nTranslate -1.2 .6 .5\nShape "sphere" "float radius" [.45]\nAttributeEnd\n'
+                                  'AttributeBegin\nMaterial "metal" "rgb eta" [.2 .9 1.1] "rgb k" [3.9 2.4 2.2] "float roughness" [.05]\nTranslate 1.2 .2 .3\n'
+                                  'Shape "sphere" "float radius" [.4]\nAttributeEnd\n', integ=UNIFORM, spp=8, maxdepth=5),
     "no_lights": _scene(GEOM),
     "empty_scene": _scene(""),
     "light_only": _scene(SPHERE_LIGHT),

@@ -345,7 +345,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
                     // a triangle of an emissive mesh: aux = 1 + its light, and TAG_GENERIC — the generic shading variant is the one that looks for Le
                     const int32_t triLight = sh.area_light >= 0 ? sh.area_light + (int32_t)e.local : -1;
                     if (triLight >= 0) lightPrim[triLight] = (int32_t)i;
-                    uint32_t tag = (bogus ? TAG_BOGUS : 0u) | (md.type == 1 ? TAG_PLASTIC : 0u) | (md.kd_texture >= 0 || md.ks_texture >= 0 || triLight >= 0 || md.type == 2 || (md.type == 0 && clampf(md.sigma, 0.f, 90.f) != 0.f) ? TAG_GENERIC : 0u);      // (mirror, OrenNayar: generic variant)
+                    uint32_t tag = (bogus ? TAG_BOGUS : 0u) | (md.type == 1 ? TAG_PLASTIC : 0u) | (md.kd_texture >= 0 || md.ks_texture >= 0 || triLight >= 0 || md.type >= 2 || (md.type == 0 && clampf(md.sigma, 0.f, 90.f) != 0.f) ? TAG_GENERIC : 0u);      // (mirror, substrate, metal, OrenNayar: generic variant)
                     r0 = make_float4(a[0], a[1], a[2], u2f(tag)); r1 = make_float4(b[0], b[1], b[2], u2f(s)); r2 = make_float4(c[0], c[1], c[2], u2f((uint32_t)(triLight + 1)));
                     for (int k = 0; k < 3; ++k) {
                         primVtx[3 * i + k] = (uint32_t)(vtxBase[s] + (uint32_t)v[k]);
@@ -361,12 +361,14 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     std::vector<DevMaterial> mats(d->n_materials);
     for (uint32_t m = 0; m < d->n_materials; ++m) {
         const HprtMaterialDesc &in = d->materials[m];
-        if (in.type < 0 || in.type > 2) return SetError(HPRT_E_UNSUPPORTED, "material type outside the hot-path scope (matte, plastic, mirror)");
+        if (in.type < 0 || in.type > 4) return SetError(HPRT_E_UNSUPPORTED, "material type outside the hot-path scope (matte, plastic, mirror, substrate, metal)");
         if (in.kd_texture >= (int32_t)d->n_textures || in.ks_texture >= (int32_t)d->n_textures) return SetError(HPRT_E_INVALID, "material texture index out of range");
         DevMaterial &o = mats[m];
         o.KdTex = in.kd_texture >= 0 ? in.kd_texture : -1; o.KsTex = in.ks_texture >= 0 ? in.ks_texture : -1;
         o.type = in.type; memcpy(o.Kd, in.Kd, 12); memcpy(o.Ks, in.Ks, 12);
         o.alpha = in.remap_roughness ? RoughnessToAlpha(in.roughness) : in.roughness;
+        o.alphaY = o.alpha;
+        if (in.type >= 3) o.alphaY = in.remap_roughness ? RoughnessToAlpha(in.sigma) : in.sigma;      // substrate / metal: sigma carries vroughness
         // MatteMaterial: sig = Clamp(sigma, 0, 90); sig != 0 -> OrenNayar(r, sig) (materials/matte.cpp:55-61, core/reflection.h:414-420)
         const float sig = clampf(in.sigma, 0.f, 90.f);
         o.oren = in.type == 0 && sig != 0.f ? 1 : 0; o.orenA = 1.f; o.orenB = 0.f;

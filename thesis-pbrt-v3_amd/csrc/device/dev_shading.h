@@ -318,6 +318,9 @@ struct DevBsdf {
     bool hasR;             // a SpecularReflection lobe with FresnelNoOp (mirror): the BSDF's only lobe when present
     rgb Rr;
     bool oren; float orenA, orenB;      // the diffuse lobe is OrenNayar, not LambertianReflection
+    float alphaY;          // Trowbridge-Reitz alpha along v (== alpha for plastic)
+    int kind;              // 0: the lobes above; 2: ONE FresnelBlend lobe (substrate: Rd, Rs, alpha, alphaY); 3: ONE conductor
+                           // microfacet lobe (metal: Rd = eta, Rs = k, R = 1).  Kinds 2 and 3 are flagged hasS (a glossy reflection lobe)
 };
 __device__ __forceinline__ float cos_theta(vec3 w) { return w.z; }
 __device__ __forceinline__ float cos2_theta(vec3 w) { return w.z * w.z; }
@@ -345,24 +348,24 @@ __device__ __forceinline__ float fr_dielectric(float cosThetaI, float etaI, floa
     float Rperp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
     return (Rparl * Rparl + Rperp * Rperp) / 2;
 }
-// TrowbridgeReitzDistribution (core/microfacet.cpp:163-193, 238-344), alphax == alphay == a
-__device__ __forceinline__ float tr_D(float a, vec3 wh) {
+// TrowbridgeReitzDistribution (core/microfacet.cpp:163-193, 238-344)
+__device__ __forceinline__ float tr_D(float ax, float ay, vec3 wh) {
     float tan2Theta = tan2_theta(wh);
     if (is_inf(tan2Theta)) return 0.;
     const float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
-    float e = (cos2_phi(wh) / (a * a) + sin2_phi(wh) / (a * a)) * tan2Theta;
-    return 1 / (HPRT_PI * a * a * cos4Theta * (1 + e) * (1 + e));
+    float e = (cos2_phi(wh) / (ax * ax) + sin2_phi(wh) / (ay * ay)) * tan2Theta;
+    return 1 / (HPRT_PI * ax * ay * cos4Theta * (1 + e) * (1 + e));
 }
-__device__ __forceinline__ float tr_lambda(float a, vec3 w) {
+__device__ __forceinline__ float tr_lambda(float ax, float ay, vec3 w) {
     float absTanTheta = fabsf(tan_theta(w));
     if (is_inf(absTanTheta)) return 0.;
-    float alpha = sqrtf(cos2_phi(w) * a * a + sin2_phi(w) * a * a);
+    float alpha = sqrtf(cos2_phi(w) * ax * ax + sin2_phi(w) * ay * ay);
     float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
     return (-1 + sqrtf(1.f + alpha2Tan2Theta)) / 2;
 }
-__device__ __forceinline__ float tr_G1(float a, vec3 w) { return 1 / (1 + tr_lambda(a, w)); }
-__device__ __forceinline__ float tr_G(float a, vec3 wo, vec3 wi) { return 1 / (1 + tr_lambda(a, wo) + tr_lambda(a, wi)); }
-__device__ __forceinline__ float tr_pdf(float a, vec3 wo, vec3 wh) { return tr_D(a, wh) * tr_G1(a, wo) * absdot(wo, wh) / abs_cos_theta(wo); }
+__device__ __forceinline__ float tr_G1(float ax, float ay, vec3 w) { return 1 / (1 + tr_lambda(ax, ay, w)); }
+__device__ __forceinline__ float tr_G(float ax, float ay, vec3 wo, vec3 wi) { return 1 / (1 + tr_lambda(ax, ay, wo) + tr_lambda(ax, ay, wi)); }
+__device__ __forceinline__ float tr_pdf(float ax, float ay, vec3 wo, vec3 wh) { return tr_D(ax, ay, wh) * tr_G1(ax, ay, wo) * absdot(wo, wh) / abs_cos_theta(wo); }
 __device__ __forceinline__ void tr_sample11(float cosTheta, float U1, float U2, float *slope_x, float *slope_y) {
     if ((double)cosTheta > .9999) {
         float r = sqrtf(U1 / (1 - U1));
@@ -391,16 +394,16 @@ __device__ __forceinline__ void tr_sample11(float cosTheta, float U1, float U2, 
               (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
     *slope_y = S * z * sqrtf(1.f + *slope_x * *slope_x);
 }
-__device__ __forceinline__ vec3 tr_sample_wh(float a, vec3 wo, float u0, float u1) {
+__device__ __forceinline__ vec3 tr_sample_wh(float ax, float ay, vec3 wo, float u0, float u1) {
     bool flip = wo.z < 0;
     vec3 wi = flip ? -wo : wo;
-    vec3 wiS = normalize(vec3(a * wi.x, a * wi.y, wi.z));
+    vec3 wiS = normalize(vec3(ax * wi.x, ay * wi.y, wi.z));
     float sx, sy;
     tr_sample11(cos_theta(wiS), u0, u1, &sx, &sy);
     float tmp = cos_phi(wiS) * sx - sin_phi(wiS) * sy;
     sy = sin_phi(wiS) * sx + cos_phi(wiS) * sy;
     sx = tmp;
-    sx = a * sx; sy = a * sy;
+    sx = ax * sx; sy = ay * sy;
     vec3 wh = normalize(vec3(-sx, -sy, 1.f));
     if (flip) wh = -wh;
     return wh;
@@ -423,6 +426,28 @@ __device__ __forceinline__ rgb lambert_f(const DevBsdf &b, vec3 wo, vec3 wi) {
     return b.Rd * HPRT_INV_PI * (b.orenA + b.orenB * maxCos * sinAlpha * tanBeta);
 }
 __device__ __forceinline__ float lambert_pdf(vec3 wo, vec3 wi) { return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * HPRT_INV_PI : 0; }
+__device__ __forceinline__ rgb rgb_sqrt(rgb a) { return rgb(sqrtf(a.r), sqrtf(a.g), sqrtf(a.b)); }
+__device__ __forceinline__ rgb rgb_sub(rgb a, rgb b) { return rgb(a.r - b.r, a.g - b.g, a.b - b.b); }
+__device__ __forceinline__ rgb rgb_div(rgb a, rgb b) { return rgb(a.r / b.r, a.g / b.g, a.b / b.b); }
+// FrConductor(cosThetaI, etai = 1, etat = eta, k), core/reflection.cpp:70-95
+__device__ __forceinline__ rgb fr_conductor(float cosThetaI, rgb etat, rgb k) {
+    cosThetaI = clampf(cosThetaI, -1, 1);
+    const rgb etai(1.f);
+    const rgb eta = rgb_div(etat, etai), etak = rgb_div(k, etai);
+    const float cosThetaI2 = cosThetaI * cosThetaI;
+    const float sinThetaI2 = (float)(1. - (double)cosThetaI2);
+    const rgb eta2 = eta * eta, etak2 = etak * etak;
+    const rgb t0 = rgb_sub(rgb_sub(eta2, etak2), rgb(sinThetaI2));
+    const rgb a2plusb2 = rgb_sqrt(t0 * t0 + (eta2 * 4.f) * etak2);
+    const rgb t1 = a2plusb2 + rgb(cosThetaI2);
+    const rgb a = rgb_sqrt((a2plusb2 + t0) * 0.5f);
+    const rgb t2 = a * ((float)2 * cosThetaI);
+    const rgb Rs = rgb_div(rgb_sub(t1, t2), t1 + t2);
+    const rgb t3 = a2plusb2 * cosThetaI2 + rgb(sinThetaI2 * sinThetaI2);
+    const rgb t4 = t2 * sinThetaI2;
+    const rgb Rp = rgb_div(Rs * rgb_sub(t3, t4), t3 + t4);
+    return (Rp + Rs) * 0.5f;
+}
 // MicrofacetReflection::f / Pdf (core/reflection.cpp:226-236, 416-420), FresnelDielectric(1.5, 1)
 __device__ __forceinline__ rgb mf_f(const DevBsdf &b, vec3 wo, vec3 wi) {
     float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
@@ -430,15 +455,34 @@ __device__ __forceinline__ rgb mf_f(const DevBsdf &b, vec3 wo, vec3 wi) {
     if (cosThetaI == 0 || cosThetaO == 0) return rgb(0.f);
     if (wh.x == 0 && wh.y == 0 && wh.z == 0) return rgb(0.f);
     wh = normalize(wh);
+    // FresnelDielectric(1.5, 1) (plastic), or FresnelConductor(1, eta, k) with R = 1 (metal: Rd = eta, Rs = k)
+    if (b.kind == 3) return rgb(1.f) * tr_D(b.alpha, b.alphaY, wh) * tr_G(b.alpha, b.alphaY, wo, wi) * fr_conductor(fabsf(dot(wi, wh)), b.Rd, b.Rs) / (4 * cosThetaI * cosThetaO);
     rgb F(fr_dielectric(dot(wi, wh), 1.5f, 1.f));
-    return b.Rs * tr_D(b.alpha, wh) * tr_G(b.alpha, wo, wi) * F / (4 * cosThetaI * cosThetaO);
+    return b.Rs * tr_D(b.alpha, b.alphaY, wh) * tr_G(b.alpha, b.alphaY, wo, wi) * F / (4 * cosThetaI * cosThetaO);
 }
 __device__ __forceinline__ float mf_pdf(const DevBsdf &b, vec3 wo, vec3 wi) {
     if (!same_hemisphere(wo, wi)) return 0;
     vec3 wh = normalize(wo + wi);
-    return tr_pdf(b.alpha, wo, wh) / (4 * dot(wo, wh));
+    return tr_pdf(b.alpha, b.alphaY, wo, wh) / (4 * dot(wo, wh));
 }
 
+// FresnelBlend (core/reflection.cpp:285-298, 450-475): Rd, Rs, alpha, alphaY
+__device__ __forceinline__ float pow5f(float v) { return (v * v) * (v * v) * v; }
+__device__ __forceinline__ rgb blend_f(const DevBsdf &b, vec3 wo, vec3 wi) {
+    const rgb diffuse = b.Rd * (28.f / (23.f * HPRT_PI)) * rgb_sub(rgb(1.f), b.Rs) * (1 - pow5f(1 - .5f * abs_cos_theta(wi))) * (1 - pow5f(1 - .5f * abs_cos_theta(wo)));
+    vec3 wh = wi + wo;
+    if (wh.x == 0 && wh.y == 0 && wh.z == 0) return rgb(0.f);
+    wh = normalize(wh);
+    const rgb schlick = b.Rs + rgb_sub(rgb(1.f), b.Rs) * pow5f(1 - dot(wi, wh));
+    const rgb specular = schlick * (tr_D(b.alpha, b.alphaY, wh) / (4 * absdot(wi, wh) * sel_max(abs_cos_theta(wi), abs_cos_theta(wo))));
+    return diffuse + specular;
+}
+__device__ __forceinline__ float blend_pdf(const DevBsdf &b, vec3 wo, vec3 wi) {
+    if (!same_hemisphere(wo, wi)) return 0;
+    const vec3 wh = normalize(wo + wi);
+    const float pdf_wh = tr_pdf(b.alpha, b.alphaY, wo, wh);
+    return .5f * (abs_cos_theta(wi) * HPRT_INV_PI + pdf_wh / (4 * dot(wo, wh)));
+}
 // materials/matte.cpp:45-62, materials/plastic.cpp:45-70: lobes are added in the order
 // diffuse, specular; a black reflectance adds no lobe.
 // ---- image textures: SurfaceInteraction::ComputeDifferentials (core/interaction.cpp:103-149, the (u,v) part),
@@ -560,6 +604,16 @@ __device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, D
     b->alpha = 0; b->hasD = false; b->hasS = false; b->Rd = rgb(0.f); b->Rs = rgb(0.f);
     b->hasR = false; b->Rr = rgb(0.f); b->oren = false; b->orenA = 1.f; b->orenB = 0.f;
     const DevMaterial m = sc.materials[sc.shapes[si.shape].material];
+    b->alphaY = 0; b->kind = 0;
+    if (m.type == 3) {      // SubstrateMaterial, materials/substrate.cpp:44-65: one FresnelBlend lobe unless both reflectances are black
+        const rgb d = clamp0(kdOverride ? *kdOverride : rgb(m.Kd[0], m.Kd[1], m.Kd[2])), sp = clamp0(ksOverride ? *ksOverride : rgb(m.Ks[0], m.Ks[1], m.Ks[2]));
+        if (!is_black(d) || !is_black(sp)) { b->kind = 2; b->hasS = true; b->Rd = d; b->Rs = sp; b->alpha = m.alpha; b->alphaY = m.alphaY; }
+        return;
+    }
+    if (m.type == 4) {      // MetalMaterial, materials/metal.cpp:59-79: one conductor microfacet lobe, always
+        b->kind = 3; b->hasS = true; b->Rd = rgb(m.Kd[0], m.Kd[1], m.Kd[2]); b->Rs = rgb(m.Ks[0], m.Ks[1], m.Ks[2]); b->alpha = m.alpha; b->alphaY = m.alphaY;
+        return;
+    }
     if (m.type == 2) {      // MirrorMaterial, materials/mirror.cpp:44-56
         rgb kr = clamp0(ksOverride ? *ksOverride : rgb(m.Ks[0], m.Ks[1], m.Ks[2]));
         if (!is_black(kr)) { b->hasR = true; b->Rr = kr; }
@@ -569,7 +623,7 @@ __device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, D
     if (!is_black(kd)) { b->hasD = true; b->Rd = kd; if (m.oren) { b->oren = true; b->orenA = m.orenA; b->orenB = m.orenB; } }
     if (m.type == 1) {
         rgb ks = clamp0(ksOverride ? *ksOverride : rgb(m.Ks[0], m.Ks[1], m.Ks[2]));
-        if (!is_black(ks)) { b->hasS = true; b->Rs = ks; b->alpha = m.alpha; }
+        if (!is_black(ks)) { b->hasS = true; b->Rs = ks; b->alpha = m.alpha; b->alphaY = m.alpha; }
     }
 }
 __device__ __forceinline__ vec3 to_local(const DevBsdf &b, vec3 v) { return vec3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
@@ -588,7 +642,7 @@ __device__ __forceinline__ rgb bsdf_f(const DevBsdf &b, vec3 woW, vec3 wiW) {
     bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
     rgb f(0.f);
     if (b.hasD && reflect) f = f + lambert_f(b, wo, wi);
-    if (b.hasS && reflect) f = f + mf_f(b, wo, wi);
+    if (b.hasS && reflect) f = f + (b.kind == 2 ? blend_f(b, wo, wi) : mf_f(b, wo, wi));
     return f;
 }
 // BSDF::Pdf, core/reflection.cpp:764-778
@@ -599,7 +653,7 @@ __device__ __forceinline__ float bsdf_pdf(const DevBsdf &b, vec3 woW, vec3 wiW) 
     if (wo.z == 0) return 0.f;
     float pdf = 0.f;
     if (b.hasD) pdf += lambert_pdf(wo, wi);
-    if (b.hasS) pdf += mf_pdf(b, wo, wi);
+    if (b.hasS) pdf += b.kind == 2 ? blend_pdf(b, wo, wi) : mf_pdf(b, wo, wi);
     return pdf / matching;
 }
 // BSDF::Sample_f, core/reflection.cpp:703-762.  *pdf keeps its incoming value on the
@@ -631,10 +685,25 @@ __device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW
         wi = vec3(dx, dy, z);
         if (wo.z < 0) wi.z *= -1;
         *pdf = lambert_pdf(wo, wi);
+    } else if (b.kind == 2) {      // FresnelBlend::Sample_f, core/reflection.cpp:450-468
+        float v0 = ur0;
+        if ((double)v0 < .5) {
+            v0 = sel_min(2 * v0, HPRT_ONE_MINUS_EPS);
+            float dx, dy; concentric_disk(v0, u1, &dx, &dy);
+            float z = sqrtf(sel_max(0.f, 1 - dx * dx - dy * dy));
+            wi = vec3(dx, dy, z);
+            if (wo.z < 0) wi.z *= -1;
+            *pdf = blend_pdf(b, wo, wi);
+        } else {
+            v0 = sel_min(2 * (v0 - .5f), HPRT_ONE_MINUS_EPS);
+            vec3 wh = tr_sample_wh(b.alpha, b.alphaY, wo, v0, u1);
+            wi = -wo + 2 * dot(wo, wh) * wh;
+            if (same_hemisphere(wo, wi)) *pdf = blend_pdf(b, wo, wi);
+        }
     } else {              // MicrofacetReflection::Sample_f, core/reflection.cpp:402-414 (wo.z != 0 here)
-        vec3 wh = tr_sample_wh(b.alpha, wo, ur0, u1);
+        vec3 wh = tr_sample_wh(b.alpha, b.alphaY, wo, ur0, u1);
         wi = -wo + 2 * dot(wo, wh) * wh;
-        if (same_hemisphere(wo, wi)) *pdf = tr_pdf(b.alpha, wo, wh) / (4 * dot(wo, wh));
+        if (same_hemisphere(wo, wi)) *pdf = tr_pdf(b.alpha, b.alphaY, wo, wh) / (4 * dot(wo, wh));
     }
     if (*pdf == 0) { *sampledType = 0; return rgb(0.f); }
     *wiW = to_world(b, wi);
@@ -643,7 +712,7 @@ __device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW
     bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
     rgb f(0.f);
     if (b.hasD && reflect) f = f + lambert_f(b, wo, wi);
-    if (b.hasS && reflect) f = f + mf_f(b, wo, wi);
+    if (b.hasS && reflect) f = f + (b.kind == 2 ? blend_f(b, wo, wi) : mf_f(b, wo, wi));
     return f;
 }
 

@@ -794,7 +794,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
             }
             bsdf_init(sc, si, &bsdf, useKd ? &kdTex : nullptr, useKs ? &ksTex : nullptr);
             if (MODE == 0) { bsdf.hasS = false; bsdf.Rs = rgb(0.f); bsdf.alpha = 0.f; }   // matte: no microfacet lobe (matte.cpp:45-62)
-            if (MODE != 2) { bsdf.hasR = false; bsdf.oren = false; }      // mirrors and OrenNayar surfaces are shaded by the generic variant
+            if (MODE != 2) { bsdf.hasR = false; bsdf.oren = false; bsdf.kind = 0; }      // mirror, substrate, metal and OrenNayar surfaces are shaded by the generic variant
             // ---- direct lighting (UniformSampleOneLight + EstimateDirect) ----
             if (bsdf_num(bsdf) > 0 && sc.nLights > 0) {
                 // The reference draws five sample values here (light pick, uLight, uScattering: core/integrator.cpp:96-104); a value

@@ -258,6 +258,34 @@ struct Frontend {
             const Param *rp = geom.find("remaproughness", "bool"); if (!rp) rp = mp->find("remaproughness", "bool");
             if (rp && rp->bools.size() == 1) remap = rp->bools[0];
             m.remapRoughness = remap ? 1 : 0;
+        } else if (name == "substrate") {   // CreateSubstrateMaterial, materials/substrate.cpp:67-82
+            const float dk[3] = {0.5f, 0.5f, 0.5f};
+            m.type = kSubstrate;
+            spectrumParam(geom, *mp, "Kd", dk, m.Kd, &m.KdTex);
+            spectrumParam(geom, *mp, "Ks", dk, m.Ks, &m.KsTex);
+            m.roughness = floatParam(geom, *mp, "uroughness", .1f);
+            m.sigma = floatParam(geom, *mp, "vroughness", .1f);
+            bool remap = true;
+            const Param *rp = geom.find("remaproughness", "bool"); if (!rp) rp = mp->find("remaproughness", "bool");
+            if (rp && rp->bools.size() == 1) remap = rp->bools[0];
+            m.remapRoughness = remap ? 1 : 0;
+        } else if (name == "metal" && (mp->find("eta", "rgb") || mp->find("eta", "color") || geom.find("eta", "rgb") || geom.find("eta", "color"))) {
+            // CreateMetalMaterial, materials/metal.cpp:115-134 — with eta and k given as RGB; their defaults are the measured
+            // copper SPECTRA (metal.cpp:81-113), which an RGB build converts through its CIE tables: outside this scope
+            const float one[3] = {1.f, 1.f, 1.f};
+            int dummy = -1;
+            m.type = kMetal;
+            spectrumParam(geom, *mp, "eta", one, m.Kd, &dummy);
+            spectrumParam(geom, *mp, "k", one, m.Ks, &dummy);
+            if (!(mp->find("k", "rgb") || mp->find("k", "color") || geom.find("k", "rgb") || geom.find("k", "color")))
+                warn("metal without an RGB \"k\": the copper default is spectral data outside the scope; k = 1 used");
+            const float rough = floatParam(geom, *mp, "roughness", .01f);
+            m.roughness = floatParam(geom, *mp, "uroughness", rough);      // GetFloatTextureOrNull: the common roughness when absent
+            m.sigma = floatParam(geom, *mp, "vroughness", rough);
+            bool remap = true;
+            const Param *rp = geom.find("remaproughness", "bool"); if (!rp) rp = mp->find("remaproughness", "bool");
+            if (rp && rp->bools.size() == 1) remap = rp->bools[0];
+            m.remapRoughness = remap ? 1 : 0;
         } else if (name == "mirror") {      // CreateMirrorMaterial, materials/mirror.cpp:58-64
             const float dk[3] = {0.9f, 0.9f, 0.9f};
             m.type = kMirror;
