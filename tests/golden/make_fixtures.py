@@ -29,9 +29,11 @@ gets the resulting files with the repository snapshot.
                          real stand-in for BASELINE.json's conference-room configuration.  Everything outside the hot
                          path's scope is replaced here, in the text, before parsing: the environment light (its map is
                          not in the repository) by a point light under the ceiling, sobol by halton, the triangle filter
-                         by the box filter, maxdepth 65 by 5, image-mapped parameters by constants (the float pyramids
-                         would add 37 MB); substrate / metal / glass / mirror / uber materials become matte with their Kd
-                         (front-end substitution, recorded as warnings).  No reference render exists for it (the
+                         by the box filter, maxdepth 65 by 5, image-mapped parameters by constants (two of the four
+                         image files are not in the repository, the float pyramids of the others would add 37 MB).
+                         Its matte (incl. the OrenNayar plant pot), substrate, metal and mirror materials are kept (round
+                         2); glass and uber become matte with their Kd (front-end substitution, recorded as warnings).
+                         No reference render exists for it (the
                          checked-in TungstenRender.png is another renderer's): it pins nothing, it is a workload.
 """
 import importlib
