@@ -562,6 +562,10 @@ struct Renderer {
             if (f.IsBlack() || pdf == 0.f) break;
             beta *= f * AbsDot(wi, isect.shading.n) / pdf;
             specularBounce = (flags & BSDF_SPECULAR) != 0;
+            if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {      // path.cpp:154-162
+                Float eta = bsdf.eta;
+                etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+            }
             ray = SpawnRay(isect.p, isect.pError, isect.n, wi);
             rdiff.has = false;
             Spec rrBeta = beta * etaScale;

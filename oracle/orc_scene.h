@@ -12,7 +12,7 @@
 
 namespace orc {
 
-enum { MAT_MATTE = 0, MAT_PLASTIC = 1, MAT_MIRROR = 2, MAT_SUBSTRATE = 3, MAT_METAL = 4 };
+enum { MAT_MATTE = 0, MAT_PLASTIC = 1, MAT_MIRROR = 2, MAT_SUBSTRATE = 3, MAT_METAL = 4, MAT_GLASS = 5 };      // glass: Kd = Kt, Ks = Kr, roughness = eta
 // mirror: Kr travels in Ks; substrate: roughness = uroughness, sigma = vroughness; metal: Kd = eta, Ks = k, roughness / sigma likewise
 enum { LIGHT_POINT = 0, LIGHT_DISTANT = 1, LIGHT_AREA = 2 };
 enum { SHAPE_MESH = 0, SHAPE_SPHERE = 1 };

@@ -55,6 +55,16 @@ inline Float Cos2Phi(const V3 &w) { return CosPhi(w) * CosPhi(w); }
 inline Float Sin2Phi(const V3 &w) { return SinPhi(w) * SinPhi(w); }
 inline V3 Reflect(const V3 &wo, const V3 &n) { return -wo + 2 * Dot(wo, n) * n; }
 inline bool SameHemisphere(const V3 &w, const V3 &wp) { return w.z * wp.z > 0; }
+// core/reflection.h:96-108
+inline bool Refract(const V3 &wi, const V3 &n, Float eta, V3 *wt) {
+    Float cosThetaI = Dot(n, wi);
+    Float sin2ThetaI = smax(Float(0), Float(1 - cosThetaI * cosThetaI));
+    Float sin2ThetaT = eta * eta * sin2ThetaI;
+    if (sin2ThetaT >= 1) return false;
+    Float cosThetaT = std::sqrt(1 - sin2ThetaT);
+    *wt = eta * -wi + (eta * cosThetaI - cosThetaT) * n;
+    return true;
+}
 
 // core/reflection.cpp:47-68
 inline Float FrDielectric(Float cosThetaI, Float etaI, Float etaT) {
@@ -151,7 +161,7 @@ struct TRDist {
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16,
        BSDF_ALL = 31 };
 enum { BXDF_LAMBERT = 0, BXDF_MICROFACET = 1, BXDF_SPECULAR_REFLECTION = 2, BXDF_OREN_NAYAR = 3, BXDF_FRESNEL_BLEND = 4,
-       BXDF_MICROFACET_CONDUCTOR = 5 };
+       BXDF_MICROFACET_CONDUCTOR = 5, BXDF_FRESNEL_SPECULAR = 6 };
 
 inline Spec SqrtS(const Spec &s) { return Spec(std::sqrt(s.c[0]), std::sqrt(s.c[1]), std::sqrt(s.c[2])); }
 // FrConductor, core/reflection.cpp:70-95
@@ -180,11 +190,12 @@ struct BxDF {
     Spec R;
     TRDist dist;   // microfacet only; Fresnel is FresnelDielectric(1.5, 1) (plastic.cpp:56)
     Float A = 1, B = 0;   // OrenNayar (core/reflection.h:414-420)
-    Spec S, K;            // FresnelBlend: S = Rs; conductor microfacet: S = eta, K = k
+    Spec S, K;            // FresnelBlend: S = Rs; conductor microfacet: S = eta, K = k; FresnelSpecular: S = T
+    Float etaA = 1, etaB = 1;      // FresnelSpecular (TransportMode::Radiance)
     bool MatchesFlags(int t) const { return (type & t) == type; }
     Spec f(const V3 &wo, const V3 &wi) const {
         if (kind == BXDF_LAMBERT) return R * InvPi;       // reflection.cpp:178-180
-        if (kind == BXDF_SPECULAR_REFLECTION) return Spec(0.f);      // reflection.h:199-201
+        if (kind == BXDF_SPECULAR_REFLECTION || kind == BXDF_FRESNEL_SPECULAR) return Spec(0.f);      // reflection.h:199-201, 527-529
         if (kind == BXDF_FRESNEL_BLEND) {                 // reflection.cpp:285-298; R = Rd, S = Rs
             auto pow5 = [](Float v) { return (v * v) * (v * v) * v; };
             Spec diffuse = (28.f / (23.f * Pi)) * R * (Spec(1.f) - S) * (1 - pow5(1 - .5f * AbsCosTheta(wi))) * (1 - pow5(1 - .5f * AbsCosTheta(wo)));
@@ -220,7 +231,7 @@ struct BxDF {
         return R * dist.D(wh) * dist.G(wo, wi) * F / (4 * cosThetaI * cosThetaO);
     }
     Float Pdf(const V3 &wo, const V3 &wi) const {
-        if (kind == BXDF_SPECULAR_REFLECTION) return 0;                                          // reflection.h:204
+        if (kind == BXDF_SPECULAR_REFLECTION || kind == BXDF_FRESNEL_SPECULAR) return 0;               // reflection.h:204, 532
         if (kind == BXDF_LAMBERT || kind == BXDF_OREN_NAYAR) return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * InvPi : 0;   // :387-389
         if (kind == BXDF_FRESNEL_BLEND) {                                                        // :470-475
             if (!SameHemisphere(wo, wi)) return 0;
@@ -232,7 +243,26 @@ struct BxDF {
         V3 wh = Normalize(wo + wi);
         return dist.Pdf(wo, wh) / (4 * Dot(wo, wh));
     }
-    Spec Sample_f(const V3 &wo, V3 *wi, const P2 &u, Float *pdf) const {
+    Spec Sample_f(const V3 &wo, V3 *wi, const P2 &u, Float *pdf, int *sampledType = nullptr) const {
+        if (kind == BXDF_FRESNEL_SPECULAR) {               // reflection.cpp:477-512
+            Float F = FrDielectric(CosTheta(wo), etaA, etaB);
+            if (u.x < F) {
+                *wi = V3(-wo.x, -wo.y, wo.z);
+                if (sampledType) *sampledType = BSDF_SPECULAR | BSDF_REFLECTION;
+                *pdf = F;
+                return F * R / AbsCosTheta(*wi);
+            } else {
+                bool entering = CosTheta(wo) > 0;
+                Float etaI = entering ? etaA : etaB;
+                Float etaT = entering ? etaB : etaA;
+                if (!Refract(wo, Faceforward(V3(0, 0, 1), wo), etaI / etaT, wi)) return 0;
+                Spec ft = S * (1 - F);
+                ft *= (etaI * etaI) / (etaT * etaT);
+                if (sampledType) *sampledType = BSDF_SPECULAR | BSDF_TRANSMISSION;
+                *pdf = 1 - F;
+                return ft / AbsCosTheta(*wi);
+            }
+        }
         if (kind == BXDF_SPECULAR_REFLECTION) {            // :136-143, FresnelNoOp::Evaluate == Spectrum(1.)
             *wi = V3(-wo.x, -wo.y, wo.z);
             *pdf = 1;
@@ -274,7 +304,9 @@ struct BSDF {
     V3 ns, ng, ss, ts;
     int nBxDFs = 0;
     BxDF bxdfs[2];
+    Float eta = 1;        // BSDF::eta (core/reflection.h:156-157)
     void Init(const SurfaceInteraction &si) {
+        eta = 1;
         ns = si.shading.n; ng = si.n;
         ss = Normalize(si.shading.dpdu);
         ts = Cross(ns, ss);
@@ -327,7 +359,7 @@ struct BSDF {
         if (wo.z == 0) return 0.;
         *pdf = 0;
         if (sampledType) *sampledType = bxdf->type;
-        Spec f = bxdf->Sample_f(wo, &wi, uRemapped, pdf);
+        Spec f = bxdf->Sample_f(wo, &wi, uRemapped, pdf, sampledType);
         if (*pdf == 0) { if (sampledType) *sampledType = 0; return 0; }
         *wiWorld = LocalToWorld(wi);
         if (!(bxdf->type & BSDF_SPECULAR) && matchingComps > 1)
@@ -443,7 +475,14 @@ inline void ComputeScatteringFunctions(const Scene &scene, const Material &m, co
     bsdf->Init(si);
     const Spec Kd = m.KdTex >= 0 ? EvalImageTexture(scene.textures[m.KdTex], si) : Spec(m.Kd[0], m.Kd[1], m.Kd[2]);
     const Spec Ks = m.KsTex >= 0 ? EvalImageTexture(scene.textures[m.KsTex], si) : Spec(m.Ks[0], m.Ks[1], m.Ks[2]);
-    if (m.type == MAT_MIRROR) {      // materials/mirror.cpp:44-56 (Kr in Ks)
+    if (m.type == MAT_GLASS) {       // materials/glass.cpp:44-65, smooth case with allowMultipleLobes (Kd = Kt, Ks = Kr, roughness = eta)
+        bsdf->eta = m.roughness;
+        Spec R = Ks.Clamp(), T = Kd.Clamp();
+        if (R.IsBlack() && T.IsBlack()) return;
+        BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+        b.kind = BXDF_FRESNEL_SPECULAR; b.type = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
+        b.R = R; b.S = T; b.etaA = 1.f; b.etaB = m.roughness;
+    } else if (m.type == MAT_MIRROR) {      // materials/mirror.cpp:44-56 (Kr in Ks)
         Spec R = Ks.Clamp();
         if (!R.IsBlack()) {
             BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];

@@ -122,6 +122,13 @@ CASES = {
                                   '\nAttributeBegin\nMaterial "substrate"\nTranslate -1.2 .6 .5\nShape "sphere" "float radius" [.45]\nAttributeEnd\n'
                                   'AttributeBegin\nMaterial "metal" "rgb eta" [.2 .9 1.1] "rgb k" [3.9 2.4 2.2] "float roughness" [.05]\nTranslate 1.2 .2 .3\n'
                                   'Shape "sphere" "float radius" [.4]\nAttributeEnd\n', integ=UNIFORM, spp=8, maxdepth=5),
+    # ---- smooth glass (FresnelSpecular: reflection or refraction by the Fresnel term, total internal reflection, the
+    #      radiance scaling at the boundary and etaScale in the Russian roulette, integrators/path.cpp:154-162, 191-199) ----
+    "glass": _scene(SPHERE_LIGHT + QUAD_LIGHT + GEOM + 'AttributeBegin\nMaterial "glass"\nTranslate -1.0 -.2 .55\nShape "sphere" "float radius" [.5]\nAttributeEnd\n'
+                    'AttributeBegin\nMaterial "glass" "float index" [1.33] "color Kt" [.9 1 .95] "color Kr" [.8 .8 .8]\n'
+                    'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0] '
+                    '"point P" [.5 -1.2 .1  1.5 -1.2 .1  1.5 -.9 .1  .5 -.9 .1  .5 -1.2 1.1  1.5 -1.2 1.1  1.5 -.9 1.1  .5 -.9 1.1]\nAttributeEnd\n',
+                    integ=UNIFORM + ' "float rrthreshold" [1]', spp=8, maxdepth=10),
     "no_lights": _scene(GEOM),
     "empty_scene": _scene(""),
     "light_only": _scene(SPHERE_LIGHT),

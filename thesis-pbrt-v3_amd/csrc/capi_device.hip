@@ -361,14 +361,15 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     std::vector<DevMaterial> mats(d->n_materials);
     for (uint32_t m = 0; m < d->n_materials; ++m) {
         const HprtMaterialDesc &in = d->materials[m];
-        if (in.type < 0 || in.type > 4) return SetError(HPRT_E_UNSUPPORTED, "material type outside the hot-path scope (matte, plastic, mirror, substrate, metal)");
+        if (in.type < 0 || in.type > 5) return SetError(HPRT_E_UNSUPPORTED, "material type outside the hot-path scope (matte, plastic, mirror, substrate, metal, glass)");
         if (in.kd_texture >= (int32_t)d->n_textures || in.ks_texture >= (int32_t)d->n_textures) return SetError(HPRT_E_INVALID, "material texture index out of range");
         DevMaterial &o = mats[m];
         o.KdTex = in.kd_texture >= 0 ? in.kd_texture : -1; o.KsTex = in.ks_texture >= 0 ? in.ks_texture : -1;
         o.type = in.type; memcpy(o.Kd, in.Kd, 12); memcpy(o.Ks, in.Ks, 12);
         o.alpha = in.remap_roughness ? RoughnessToAlpha(in.roughness) : in.roughness;
         o.alphaY = o.alpha;
-        if (in.type >= 3) o.alphaY = in.remap_roughness ? RoughnessToAlpha(in.sigma) : in.sigma;      // substrate / metal: sigma carries vroughness
+        if (in.type == 3 || in.type == 4) o.alphaY = in.remap_roughness ? RoughnessToAlpha(in.sigma) : in.sigma;      // substrate / metal: sigma carries vroughness
+        if (in.type == 5) o.alpha = in.roughness;      // glass: the index of refraction, as given
         // MatteMaterial: sig = Clamp(sigma, 0, 90); sig != 0 -> OrenNayar(r, sig) (materials/matte.cpp:55-61, core/reflection.h:414-420)
         const float sig = clampf(in.sigma, 0.f, 90.f);
         o.oren = in.type == 0 && sig != 0.f ? 1 : 0; o.orenA = 1.f; o.orenB = 0.f;

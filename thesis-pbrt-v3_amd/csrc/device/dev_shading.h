@@ -319,7 +319,8 @@ struct DevBsdf {
     rgb Rr;
     bool oren; float orenA, orenB;      // the diffuse lobe is OrenNayar, not LambertianReflection
     float alphaY;          // Trowbridge-Reitz alpha along v (== alpha for plastic)
-    int kind;              // 0: the lobes above; 2: ONE FresnelBlend lobe (substrate: Rd, Rs, alpha, alphaY); 3: ONE conductor
+    float eta;             // BSDF::eta (1 unless glass)
+    int kind;              // 0: the lobes above; 4 (with hasR): ONE FresnelSpecular lobe (glass: Rr = R, Rd = T, eta); 2: ONE FresnelBlend lobe (substrate: Rd, Rs, alpha, alphaY); 3: ONE conductor
                            // microfacet lobe (metal: Rd = eta, Rs = k, R = 1).  Kinds 2 and 3 are flagged hasS (a glossy reflection lobe)
 };
 __device__ __forceinline__ float cos_theta(vec3 w) { return w.z; }
@@ -604,7 +605,14 @@ __device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, D
     b->alpha = 0; b->hasD = false; b->hasS = false; b->Rd = rgb(0.f); b->Rs = rgb(0.f);
     b->hasR = false; b->Rr = rgb(0.f); b->oren = false; b->orenA = 1.f; b->orenB = 0.f;
     const DevMaterial m = sc.materials[sc.shapes[si.shape].material];
-    b->alphaY = 0; b->kind = 0;
+    b->alphaY = 0; b->kind = 0; b->eta = 1.f;
+    if (m.type == 5) {      // GlassMaterial, smooth (materials/glass.cpp:44-65 with allowMultipleLobes): one FresnelSpecular lobe
+        b->eta = m.alpha;
+        const rgb R = clamp0(ksOverride ? *ksOverride : rgb(m.Ks[0], m.Ks[1], m.Ks[2])), T = clamp0(kdOverride ? *kdOverride : rgb(m.Kd[0], m.Kd[1], m.Kd[2]));
+        if (is_black(R) && is_black(T)) return;
+        b->hasR = true; b->kind = 4; b->Rr = R; b->Rd = T;
+        return;
+    }
     if (m.type == 3) {      // SubstrateMaterial, materials/substrate.cpp:44-65: one FresnelBlend lobe unless both reflectances are black
         const rgb d = clamp0(kdOverride ? *kdOverride : rgb(m.Kd[0], m.Kd[1], m.Kd[2])), sp = clamp0(ksOverride ? *ksOverride : rgb(m.Ks[0], m.Ks[1], m.Ks[2]));
         if (!is_black(d) || !is_black(sp)) { b->kind = 2; b->hasS = true; b->Rd = d; b->Rs = sp; b->alpha = m.alpha; b->alphaY = m.alphaY; }
@@ -664,6 +672,35 @@ __device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW
         // returns its value as sampled, with its pdf of 1 (:744-760 skip specular lobes)
         const vec3 wo = to_local(b, woW);
         if (wo.z == 0) return rgb(0.f);
+        if (b.kind == 4) {      // FresnelSpecular::Sample_f, core/reflection.cpp:477-512 (etaA = 1, etaB = eta, TransportMode::Radiance)
+            const float uu = sel_min(u0, HPRT_ONE_MINUS_EPS);      // uRemapped of the one matching lobe
+            const float F = fr_dielectric(cos_theta(wo), 1.f, b.eta);
+            if (uu < F) {
+                const vec3 wi(-wo.x, -wo.y, wo.z);
+                *sampledType = BX_SPECULAR | BX_REFLECTION;
+                *pdf = F;
+                *wiW = to_world(b, wi);
+                return b.Rr * F / abs_cos_theta(wi);
+            }
+            const bool entering = cos_theta(wo) > 0;
+            const float etaI = entering ? 1.f : b.eta, etaT = entering ? b.eta : 1.f;
+            // Refract(wo, Faceforward(Normal3f(0, 0, 1), wo), etaI / etaT, wi), core/reflection.h:96-108
+            const vec3 n = face_forward(vec3(0.f, 0.f, 1.f), wo);
+            const float er = etaI / etaT;
+            const float cosThetaI = dot(n, wo);
+            const float sin2ThetaI = sel_max(0.f, 1 - cosThetaI * cosThetaI);
+            const float sin2ThetaT = er * er * sin2ThetaI;
+            *pdf = 0;
+            if (sin2ThetaT >= 1) { *sampledType = 0; return rgb(0.f); }      // total internal reflection: BSDF::Sample_f sees pdf == 0
+            const float cosThetaT = sqrtf(1 - sin2ThetaT);
+            const vec3 wi = er * -wo + (er * cosThetaI - cosThetaT) * n;
+            rgb ft = b.Rd * (1 - F);
+            ft = ft * ((etaI * etaI) / (etaT * etaT));
+            *sampledType = BX_SPECULAR | BX_TRANSMISSION;
+            *pdf = 1 - F;
+            *wiW = to_world(b, wi);
+            return ft / abs_cos_theta(wi);
+        }
         const vec3 wi(-wo.x, -wo.y, wo.z);
         *pdf = 1;
         *sampledType = BX_REFLECTION | BX_SPECULAR;

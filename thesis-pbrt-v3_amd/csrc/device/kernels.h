@@ -18,7 +18,7 @@ struct HitStream { float4 *a; float2 *b; };           // a = {t, prim, b0, b1}  
 struct PathStream {
     RayStream ray;          // current path segment; ray.b.w = sampler dimension (bits 0-15) | bounces (bits 16-30) | the segment left a specular lobe (bit 31)
     float4 *beta;           // {beta.rgb, path id}   path id = sampleInBatch * nPix + pixel
-    float4 *L;              // {L.rgb, 1 if the path continues after this vertex else 0}
+    float4 *L;              // {L.rgb, w}: w = 0 if the path ends at this vertex, else its etaScale (1 until it crosses a dielectric boundary)
 };
 // What a shading pass leaves for the rest of its bounce, indexed like its output PathStream
 struct VertexStreams {

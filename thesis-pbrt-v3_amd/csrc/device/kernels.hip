@@ -711,6 +711,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
         const vec3 rayD(rayB.x, rayB.y, rayB.z);
         rgb beta(beta4.x, beta4.y, beta4.z);
         rgb L(L4.x, L4.y, L4.z);
+        float etaScale = L4.w;      // (a stored path continues, so its w word is its etaScale; fresh paths: 1)
         const bool found = prim >= 0;
         DevSI si;
         DevTexGeom tg;
@@ -892,7 +893,12 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                 vec3 o = offset_ray_origin(si.p, si.pErr, si.n, wi);
                 bool alive = true;
                 // Russian roulette (path.cpp:191-199); etaScale == 1 without transmission
-                rgb rrBeta = beta * 1.0f;
+                // (etaScale travels in the w word of the radiance stream: 1 until a path crosses a dielectric boundary, path.cpp:154-162)
+                if (MODE == 2 && (flags & BX_SPECULAR) && (flags & BX_TRANSMISSION)) {
+                    const float eta = bsdf.eta;
+                    etaScale *= (dot(wo, si.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                }
+                rgb rrBeta = beta * etaScale;
                 if (max_value(rrBeta) < rp.rrThreshold && bounces > 3) {
                     float qv = sel_max(.05f, 1 - max_value(rrBeta));
                     float u = halton_dim(sc, rp.hal, index, dim, &hl);
@@ -917,7 +923,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
         // Radiance so far: k_resolve adds this vertex's direct lighting to out.L[j] and, if the path
         // stops here (w == 0), passes the sum on to Lfinal; without a pending term this lane does it.
         if (!defer) {
-            if (wantNext || wantResolve) out.L[j] = make_float4(L.r, L.g, L.b, wantNext ? 1.f : 0.f);
+            if (wantNext || wantResolve) out.L[j] = make_float4(L.r, L.g, L.b, wantNext ? etaScale : 0.f);      // w: 0 = the path ends at this vertex, else its etaScale
             else Lfinal[pathId] = make_float4(L.r, L.g, L.b, 0.f);
         }
     }

@@ -286,6 +286,15 @@ struct Frontend {
             const Param *rp = geom.find("remaproughness", "bool"); if (!rp) rp = mp->find("remaproughness", "bool");
             if (rp && rp->bools.size() == 1) remap = rp->bools[0];
             m.remapRoughness = remap ? 1 : 0;
+        } else if (name == "glass") {       // CreateGlassMaterial, materials/glass.cpp:88-105: the smooth dielectric (FresnelSpecular)
+            const float one[3] = {1.f, 1.f, 1.f};
+            m.type = kGlass;
+            spectrumParam(geom, *mp, "Kr", one, m.Ks, &m.KsTex);
+            spectrumParam(geom, *mp, "Kt", one, m.Kd, &m.KdTex);
+            const bool hasEta = mp->find("eta", "float") || geom.find("eta", "float") || !mp->texture("eta").empty() || !geom.texture("eta").empty();
+            m.roughness = hasEta ? floatParam(geom, *mp, "eta", 1.5f) : floatParam(geom, *mp, "index", 1.5f);
+            if (floatParam(geom, *mp, "uroughness", 0.f) != 0.f || floatParam(geom, *mp, "vroughness", 0.f) != 0.f)
+                warn("rough glass (MicrofacetTransmission) is outside the hot-path scope; rendered as smooth glass");
         } else if (name == "mirror") {      // CreateMirrorMaterial, materials/mirror.cpp:58-64
             const float dk[3] = {0.9f, 0.9f, 0.9f};
             m.type = kMirror;
