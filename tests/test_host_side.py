@@ -149,9 +149,10 @@ def test_frontend_rejects_and_warns(hprt, tmp_path):
         _parse_text(hprt, tmp_path, HEADER + "Bogus 1 2 3\nWorldEnd\n")
     with pytest.raises(hprt.HprtError):
         hprt.Model.parse(str(tmp_path / "missing.pbrt"))
-    m = _parse_text(hprt, tmp_path, HEADER + 'Material "glass"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nShape "cone"\nWorldEnd\n')
+    m = _parse_text(hprt, tmp_path, HEADER + 'Material "translucent"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
+                    'Material "glass" "float uroughness" [.2]\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 1 1 0 1 0 1 1]\nShape "cone"\nWorldEnd\n')
     w = " ".join(m.warnings())
-    assert "glass" in w and "cone" in w
+    assert "translucent" in w and "rough glass" in w and "cone" in w
 
 
 def test_loop_subdivision_of_a_closed_and_an_open_mesh(hprt, tmp_path):
