@@ -54,7 +54,7 @@ typedef struct HprtRenderOptions {
     int32_t sample_pixel_center;
     int32_t max_depth;             /* Integrator "maxdepth" (integrators/path.cpp:209)          */
     float rr_threshold;            /* integrators/path.cpp:224                                   */
-    int32_t light_strategy;        /* 0 uniform, 1 power, 2 spatial (core/lightdistrib.cpp:47-66)*/
+    int32_t light_strategy;        /* 0 uniform, 1 power, 2 spatial (core/lightdistrib.cpp:47-66); all three built */
     int32_t max_node_prims, isect_cost, trav_cost; /* accelerators/bvh.cpp:529-535 */
 } HprtRenderOptions;
 

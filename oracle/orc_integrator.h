@@ -340,7 +340,15 @@ struct Renderer {
     std::vector<BVH> objectBvh;    // one per object definition (core/api.cpp:1798-1806)
     Camera camera;
     Film film;
-    Distribution1D lightDistrib;
+    Distribution1D lightDistrib;          // "uniform" (or a single light) and "power": one distribution for every point
+    // "spatial" (the reference's default with more than one light): SpatialLightDistribution, core/lightdistrib.cpp:77-300 — a
+    // distribution per voxel of a grid over the world bound, computed when a vertex first falls into the voxel.  (The
+    // reference's lock-free hash table is only its cache: a voxel's distribution is a pure function of the voxel.)
+    bool spatial = false;
+    int nVoxels[3] = {1, 1, 1};
+    B3 worldBound;
+    mutable std::mutex voxelMutex;
+    mutable std::unordered_map<uint64_t, std::unique_ptr<Distribution1D>> voxelDist;
     Float worldRadius = 0; V3 worldCenter;
     int nThreads = 1;
     Counters total;
@@ -366,17 +374,26 @@ struct Renderer {
         bvh.Build(&scene, &scene.prims, &objectBvh, 0);
         camera.Init(scene.prm);
         film.Init(scene.prm);
-        if (scene.lights.size() > 1 && scene.prm.lightStrategy == 2) {
-            *err = "spatial light distribution with >1 light is out of scope (SURVEY.md §2)"; return false;
-        }
-        std::vector<Float> prob(smax<size_t>(1, scene.lights.size()), Float(1));
-        lightDistrib.Init(prob.data(), (int)scene.lights.size());
         // Scene ctor + Light::Preprocess (core/scene.h:56-66, lights/distant.h:57-59)
         B3 wb = bvh.WorldBound();
+        worldBound = wb;
         worldCenter = (wb.pMin + wb.pMax) / 2;
         bool inside = worldCenter.x >= wb.pMin.x && worldCenter.x <= wb.pMax.x && worldCenter.y >= wb.pMin.y &&
                       worldCenter.y <= wb.pMax.y && worldCenter.z >= wb.pMin.z && worldCenter.z <= wb.pMax.z;
         worldRadius = inside ? Distance(worldCenter, wb.pMax) : 0;
+        // CreateLightSampleDistribution, core/lightdistrib.cpp:48-66
+        const int strategy = scene.lights.size() <= 1 ? 0 : scene.prm.lightStrategy;
+        std::vector<Float> prob(smax<size_t>(1, scene.lights.size()), Float(1));
+        if (strategy == 1)      // ComputeLightPowerDistribution, core/integrator.cpp:219-227
+            for (size_t i = 0; i < scene.lights.size(); ++i) prob[i] = LightPower(scene.lights[i]).y();
+        lightDistrib.Init(prob.data(), (int)scene.lights.size());
+        spatial = strategy == 2;
+        if (spatial) {          // SpatialLightDistribution::SpatialLightDistribution, core/lightdistrib.cpp:95-120 (maxVoxels = 64)
+            V3 diag = wb.pMax - wb.pMin;
+            int me = (diag.x > diag.y && diag.x > diag.z) ? 0 : (diag.y > diag.z ? 1 : 2);      // Bounds3::MaximumExtent, geometry.h:942-950
+            Float bmax = diag[me];
+            for (int i = 0; i < 3; ++i) nVoxels[i] = smax(1, int(std::round(diag[i] / bmax * 64)));
+        }
         return true;
     }
 
@@ -403,6 +420,62 @@ struct Renderer {
     Spec Le(const SurfaceInteraction &isect, const V3 &w) const {
         int al = AreaLightOf(isect);
         return al >= 0 ? AreaL(scene.lights[al], isect.n, w) : Spec(0.f);
+    }
+    // Light::Power: lights/point.cpp:55, lights/distant.cpp:61-63, lights/diffuse.cpp:64-66 (area = shape->Area())
+    Spec LightPower(const Light &l) const {
+        if (l.type == LIGHT_POINT) return 4 * Pi * l.I;
+        if (l.type == LIGHT_DISTANT) return l.I * Pi * worldRadius * worldRadius;
+        const ShapeRec &sh = scene.shapes[l.shape];
+        Float area;
+        if (sh.kind == SHAPE_MESH) {
+            const Mesh &m = scene.meshes[sh.meshIndex];
+            const int *v = &m.idx[3 * ((int)(&l - scene.lights.data()) - sh.areaLight)];
+            area = TriangleArea(m.p[v[0]], m.p[v[1]], m.p[v[2]]);
+        } else { const Sphere &s = scene.spheres[sh.sphereIndex]; area = s.phiMax * s.radius * (s.zMax - s.zMin); }
+        return (Float)(l.twoSided ? 2 : 1) * l.I * area * Pi;
+    }
+    // LightDistribution::Lookup(p)
+    const Distribution1D &LookupLightDistribution(const V3 &p) const {
+        if (!spatial) return lightDistrib;
+        // SpatialLightDistribution::Lookup, core/lightdistrib.cpp:134-147: Bounds3::Offset, then int(offset * nVoxels) clamped
+        V3 o = p - worldBound.pMin;
+        if (worldBound.pMax.x > worldBound.pMin.x) o.x /= worldBound.pMax.x - worldBound.pMin.x;
+        if (worldBound.pMax.y > worldBound.pMin.y) o.y /= worldBound.pMax.y - worldBound.pMin.y;
+        if (worldBound.pMax.z > worldBound.pMin.z) o.z /= worldBound.pMax.z - worldBound.pMin.z;
+        int pi[3];
+        for (int i = 0; i < 3; ++i) pi[i] = Clamp(int(o[i] * nVoxels[i]), 0, nVoxels[i] - 1);
+        const uint64_t packed = ((uint64_t)pi[0] << 40) | ((uint64_t)pi[1] << 20) | (uint64_t)pi[2];
+        std::lock_guard<std::mutex> lock(voxelMutex);
+        auto it = voxelDist.find(packed);
+        if (it != voxelDist.end()) return *it->second;
+        // ComputeDistribution, core/lightdistrib.cpp:231-298
+        V3 p0(Float(pi[0]) / Float(nVoxels[0]), Float(pi[1]) / Float(nVoxels[1]), Float(pi[2]) / Float(nVoxels[2]));
+        V3 p1(Float(pi[0] + 1) / Float(nVoxels[0]), Float(pi[1] + 1) / Float(nVoxels[1]), Float(pi[2] + 1) / Float(nVoxels[2]));
+        auto wlerp = [&](const V3 &t) { return V3(Lerp(t.x, worldBound.pMin.x, worldBound.pMax.x), Lerp(t.y, worldBound.pMin.y, worldBound.pMax.y),
+                                                  Lerp(t.z, worldBound.pMin.z, worldBound.pMax.z)); };
+        const V3 vMin = wlerp(p0), vMax = wlerp(p1);
+        const int nSamples = 128;
+        std::vector<Float> lightContrib(scene.lights.size(), Float(0));
+        for (int i = 0; i < nSamples; ++i) {
+            V3 t(RadicalInverse(0, i), RadicalInverse(1, i), RadicalInverse(2, i));
+            Interaction intr;
+            intr.p = V3(Lerp(t.x, vMin.x, vMax.x), Lerp(t.y, vMin.y, vMax.y), Lerp(t.z, vMin.z, vMax.z));
+            intr.pError = V3(); intr.n = V3();
+            P2 u(RadicalInverse(3, i), RadicalInverse(4, i));
+            for (size_t j = 0; j < scene.lights.size(); ++j) {
+                Float pdf; V3 wi; Interaction pl;
+                Spec Li = Sample_Li(scene.lights[j], intr, u, &wi, &pdf, &pl);
+                if (pdf > 0) lightContrib[j] += Li.y() / pdf;
+            }
+        }
+        Float sumContrib = 0;
+        for (Float c : lightContrib) sumContrib += c;      // std::accumulate(..., Float(0))
+        Float avgContrib = sumContrib / (nSamples * lightContrib.size());
+        Float minContrib = (avgContrib > 0) ? (Float)(.001 * (double)avgContrib) : 1;
+        for (Float &c : lightContrib) c = smax(c, minContrib);
+        std::unique_ptr<Distribution1D> d(new Distribution1D());
+        d->Init(lightContrib.data(), (int)lightContrib.size());
+        return *(voxelDist[packed] = std::move(d));
     }
     // Light::Sample_Li for the three light types
     Spec Sample_Li(const Light &l, const Interaction &ref, const P2 &u, V3 *wi, Float *pdf, Interaction *pLight) const {
@@ -525,7 +598,7 @@ struct Renderer {
         int nLights = (int)scene.lights.size();
         if (nLights == 0) return Spec(0.f);
         Float lightPdf;
-        int lightNum = lightDistrib.SampleDiscrete(sampler.Get1D(), &lightPdf);
+        int lightNum = LookupLightDistribution(isect.p).SampleDiscrete(sampler.Get1D(), &lightPdf);      // path.cpp:125
         if (lightPdf == 0) return Spec(0.f);
         P2 uLight = sampler.Get2D();
         P2 uScattering = sampler.Get2D();

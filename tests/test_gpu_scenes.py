@@ -129,6 +129,18 @@ CASES = {
                     'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0] '
                     '"point P" [.5 -1.2 .1  1.5 -1.2 .1  1.5 -.9 .1  .5 -.9 .1  .5 -1.2 1.1  1.5 -1.2 1.1  1.5 -.9 1.1  .5 -.9 1.1]\nAttributeEnd\n',
                     integ=UNIFORM + ' "float rrthreshold" [1]', spp=8, maxdepth=10),
+    # ---- the other light sample distributions (core/lightdistrib.cpp): "spatial" is the reference's DEFAULT with more than one light ----
+    "three_lights_spatial": _scene('LightSource "point" "point from" [1 -2 4] "color I" [20 5 5]\n'
+                                   'LightSource "distant" "point from" [-1 -1 3] "point to" [0 0 0] "color L" [.5 1 .5]\n' + SPHERE_LIGHT + GEOM),
+    "three_lights_power": _scene('LightSource "point" "point from" [1 -2 4] "color I" [20 5 5]\n'
+                                 'LightSource "distant" "point from" [-1 -1 3] "point to" [0 0 0] "color L" [.5 1 .5]\n' + SPHERE_LIGHT + GEOM,
+                                 integ='"string lightsamplestrategy" "power"'),
+    "emitters_of_all_kinds_spatial": _scene('LightSource "point" "point from" [-2 -2 3] "color I" [6 6 9]\n' + SPHERE_LIGHT + QUAD_LIGHT +
+                                            'AttributeBegin\nAreaLightSource "diffuse" "color L" [3 6 3] "bool twosided" "true"\n' + MATTE +
+                                            'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-2 1.5 .2  -1 1.5 .2  -1.5 2.2 .6]\nAttributeEnd\n' + GEOM, spp=8),
+    "emissive_mesh_power": _scene(MATTE + 'Shape "trianglemesh" ' + FLOOR + '\nAttributeBegin\nTranslate 0 0 1.5\nScale .3 .3 .6\nAreaLightSource "diffuse" "color L" [4 4 4]\n' +
+                                  PLASTIC + 'Shape "trianglemesh" ' + _grid_mesh(5, 5, lambda x, y: 0.25 * np.sin(2.3 * x) * np.cos(1.7 * y)) + "\nAttributeEnd\n" + PLASTIC +
+                                  'Shape "trianglemesh" ' + BUMPY + "\n", integ='"string lightsamplestrategy" "power"', maxdepth=4),
     "no_lights": _scene(GEOM),
     "empty_scene": _scene(""),
     "light_only": _scene(SPHERE_LIGHT),

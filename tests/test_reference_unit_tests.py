@@ -37,6 +37,16 @@ def test_product_host_math_unit_tests(hprt):
     assert list(f) == [0, 0]
 
 
+def test_voxel_sample_points_of_the_spatial_light_distribution(hprt, orc):
+    """SpatialLightDistribution::ComputeDistribution (core/lightdistrib.cpp:251-262) samples every voxel at RadicalInverse(0..4, i),
+    i < 128: the product's host table against the oracle's RadicalInverse (itself held to LowDiscrepancy.RadicalInverse)."""
+    pts = np.zeros((5, 128), np.float32)
+    assert hprt.lib.hprt_debug_voxel_points(pts.ctypes.data_as(C.c_void_p)) == 0
+    want = np.array([[orc.lib.orc_radical_inverse(b, i) for i in range(128)] for b in range(5)], np.float32)
+    assert np.array_equal(pts.view(np.uint32), want.view(np.uint32))
+    assert pts[0, 1] == 0.5 and abs(pts[1, 1] - 1 / 3) < 1e-7 and pts.max() < 1
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def _one_shape_scene(hprt, shape, bmin, bmax):
     """hprt_scene_create from a description filled here: one shape, one matte material, no lights."""

@@ -120,6 +120,30 @@ void MakeCamera(const HprtRenderOptions &o, DevCamera *cam) {
     cam->dyCamera = xf_point(cam->rasterToCamera, vec3(0, 1, 0)) - xf_point(cam->rasterToCamera, vec3(0, 0, 0));
 }
 
+// RadicalInverse(0..4, i), i < 128 (core/lowdiscrepancy.cpp:2478-2488, 389-403): the 3D point and the 2D light sample of
+// SpatialLightDistribution::ComputeDistribution's 128 samples per voxel, as [5][128]
+void VoxelSamplePoints(float *out) {
+    const int bases[5] = {2, 3, 5, 7, 11};
+    for (int b = 0; b < 5; ++b)
+        for (uint32_t i = 0; i < 128; ++i) {
+            float v;
+            if (b == 0) {
+                uint32_t n = i;      // ReverseBits32(a) * 0x1p-32, evaluated in double
+                n = (n << 16) | (n >> 16); n = ((n & 0x00ff00ffu) << 8) | ((n & 0xff00ff00u) >> 8); n = ((n & 0x0f0f0f0fu) << 4) | ((n & 0xf0f0f0f0u) >> 4);
+                n = ((n & 0x33333333u) << 2) | ((n & 0xccccccccu) >> 2); n = ((n & 0x55555555u) << 1) | ((n & 0xaaaaaaaau) >> 1);
+                v = (float)((double)n * 0x1p-32);
+            } else {
+                const int base = bases[b];
+                const float invBase = (float)1 / (float)base;
+                uint64_t reversedDigits = 0, a = i;
+                float invBaseN = 1;
+                while (a) { uint64_t next = a / base, digit = a - next * base; reversedDigits = reversedDigits * base + digit; invBaseN *= invBase; a = next; }
+                v = sel_min((float)reversedDigits * invBaseN, HPRT_ONE_MINUS_EPS);
+            }
+            out[128 * b + i] = v;
+        }
+}
+
 // A path vertex consumes up to 8 sampler dimensions after the camera sample's 5; the reference's
 // Halton sampler aborts at dimension PrimeTableSize = 1000 (core/lowdiscrepancy.h:52, lowdiscrepancy.cpp:4558), so depths
 // whose paths could get there are refused instead of sampled from a dimension the reference does not have.
@@ -287,8 +311,9 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
             if (!own) return SetError(HPRT_E_INVALID, "area light and its shape do not reference each other");
         }
     }
-    if (d->n_lights > 1 && d->light_strategy != 0)
-        return SetError(HPRT_E_UNSUPPORTED, "with more than one light only lightsamplestrategy \"uniform\" is in scope (SURVEY.md §2)");
+    // CreateLightSampleDistribution (core/lightdistrib.cpp:48-66): a single light always gets the uniform distribution
+    const int lightStrategy = d->n_lights <= 1 ? 0 : d->light_strategy;
+    if (lightStrategy < 0 || lightStrategy > 2) return SetError(HPRT_E_INVALID, "light_strategy must be 0 (uniform), 1 (power) or 2 (spatial)");
     int dev;
     int rc = CheckDevice(device, &dev);
     if (rc != HPRT_OK) return rc;
@@ -415,8 +440,40 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
         o.sphere = in.type == 2 && !onMesh ? sphereOfShape[in.shape] : -1;
         o.shapeFlags = in.type == 2 ? shapes[in.shape].flags : 0u;
     }
-    // UniformLightDistribution (core/lightdistrib.cpp:68-75) as a Distribution1D (core/sampling.h:57-70)
+    // Scene::worldBound + Bounds3::BoundingSphere (core/scene.h:56-66, core/geometry.h:980-983)
+    float worldRadius = 0.f;
+    vec3 wbLo, wbHi;
+    if (d->n_nodes) {
+        const BvhNode &root = ((const BvhNode *)d->nodes)[0];
+        wbLo = vec3(root.bmin[0], root.bmin[1], root.bmin[2]); wbHi = vec3(root.bmax[0], root.bmax[1], root.bmax[2]);
+        vec3 c = div_by(wbLo + wbHi, 2.f);
+        bool inside = c.x >= wbLo.x && c.x <= wbHi.x && c.y >= wbLo.y && c.y <= wbHi.y && c.z >= wbLo.z && c.z <= wbHi.z;
+        worldRadius = inside ? dist(c, wbHi) : 0.f;
+    }
+    // UniformLightDistribution (core/lightdistrib.cpp:68-75) or PowerLightDistribution (:77-82, ComputeLightPowerDistribution,
+    // core/integrator.cpp:219-227: Light::Power().y()) as a Distribution1D (core/sampling.h:57-70)
     std::vector<float> func(std::max<uint32_t>(1, d->n_lights), 1.f), cdf(d->n_lights + 1, 0.f);
+    if (lightStrategy == 1)
+        for (uint32_t l = 0; l < d->n_lights; ++l) {
+            const HprtLightDesc &in = d->lights[l];
+            const rgb I(in.I[0], in.I[1], in.I[2]);
+            rgb power;
+            if (in.type == 0) power = I * (4 * HPRT_PI);                                      // lights/point.cpp:55
+            else if (in.type == 1) power = I * HPRT_PI * worldRadius * worldRadius;          // lights/distant.cpp:61-63
+            else {                                                                            // lights/diffuse.cpp:64-66, area = shape->Area()
+                const HprtShapeDesc &ls = d->shapes[in.shape];
+                float area;
+                if (ls.kind == 1) area = ls.phi_max * ls.radius * (ls.z_max - ls.z_min);      // Sphere::Area, shapes/sphere.cpp:215
+                else {                                                                        // Triangle::Area, shapes/triangle.cpp:576-582
+                    const int32_t *v = &ls.indices[3 * (size_t)((int32_t)l - ls.area_light)];
+                    const vec3 p0(ls.P[3 * v[0]], ls.P[3 * v[0] + 1], ls.P[3 * v[0] + 2]), p1(ls.P[3 * v[1]], ls.P[3 * v[1] + 1], ls.P[3 * v[1] + 2]),
+                               p2(ls.P[3 * v[2]], ls.P[3 * v[2] + 1], ls.P[3 * v[2] + 2]);
+                    area = (float)(0.5 * (double)length(cross(p1 - p0, p2 - p0)));
+                }
+                power = I * (float)(in.two_sided ? 2 : 1) * area * HPRT_PI;
+            }
+            func[l] = luminance(power);
+        }
     float funcInt = 0.f;
     if (d->n_lights) dist1d_build(func.data(), (int)d->n_lights, cdf.data(), &funcInt);
     // Halton tables + 64-bit division magics
@@ -513,19 +570,40 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     dv.deepStack = sc->deepStack.as<uint2>();
     dv.perms = sc->perms.as<uint16_t>(); dv.primes = sc->primes.as<int32_t>(); dv.primeSums = sc->primeSums.as<int32_t>();
     dv.primeMagic = sc->primeMagic.as<uint64_t>();
-    // Scene::worldBound + Bounds3::BoundingSphere (core/scene.h:56-66, core/geometry.h:980-983)
-    dv.worldRadius = 0.f;
-    if (d->n_nodes) {
-        const BvhNode &root = ((const BvhNode *)d->nodes)[0];
-        vec3 lo(root.bmin[0], root.bmin[1], root.bmin[2]), hi(root.bmax[0], root.bmax[1], root.bmax[2]);
-        vec3 c = div_by(lo + hi, 2.f);
-        bool inside = c.x >= lo.x && c.x <= hi.x && c.y >= lo.y && c.y <= hi.y && c.z >= lo.z && c.z <= hi.z;
-        dv.worldRadius = inside ? dist(c, hi) : 0.f;
+    dv.worldRadius = worldRadius;
+    dv.spatial = 0; dv.voxN[0] = dv.voxN[1] = dv.voxN[2] = 1; dv.voxFunc = dv.voxCdf = dv.voxFuncInt = nullptr;
+    for (int a = 0; a < 3; ++a) { dv.wbMin[a] = wbLo.get(a); dv.wbMax[a] = wbHi.get(a); }
+    if (lightStrategy == 2) {
+        // SpatialLightDistribution (core/lightdistrib.cpp:95-120, maxVoxels = 64): the voxel grid over the world bound.  The reference
+        // fills a voxel's distribution when a vertex first falls into it; a voxel's distribution being a pure function of the voxel,
+        // here every voxel is computed now, on the device (k_voxel_contrib / k_voxel_dist).
+        const vec3 diag = wbHi - wbLo;
+        const int me = (diag.x > diag.y && diag.x > diag.z) ? 0 : (diag.y > diag.z ? 1 : 2);      // Bounds3::MaximumExtent
+        const float bmax = diag.get(me);
+        uint64_t nVox = 1;
+        for (int a = 0; a < 3; ++a) { dv.voxN[a] = std::max(1, int(std::round(diag.get(a) / bmax * 64))); nVox *= (uint64_t)dv.voxN[a]; }
+        const uint64_t tableFloats = nVox * (2ull * d->n_lights + 2ull);
+        if (tableFloats > (1ull << 28))
+            return SetError(HPRT_E_UNSUPPORTED, "spatial light distribution: voxels x lights exceeds the 1 GiB table of this build (use \"uniform\" or \"power\")");
+        HIP_TRY(sc->voxFunc.alloc(nVox * d->n_lights * sizeof(float)));
+        HIP_TRY(sc->voxCdf.alloc(nVox * (d->n_lights + 1ull) * sizeof(float)));
+        HIP_TRY(sc->voxFuncInt.alloc(nVox * sizeof(float)));
+        std::vector<float> ri(5 * 128);
+        VoxelSamplePoints(ri.data());
+        HIP_TRY(upload(sc->voxRi, ri));
+        dv.spatial = 1;
+        dv.voxFunc = sc->voxFunc.as<float>(); dv.voxCdf = sc->voxCdf.as<float>(); dv.voxFuncInt = sc->voxFuncInt.as<float>();
+        LaunchVoxelDistributions(nullptr, dv, sc->voxRi.as<float>(), (uint32_t)nVox, sc->voxFunc.as<float>(), sc->voxCdf.as<float>(), sc->voxFuncInt.as<float>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
     }
     HIP_TRY(hipHostMalloc((void **)&sc->hostCounts, (4096 + 256) * sizeof(uint32_t)));
     *out = guard.release();
     return HPRT_OK;
 } catch (...) { return hprt::HandleException(); }
+
+// Diagnostics hook (not part of include/hprt.h): the 128 sample points of a voxel, RadicalInverse(0..4, i) as [5][128]
+__attribute__((visibility("default"))) int hprt_debug_voxel_points(float out[640]) { if (!out) return HPRT_E_INVALID; VoxelSamplePoints(out); return HPRT_OK; }
 
 int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int device, HprtScene **out) try {
     if (!m || !b || !out) return SetError(HPRT_E_INVALID, "hprt_scene_create_from_model: null argument");

@@ -82,7 +82,11 @@ struct DevScene {
     const DevTexture *textures; const DevMipLevel *mipLevels; const float *texels; const float *weightLut;   // image textures; weightLut: MIPMap::weightLut[128]
     const DevSphere *spheres; uint32_t nSpheres;
     const DevInstance *instances; uint32_t nInstances;
-    const float *lightFunc, *lightCdf; float lightFuncInt;      // Distribution1D (core/sampling.h:55-109)
+    const float *lightFunc, *lightCdf; float lightFuncInt;      // Distribution1D (core/sampling.h:55-109): uniform or power strategy
+    // SpatialLightDistribution (core/lightdistrib.cpp:77-300), computed for every voxel at scene creation: per voxel v the
+    // Distribution1D's func[nLights] at voxFunc + v * nLights, cdf[nLights + 1] at voxCdf + v * (nLights + 1), funcInt at voxFuncInt[v]
+    int32_t spatial; int32_t voxN[3]; float wbMin[3], wbMax[3];
+    const float *voxFunc, *voxCdf, *voxFuncInt;
     float worldRadius;                                           // DistantLight::Preprocess
     uint2 *deepStack;                                            // traversal stack entries beyond the LDS ones: [entry][grid thread]
     // Halton tables

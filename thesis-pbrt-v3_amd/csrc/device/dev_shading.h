@@ -924,7 +924,25 @@ __device__ __forceinline__ float light_pdf(const DevScene &sc, const DevLight &l
     return 1 / (2 * HPRT_PI * (1 - cosThetaMax));
 }
 // Distribution1D::SampleDiscrete (core/sampling.h:86-96) with FindInterval (core/pbrt.h:403-415)
-__device__ __forceinline__ int light_pick(const DevScene &sc, float u, float *pdf) {
+// over LightDistribution::Lookup(p) (integrators/path.cpp:125): the scene's one distribution, or the voxel's
+// (SpatialLightDistribution::Lookup, core/lightdistrib.cpp:134-147: Bounds3::Offset, int(offset * nVoxels) clamped)
+__device__ __forceinline__ int light_voxel(const DevScene &sc, vec3 p) {
+    float o[3] = {p.x - sc.wbMin[0], p.y - sc.wbMin[1], p.z - sc.wbMin[2]};
+    int pi[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (sc.wbMax[i] > sc.wbMin[i]) o[i] /= sc.wbMax[i] - sc.wbMin[i];
+        int v = (int)(o[i] * sc.voxN[i]);
+        pi[i] = v < 0 ? 0 : (v > sc.voxN[i] - 1 ? sc.voxN[i] - 1 : v);
+    }
+    return (pi[0] * sc.voxN[1] + pi[1]) * sc.voxN[2] + pi[2];
+}
+__device__ __forceinline__ int light_pick(const DevScene &sc, vec3 p, float u, float *pdf) {
+    if (sc.spatial) {
+        const int v = light_voxel(sc, p);
+        const int n = (int)sc.nLights;
+        return dist1d_sample_discrete(sc.voxCdf + (size_t)v * (n + 1), sc.voxFunc + (size_t)v * n, sc.voxFuncInt[v], n, u, pdf);
+    }
     return dist1d_sample_discrete(sc.lightCdf, sc.lightFunc, sc.lightFuncInt, (int)sc.nLights, u, pdf);
 }
 __device__ __forceinline__ float power_heuristic(float fPdf, float gPdf) {   // core/sampling.h:171-174, nf = ng = 1

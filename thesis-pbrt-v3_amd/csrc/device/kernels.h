@@ -100,6 +100,8 @@ void LaunchFilmForeign(hipStream_t st, const RenderParams &rp, const FilmGeom &f
 void LaunchFilmForeignExport(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, const float *LallR, const float *LallG,
                              const float *LallB, const FilmExtras &ex, uint32_t nGroups, const uint32_t *groupDest, const uint32_t *groupTile,
                              FilmRecord *out);
+// SpatialLightDistribution for every voxel: ri = RadicalInverse(0..4, i), i < 128, as [5][128] floats on the device
+void LaunchVoxelDistributions(hipStream_t st, const DevScene &sc, const float *ri, uint32_t nVox, float *func, float *cdf, float *funcInt);
 void LaunchFilmApplyRecords(hipStream_t st, const FilmRecord *rec, const uint32_t *destBegin, uint32_t nDest, float *film);
 
 }  // namespace hprt

@@ -803,7 +803,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                 // every pick value selects light 0 with pdf 1, and point / distant lights ignore uLight (lights/point.cpp:44-53,
                 // lights/distant.cpp:49-59) and never reach the BSDF-sampling branch (core/integrator.cpp:168).
                 float pickPdf;
-                const int lightNum = light_pick(sc, sc.nLights > 1u ? halton_dim(sc, rp.hal, index, dim, &hl) : 0.f, &pickPdf);
+                const int lightNum = light_pick(sc, si.p, sc.nLights > 1u ? halton_dim(sc, rp.hal, index, dim, &hl) : 0.f, &pickPdf);
                 dim += 1;
                 if (pickPdf != 0) {
                     const DevLight light = sc.lights[lightNum];
@@ -873,7 +873,8 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                     if (wantShadow || wantMis) {
                         vs.pendLight[j] = make_float4(pendLight.r, pendLight.g, pendLight.b,
                                                       __uint_as_float((uint32_t)lightNum | (wantShadow ? 0x40000000u : 0u) | (wantMis ? 0x80000000u : 0u)));
-                        if (wantMis) vs.pendMis[j] = make_float4(pendMis.r, pendMis.g, pendMis.b, pickPdf);      // (k_resolve re-derives pickPdf from the light number)
+                        // (k_resolve re-derives pickPdf from the light number — except with the spatial distribution, where it depends on the vertex)
+                        if (wantMis || sc.spatial) vs.pendMis[j] = make_float4(pendMis.r, pendMis.g, pendMis.b, pickPdf);
                         vs.pendBeta[j] = make_float4(beta.r, beta.g, beta.b, beta4.w);
                         wantResolve = true;
                     }
@@ -957,9 +958,10 @@ __global__ __launch_bounds__(256) void k_resolve(DevScene sc, VertexStreams vs, 
     const int lightNum = (int)(info & 0x3fffffffu);
     // the pending BSDF-sampled term exists for few vertices (most such rays are never queued): read it only then
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (info & 0x80000000u) pm = vs.pendMis[j];
-    // lightPdf of UniformSampleOneLight, as light_pick computed it for this light (core/integrator.cpp:94-99)
-    const float pickPdf = (sc.lightFuncInt > 0) ? sc.lightFunc[lightNum] / (sc.lightFuncInt * (int)sc.nLights) : 0;
+    if ((info & 0x80000000u) || sc.spatial) pm = vs.pendMis[j];
+    // lightPdf of UniformSampleOneLight, as light_pick computed it for this light (core/integrator.cpp:94-99); the spatial
+    // distribution's depends on the vertex's voxel and travels with the pending term
+    const float pickPdf = sc.spatial ? pm.w : ((sc.lightFuncInt > 0) ? sc.lightFunc[lightNum] / (sc.lightFuncInt * (int)sc.nLights) : 0);
     rgb Ld(0.f);
     if ((info & 0x40000000u) && !vs.occluded[j]) Ld = Ld + rgb(pl.x, pl.y, pl.z);
     if (info & 0x80000000u) {
@@ -1130,6 +1132,53 @@ __global__ __launch_bounds__(64) void k_film_apply_records(const FilmRecord *rec
     }
 }
 
+// SpatialLightDistribution::ComputeDistribution (core/lightdistrib.cpp:231-298) for EVERY voxel, at scene creation.
+// k_voxel_contrib: one thread per (voxel, light): the 128 Halton points of the voxel (ri: RadicalInverse(0..4, i), [5][128], from the
+// host), each light sampled from each point with the point's (ri[3], ri[4]); lightContrib += Li.y() / pdf in sample order.
+__global__ __launch_bounds__(256) void k_voxel_contrib(DevScene sc, const float *ri, uint32_t nVox, float *contrib) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = sc.nLights;
+    if (g >= (size_t)nVox * n) return;
+    const uint32_t v = (uint32_t)(g / n), j = (uint32_t)(g % n);
+    int pi[3]; pi[2] = (int)(v % (uint32_t)sc.voxN[2]); pi[1] = (int)((v / (uint32_t)sc.voxN[2]) % (uint32_t)sc.voxN[1]); pi[0] = (int)(v / ((uint32_t)sc.voxN[2] * (uint32_t)sc.voxN[1]));
+    float vMin[3], vMax[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float t0 = (float)pi[a] / (float)sc.voxN[a], t1 = (float)(pi[a] + 1) / (float)sc.voxN[a];
+        vMin[a] = (1 - t0) * sc.wbMin[a] + t0 * sc.wbMax[a];      // Bounds3::Lerp
+        vMax[a] = (1 - t1) * sc.wbMin[a] + t1 * sc.wbMax[a];
+    }
+    const DevLight light = sc.lights[j];
+    float acc = 0.f;
+    for (int i = 0; i < 128; ++i) {
+        DevIt ref;
+        ref.p = vec3((1 - ri[i]) * vMin[0] + ri[i] * vMax[0], (1 - ri[128 + i]) * vMin[1] + ri[128 + i] * vMax[1], (1 - ri[256 + i]) * vMin[2] + ri[256 + i] * vMax[2]);
+        ref.pErr = vec3(); ref.n = vec3();
+        vec3 wi; float pdf = 0.f; DevIt pl;
+        const rgb Li = light_sample<true>(sc, light, ref, ri[384 + i], ri[512 + i], &wi, &pdf, &pl);
+        if (pdf > 0) acc += luminance(Li) / pdf;
+    }
+    contrib[g] = acc;
+}
+// k_voxel_dist: one thread per voxel: the minimum weight (:286-296) and the Distribution1D constructor (core/sampling.h:57-70)
+__global__ __launch_bounds__(256) void k_voxel_dist(uint32_t nLights, uint32_t nVox, float *func, float *cdf, float *funcInt) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nVox) return;
+    float *f = func + (size_t)v * nLights, *c = cdf + (size_t)v * (nLights + 1);
+    float sum = 0.f;
+    for (uint32_t i = 0; i < nLights; ++i) sum += f[i];
+    const float avg = sum / (float)(128ull * nLights);
+    const float minContrib = (avg > 0) ? (float)(.001 * (double)avg) : 1.f;
+    for (uint32_t i = 0; i < nLights; ++i) f[i] = sel_max(f[i], minContrib);
+    const int n = (int)nLights;
+    c[0] = 0;
+    for (int i = 1; i < n + 1; ++i) c[i] = c[i - 1] + f[i - 1] / n;
+    const float fi = c[n];
+    if (fi == 0) for (int i = 1; i < n + 1; ++i) c[i] = float(i) / float(n);
+    else for (int i = 1; i < n + 1; ++i) c[i] /= fi;
+    funcInt[v] = fi;
+}
+
 __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1285,6 +1334,12 @@ void LaunchFilmOwn(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, c
 void LaunchFilmForeign(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, const float *LallR, const float *LallG,
                        const float *LallB, const FilmExtras &ex, float *film) {
     if (ex.nForeignDest) hipLaunchKernelGGL(k_film_foreign, dim3(blocks_for(ex.nForeignDest, 64)), dim3(64), 0, st, rp, fg, LallR, LallG, LallB, ex, film);
+}
+void LaunchVoxelDistributions(hipStream_t st, const DevScene &sc, const float *ri, uint32_t nVox, float *func, float *cdf, float *funcInt) {
+    const size_t total = (size_t)nVox * sc.nLights;
+    if (!total) return;
+    hipLaunchKernelGGL(k_voxel_contrib, dim3(blocks_for(total, 256)), dim3(256), 0, st, sc, ri, nVox, func);
+    hipLaunchKernelGGL(k_voxel_dist, dim3(blocks_for(nVox, 256)), dim3(256), 0, st, sc.nLights, nVox, func, cdf, funcInt);
 }
 void LaunchFilmForeignExport(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, const float *LallR, const float *LallG,
                              const float *LallB, const FilmExtras &ex, uint32_t nGroups, const uint32_t *groupDest, const uint32_t *groupTile,

@@ -45,6 +45,7 @@ struct HprtScene {
     hprt::DevBuf textures, mipLevels, texels, weightLut;
     hprt::DevBuf nodes, tris, primVtx, primN, vUV, vS, shapes, materials, lights, spheres, instances, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
     hprt::DevBuf counters, workCounter, deepStack;
+    hprt::DevBuf voxFunc, voxCdf, voxFuncInt, voxRi;      // SpatialLightDistribution tables (lightsamplestrategy "spatial")
     hprt::DevBuf rayStats, pixelStatsLocal, pixelStatsFilm; bool pixelStatsValid = false;   // HPRT_RENDER_PIXEL_STATS
     // render-time state
     hprt::DevBuf planes;                                    // backing store of the path streams (Workspace)
