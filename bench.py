@@ -363,6 +363,7 @@ def main():
             # same frame on both sides: ratio of frame rates (the CPU port traces the reference's full ray set)
             out["gpu_over_cpu"] = round(out["msamples_per_s"] / cpu_baseline["msamples_per_s"], 1)
         print(json.dumps(out))
+    comm = None      # (ncclCommDestroy now, not at interpreter shutdown)
     if dist is not None:
         dist.destroy_process_group()
 
