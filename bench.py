@@ -16,7 +16,7 @@ hprt_film_gather: one RCCL reduce over xGMI plus the ordered merge of the cross-
 
 `python bench.py --gpus N` without WORLD_SIZE in the environment starts N fresh rank processes itself (before this
 process touches the GPU) and relays rank 0's line; under torch.distributed.run it reads RANK/LOCAL_RANK/WORLD_SIZE.
-`n_gpus` is the size the RCCL communicator reports, never the flag.
+`n_gpus` is the size the RCCL communicator reports, never the flag (a --rehearse-on-one-gpu run says 1, with `world_size` ranks).
 
 Rays = closest-hit + shadow rays, as the reference counts them (core/scene.cpp:40-55), TRACED rays only.
 
@@ -181,7 +181,7 @@ def main():
         rccl_ranks, transport = info["n_ranks"], "RCCL (hprt_film_gather: ncclReduce + grouped send/recv)"
     elif world > 1:
         transport = "gloo rehearsal on one GPU (tiles.gather_film)"
-    n_gpus = rccl_ranks if rccl_ranks is not None else (1 if world == 1 else world)
+    n_gpus = rccl_ranks if rccl_ranks is not None else 1   # a rehearsal is world ranks on ONE card
 
     def merge(w):
         """Film::MergeFilmTile across ranks; part of the timed step."""

@@ -256,7 +256,7 @@ def test_bench_launches_its_own_ranks(tmp_path, killeroo_oracle):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["scaling"] == "strong" and line["config"]["spp_total"] == 4
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] is None and line["world_size"] == 2 and line["scaling"] == "strong" and line["config"]["spp_total"] == 4
     assert line["rays_per_step"] > 0 and line["value"] > 0
     got = np.load(dump)
     killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=4)
