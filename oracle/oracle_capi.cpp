@@ -287,8 +287,24 @@ int orc_sphere_reintersect_case(int seed, int partial, int nRays, float *params,
 }
 
 // detmath probes
-float orc_det_sinf(float x) { return (float)det::sin_d((double)x); }
-float orc_det_cosf(float x) { return (float)det::cos_d((double)x); }
+float orc_det_sinf(float x) { return det::sinf_glibc(x); }
+float orc_det_cosf(float x) { return det::cosf_glibc(x); }
+// Number of floats with bit patterns first, first+stride, ... (count of them, |x| < 120 only) on which the restated sinf / cosf
+// differ from the libm this process is linked with; out[0] = sinf mismatches, out[1] = cosf mismatches.
+void orc_sincosf_vs_libm(uint32_t first, uint32_t stride, uint64_t count, uint64_t out[2]) {
+    uint64_t bs = 0, bc = 0;
+    uint32_t u = first;
+    for (uint64_t i = 0; i < count; ++i, u += stride) {
+        float y; memcpy(&y, &u, 4);
+        if (!(std::fabs(y) < 120.f)) continue;
+        volatile float yy = y;
+        float a = sinf(yy), b = det::sinf_glibc(y);
+        if (memcmp(&a, &b, 4)) ++bs;
+        a = cosf(yy); b = det::cosf_glibc(y);
+        if (memcmp(&a, &b, 4)) ++bc;
+    }
+    out[0] = bs; out[1] = bc;
+}
 double orc_det_sin(double x) { return det::sin_d(x); }
 double orc_det_cos(double x) { return det::cos_d(x); }
 float orc_det_atan2f(float y, float x) { return (float)det::atan2_d((double)y, (double)x); }

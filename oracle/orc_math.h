@@ -78,8 +78,9 @@ inline Float Lerp(Float t, Float v1, Float v2) { return (1 - t) * v1 + t * v2; }
 // oracle offers two modes: g_use_libm=true follows the reference literally
 // (glibc), false uses these functions, which are built from IEEE-exact double
 // operations only and are restated operation for operation in the HIP path.
-// The float versions are (float)det_xxx((double)x): correctly rounded except
-// for ~1e-8 of arguments.
+// sinf / cosf are glibc's own algorithm restated (below: bit-identical to it);
+// the other float versions are (float)det_xxx((double)x): correctly rounded
+// except for ~1e-8 of arguments, i.e. NOT always glibc's value.
 // ---------------------------------------------------------------------------
 extern bool g_use_libm;
 
@@ -203,9 +204,80 @@ inline double log_d(double x) {
 }
 }  // namespace det
 
+// ---------------------------------------------------------------------------
+// sinf / cosf as glibc 2.35 computes them (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h, sincosf_data.c:
+// the ARM optimized-routines algorithm; NOT part of /root/reference, a dependency of it through std::sin(float) /
+// std::cos(float)).  Everything is double arithmetic on the float argument: |x| < 0.75 (the comparison is on the top
+// 12 bits of the float, so the threshold is 0.75 and not pi/4) evaluates a degree-7 / degree-8 polynomial directly,
+// |x| < 120 first subtracts n*(pi/2) with n = round(x * 2/pi) taken from a 2^24-scaled product.  x86-64 glibc picks
+// its FMA build of these files on any CPU with FMA (sysdeps/x86_64/fpu/multiarch/s_sinf.c), so every a*b+c below is
+// ONE rounding (std::fma).  tests/test_oracle_pins.py compares this restatement with the libm of the machine it runs
+// on for every float in (-120, 120) it samples; an exhaustive pass over all 2,246,049,792 such floats found no
+// difference from glibc 2.35-0ubuntu3.11 (tools/debug/sincosf_exhaustive.c).  |x| >= 120 (never reached by the path:
+// its arguments are 2*pi*u and pi/4*ratio) keeps the series above.
+// ---------------------------------------------------------------------------
+namespace det {
+struct SinCosTab { double c0, c1, c2, c3, c4, s1, s2, s3; };
+static const SinCosTab kSinCos[2] = {
+    { 0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16,
+      -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13 },
+    { -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5, 0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16,
+      -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13 } };
+inline uint32_t abstop12(float x) { uint32_t u; memcpy(&u, &x, 4); return (u >> 20) & 0x7ffu; }
+// sincosf.h sinf_poly: sin polynomial for even n, cos polynomial for odd n
+inline float sincos_poly(double x, double x2, const SinCosTab &p, int n) {
+    if ((n & 1) == 0) {
+        double x3 = x * x2;
+        double s1 = std::fma(x2, p.s3, p.s2);
+        double x7 = x3 * x2;
+        double s = std::fma(x3, p.s1, x);
+        return (float)std::fma(x7, s1, s);
+    }
+    double x4 = x2 * x2;
+    double c2 = std::fma(x2, p.c4, p.c3);
+    double c1 = std::fma(x2, p.c2, p.c1);
+    double x6 = x4 * x2;
+    double c = std::fma(x2, c1, p.c0);
+    return (float)std::fma(x6, c2, c);
+}
+// sincosf.h reduce_fast: n = round(x / (pi/2)) through a product scaled by 2^24, remainder in one fused step
+inline double sincos_reduce(double x, int *np) {
+    double r = x * 0x1.45F306DC9C883p+23;
+    int n = ((int32_t)r + 0x800000) >> 24;
+    *np = n;
+    return std::fma(-(double)n, 0x1.921FB54442D18p0, x);
+}
+inline float sinf_glibc(float y) {
+    double x = y;
+    if (abstop12(y) < 0x3f4u) {                    // |y| < 0.75
+        if (abstop12(y) < 0x398u) return y;        // |y| < 2^-12
+        return sincos_poly(x, x * x, kSinCos[0], 0);
+    }
+    if (abstop12(y) < 0x42fu) {                    // |y| < 120
+        int n; x = sincos_reduce(x, &n);
+        double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        return sincos_poly(x * s, x * x, kSinCos[(n >> 1) & 1], n);
+    }
+    return (float)sin_d((double)y);
+}
+inline float cosf_glibc(float y) {
+    double x = y;
+    if (abstop12(y) < 0x3f4u) {
+        if (abstop12(y) < 0x398u) return 1.0f;
+        return sincos_poly(x, x * x, kSinCos[0], 1);
+    }
+    if (abstop12(y) < 0x42fu) {
+        int n; x = sincos_reduce(x, &n);
+        double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        return sincos_poly(x * s, x * x, kSinCos[(n >> 1) & 1], n ^ 1);
+    }
+    return (float)cos_d((double)y);
+}
+}  // namespace det
+
 // float-argument versions, as std::sin(float) etc. in the reference.
-inline float m_sinf(float x) { return g_use_libm ? std::sin(x) : (float)det::sin_d((double)x); }
-inline float m_cosf(float x) { return g_use_libm ? std::cos(x) : (float)det::cos_d((double)x); }
+inline float m_sinf(float x) { return g_use_libm ? std::sin(x) : det::sinf_glibc(x); }
+inline float m_cosf(float x) { return g_use_libm ? std::cos(x) : det::cosf_glibc(x); }
 inline float m_atan2f(float y, float x) { return g_use_libm ? std::atan2(y, x) : (float)det::atan2_d((double)y, (double)x); }
 inline float m_acosf(float x) { return g_use_libm ? std::acos(x) : (float)det::acos_d((double)x); }
 inline float m_logf(float x) { return g_use_libm ? std::log(x) : (float)det::log_d((double)x); }

@@ -351,3 +351,39 @@ def test_untraced_light_rays_change_nothing(hprt, killeroo_model, killeroo_scene
     killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
     assert np.array_equal(film0.view(np.uint32), film_cut.view(np.uint32))
     assert c0["rays"] == st_ref["rays"] and c0["nodes_fetched"] == st_ref["nodes_fetched"]
+
+
+_FEW_WAVES_SCRIPT = r"""
+import importlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+hprt = importlib.import_module("thesis-pbrt-v3_amd")
+model = hprt.Model.load(sys.argv[2]); bvh = hprt.Bvh(model); scene = hprt.Scene(model, bvh, device=0)
+opt = model.options.copy(); opt.spp = 1
+for i, v in enumerate((0.3, 0.6, 0.3, 0.6)):
+    opt.crop[i] = v
+film, _ = scene.render(opt)
+np.save(sys.argv[3], film)
+"""
+
+
+def test_few_waves_working_through_many_queue_chunks(tmp_path, killeroo_oracle):
+    """The persistent traversal waves draw rays from the queue head in chunks and prefetch the next queue entries while the
+    current rays load.  A wave that exhausts its chunk and then draws the ADJACENT chunk (nobody else drew in between) must
+    not mistake the empty prefetch of the exhausted chunk for the first entries of the new one: that happened in round 2
+    whenever waves started staggered (other processes or streams on the card) and showed as rare film mismatches.  Here one
+    workgroup (HPRT_TRACE_MAX_BLOCKS=1, 64-ray chunks) traces every queue of a render, so adjacent draws are the rule."""
+    import os, subprocess, sys
+    from conftest import KILLEROO, ROOT
+    out = str(tmp_path / "film.npy")
+    env = dict(os.environ, HPRT_TRACE_MAX_BLOCKS="1", HPRT_TRACE_CHUNK_MAX="64")
+    r = subprocess.run([sys.executable, "-c", _FEW_WAVES_SCRIPT, ROOT, KILLEROO, out], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    killeroo_oracle.set_film(crop=(0.3, 0.6, 0.3, 0.6), spp=1)
+    try:
+        _, film0, _, _, _ = killeroo_oracle.render(spp=1, threads=16)
+    finally:
+        killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
+    bad = (got.view(np.uint32) != film0.view(np.uint32)).any(axis=2)
+    assert not bad.any(), "%d of %d pixels differ from the oracle's film" % (int(bad.sum()), bad.size)

@@ -162,13 +162,32 @@ def test_libm_mode_is_statistically_indistinguishable(killeroo_oracle, orc):
     assert np.median(rel) < 1e-6
 
 
+def test_sinf_cosf_are_glibcs(orc):
+    """The restated sinf / cosf (oracle/orc_math.h det::sinf_glibc, the device's det_sincosf) against the libm this process
+    runs on, for every third float bit pattern with |x| < 120: no difference on a CPU with FMA (x86-64 glibc then runs the
+    FMA build the restatement follows; its SSE2 build differs on 34 of the 2.2e9 floats, tools/debug/sincosf_exhaustive.c)."""
+    from concurrent.futures import ThreadPoolExecutor
+    fn = orc.lib.orc_sincosf_vs_libm
+    fn.restype = None
+    fn.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
+    def part(k):
+        out = (C.c_uint64 * 2)()
+        fn(3 * k, 24, (1 << 32) // 24, out)
+        return out[0], out[1]
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(part, range(8)))
+    bad_s, bad_c = sum(r[0] for r in res), sum(r[1] for r in res)
+    has_fma = " fma " in open("/proc/cpuinfo").read()
+    assert (bad_s, bad_c) == (0, 0) if has_fma else bad_s + bad_c < 40, (bad_s, bad_c, has_fma)
+
+
 def test_detmath_accuracy(orc):
     x = np.linspace(-7.0, 7.0, 200001).astype(np.float32)
     got_s = np.array([orc.lib.orc_det_sinf(C.c_float(float(v))) for v in x[::40]], np.float32)
     got_c = np.array([orc.lib.orc_det_cosf(C.c_float(float(v))) for v in x[::40]], np.float32)
     want_s = np.sin(x[::40].astype(np.float64)).astype(np.float32)
     want_c = np.cos(x[::40].astype(np.float64)).astype(np.float32)
-    assert (got_s != want_s).mean() < 1e-3 and (got_c != want_c).mean() < 1e-3   # correctly rounded almost everywhere
+    assert (got_s != want_s).mean() < 3e-2 and (got_c != want_c).mean() < 3e-2   # glibc's sinf/cosf are within 0.56 ulp, not correctly rounded
     assert np.abs(got_s - want_s).max() < 2e-7 and np.abs(got_c - want_c).max() < 2e-7
     ys = np.linspace(-3, 3, 301).astype(np.float32)
     for yv in ys[::10]:

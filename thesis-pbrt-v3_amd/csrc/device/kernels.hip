@@ -301,6 +301,9 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                     localNext = base < n ? base : n;
                     localEnd = (base + chunk < n) ? base + chunk : n;
                     if (localNext >= localEnd) moreWork = false;       // queue drained
+                    // the window prefetched at the end of the exhausted chunk is empty; it must not pass for the head of this
+                    // chunk when the two happen to be adjacent (same base)
+                    windowBase = 0xffffffffu;
                 }
                 const uint32_t want = (uint32_t)__popcll(idle);
                 const uint32_t base = localNext;
@@ -1195,7 +1198,9 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     if (gridItems == 0) return;
     (void)hipMemsetAsync(workCounter, 0, sizeof(uint32_t), st);
     // persistent waves: enough blocks to fill 256 CUs at this kernel's occupancy, never more than the rays need
-    const uint32_t maxBlocks = HPRT_DEEP_THREADS / HPRT_TRACE_BLOCK;      // 256 CUs x 5 workgroups of 256 threads
+    // (HPRT_TRACE_MAX_BLOCKS: test hook — a handful of waves working through many queue chunks each, tests/test_gpu_parity.py)
+    static const uint32_t blockCap = [] { const char *e = getenv("HPRT_TRACE_MAX_BLOCKS"); return e ? (uint32_t)std::max(1, atoi(e)) : 0xffffffffu; }();
+    const uint32_t maxBlocks = std::min(HPRT_DEEP_THREADS / HPRT_TRACE_BLOCK, blockCap);      // 256 CUs x 5 workgroups of 256 threads
     dim3 grid(std::min(blocks_for(gridItems, HPRT_TRACE_BLOCK), maxBlocks)), block(HPRT_TRACE_BLOCK);
     // rays per queue-head atomic: large launches take 512 at a time, small ones keep every wave busy
     const uint32_t nWaves = grid.x * (HPRT_TRACE_BLOCK / 64);

@@ -136,12 +136,14 @@ HPRT_HD vec3 offset_ray_origin(vec3 p, vec3 pErr, vec3 n, vec3 w) {
 }
 
 // ---------------------------------------------------------------------------
-// Deterministic sin/cos/atan2/acos.  The reference calls glibc here; libm
-// results are not reproducible on the device, so the product path evaluates
-// these from IEEE-exact double operations (Cody-Waite reduction + Taylor
-// polynomials, error ~1e-16) and rounds once to float: correctly rounded for
-// all but ~1e-8 of arguments.  DESIGN.md §Numerics states the measured
-// difference against glibc.
+// Deterministic sin/cos/atan2/acos.  The reference calls glibc here.  sinf and
+// cosf (the two the path calls per sample) are glibc's own algorithm restated
+// further down and return its values bit for bit; double sin/cos, atan2f and
+// acosf (sphere parametrisation, one normal-incidence branch) are evaluated
+// from IEEE-exact double operations (Cody-Waite reduction + Taylor
+// polynomials, error ~1e-16) and rounded once to float: correctly rounded for
+// all but ~1e-8 of arguments, which is not always glibc's value.  DESIGN.md
+// §5 states the measured difference against glibc.
 // ---------------------------------------------------------------------------
 HPRT_HD double k_sin(double r) {
     double z = r * r;
@@ -201,7 +203,58 @@ HPRT_HD void det_sincos(double x, double *sn, double *cs) {
     *sn = q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c));
     *cs = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
 }
-HPRT_HD void det_sincosf(float x, float *sn, float *cs) { double s, c; det_sincos((double)x, &s, &c); *sn = (float)s; *cs = (float)c; }
+// sinf / cosf: glibc 2.35's algorithm (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h — what the reference's
+// std::sin(float) / std::cos(float) run), restated so the device returns glibc's value bit for bit: double arithmetic on
+// the float argument, a degree-7 / degree-8 polynomial after one fused reduction step by n*(pi/2).  The fused
+// multiply-adds are explicit because x86-64 glibc runs its FMA build of these files; everything else in this header is
+// compiled with contraction off.  The interval tests compare the top 12 bits of the float as glibc does (0.75, 2^-12, 120).
+// oracle/orc_math.h holds the CPU restatement and the account of the exhaustive check against libm.  |x| >= 120 is not
+// reached by the path (arguments are 2*pi*u and pi/4*ratio) and keeps the series above.
+HPRT_HD unsigned det_abstop12(float x) { unsigned u; memcpy(&u, &x, 4); return (u >> 20) & 0x7ffu; }
+HPRT_HD float det_sincos_poly(double x, double x2, bool negCos, int n) {
+    if ((n & 1) == 0) {
+        double x3 = x * x2;
+        double s1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+        double x7 = x3 * x2;
+        double s = __builtin_fma(x3, -0x1.555545995a603p-3, x);
+        return (float)__builtin_fma(x7, s1, s);
+    }
+    const double sg = negCos ? -1.0 : 1.0;       // the second table row: the cosine coefficients negated (exact)
+    double x4 = x2 * x2;
+    double c2 = __builtin_fma(x2, sg * 0x1.99343027bf8c3p-16, sg * -0x1.6c087e89a359dp-10);
+    double c1 = __builtin_fma(x2, sg * 0x1.55553e1068f19p-5, sg * -0x1.ffffffd0c621cp-2);
+    double x6 = x4 * x2;
+    double c = __builtin_fma(x2, c1, sg);
+    return (float)__builtin_fma(x6, c2, c);
+}
+HPRT_HD double det_sincos_reduce(double x, int *np) {
+    double r = x * 0x1.45F306DC9C883p+23;
+    int n = ((int)r + 0x800000) >> 24;
+    *np = n;
+    return __builtin_fma(-(double)n, 0x1.921FB54442D18p0, x);
+}
+HPRT_HD void det_sincosf(float y, float *sn, float *cs) {
+    double x = y;
+    const unsigned top = det_abstop12(y);
+    if (top < 0x3f4u) {
+        if (top < 0x398u) { *sn = y; *cs = 1.0f; return; }
+        double x2 = x * x;
+        *sn = det_sincos_poly(x, x2, false, 0);
+        *cs = det_sincos_poly(x, x2, false, 1);
+        return;
+    }
+    if (top < 0x42fu) {
+        int n; x = det_sincos_reduce(x, &n);
+        const int q = n & 3;
+        const double xs = (q == 1 || q == 2) ? -x : x;
+        const double x2 = x * x;
+        const bool neg = (n & 2) != 0;
+        *sn = det_sincos_poly(xs, x2, neg, n);
+        *cs = det_sincos_poly(xs, x2, neg, n ^ 1);
+        return;
+    }
+    double s, c; det_sincos((double)y, &s, &c); *sn = (float)s; *cs = (float)c;
+}
 HPRT_HD double det_atan_pos(double t) {
     double base = 0.0; bool inv = false;
     if (t > 1.0) { t = 1.0 / t; inv = true; }
@@ -247,8 +300,8 @@ HPRT_HD double det_log(double x) {
     return (double)e * 6.93147180369123816490e-01 + ((double)e * 1.90821492927058770002e-10 + 2.0 * s * p);
 }
 HPRT_HD float det_logf(float x) { return (float)det_log((double)x); }
-HPRT_HD float det_sinf(float x) { return (float)det_sin((double)x); }
-HPRT_HD float det_cosf(float x) { return (float)det_cos((double)x); }
+HPRT_HD float det_sinf(float x) { float s, c; det_sincosf(x, &s, &c); return s; }
+HPRT_HD float det_cosf(float x) { float s, c; det_sincosf(x, &s, &c); return c; }
 HPRT_HD float det_atan2f(float y, float x) { return (float)det_atan2((double)y, (double)x); }
 HPRT_HD float det_acosf(float x) { return (float)det_acos((double)x); }
 
