@@ -108,6 +108,13 @@ def test_render_crop_film_and_counters(hprt, killeroo_model, killeroo_scene, kil
         "film differs in %d pixels, max |d| %g" % (int(np.any(film0 != film1, axis=2).sum()), float(np.abs(film0 - film1).max()))
     rgb1 = hprt.film_resolve(film1, opt.film_scale)
     assert np.array_equal(rgb0.view(np.uint32), rgb1.view(np.uint32))
+    # scratch memory filled with garbage first (large floats / small indices): the film may not depend on it
+    try:
+        for byte in (0x7F, 0x01):
+            killeroo_scene.debug_poison(byte)
+            assert np.array_equal(killeroo_scene.render(opt)[0].view(np.uint32), film1.view(np.uint32)), hex(byte)
+    finally:
+        killeroo_scene.debug_poison(None)
     assert st["camera_rays"] == c0["camera_rays"] and st["rays"] == c0["rays"] and st["shadow_rays"] == c0["shadow_rays"]
     assert st["nodes_fetched"] == c0["nodes_fetched"] and st["nodes_fetched_p"] == c0["nodes_fetched_p"]
     assert st["nodes_entered"] == c0["nodes_entered"] and st["nodes_entered_p"] == c0["nodes_entered_p"]

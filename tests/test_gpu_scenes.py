@@ -168,6 +168,11 @@ def test_scene_film_parity(hprt, orc, tmp_path, name):
     # the plain render (rays that provably change nothing are not traced) must give the same film
     film_plain, st_plain = scene.render()
     assert np.array_equal(film_plain.view(np.uint32), film1.view(np.uint32)) and st_plain["rays"] <= st["rays"] and st_plain["shadow_rays"] == st["shadow_rays"]
+    # garbage instead of whatever the allocator handed out: nothing may be consumed that the render did not write
+    scene.debug_poison(0xFF)
+    film_poisoned, _ = scene.render()
+    scene.debug_poison(None)
+    assert np.array_equal(film_poisoned.view(np.uint32), film1.view(np.uint32))
     assert film1.shape == film0.shape
     bad = np.any(film0.view(np.uint32) != film1.view(np.uint32), axis=2)
     assert not bad.any(), "%s: %d pixels differ, max |d| = %g" % (name, int(bad.sum()), float(np.abs(film0 - film1).max()))

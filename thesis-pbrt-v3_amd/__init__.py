@@ -370,6 +370,12 @@ class Scene:
             _check(lib.hprt_film_read(self._h, _ptr(film), film.shape[0] * film.shape[1]))
         return film, st.as_dict()
 
+    def debug_poison(self, byte):
+        """Test hook (not part of include/hprt.h): fill every scratch stream, queue and stack with `byte` before each render
+        (None switches it off).  A film that changes under it means a render consumed a word it never wrote."""
+        lib.hprt_debug_poison_workspace.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.hprt_debug_poison_workspace(self._h, -1 if byte is None else int(byte)))
+
     def film_records(self):
         """Cross-tile film contributions of the last render(export_foreign=True): FILM_RECORD array (HprtFilmRecord)."""
         n = C.c_size_t()

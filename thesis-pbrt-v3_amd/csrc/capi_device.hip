@@ -603,6 +603,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
 } catch (...) { return hprt::HandleException(); }
 
 // Diagnostics hook (not part of include/hprt.h): the 128 sample points of a voxel, RadicalInverse(0..4, i) as [5][128]
+__attribute__((visibility("default"))) int hprt_debug_poison_workspace(HprtScene *s, int byte) { if (!s) return HPRT_E_INVALID; s->poisonByte = byte < 0 ? -1 : (byte & 255); return HPRT_OK; }
 __attribute__((visibility("default"))) int hprt_debug_voxel_points(float out[640]) { if (!out) return HPRT_E_INVALID; VoxelSamplePoints(out); return HPRT_OK; }
 
 int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int device, HprtScene **out) try {
@@ -897,6 +898,16 @@ int EnsureWorkspace(HprtScene *s, size_t nSlots, Workspace *ps, QueueSet *qa, Qu
     return HPRT_OK;
 }
 
+// Test hook: garbage in everything a render treats as scratch.  A render whose film changes under it has consumed a word
+// it never wrote (a fresh allocation on a busy card holds other processes' data, not zeros).
+int PoisonWorkspace(HprtScene *s) {
+    if (s->poisonByte < 0) return HPRT_OK;
+    hprt::DevBuf *bufs[] = {&s->planes, &s->queues, &s->Lall, &s->deepStack, &s->rayStats, &s->irregular};
+    for (hprt::DevBuf *b : bufs) if (b->p && b->bytes) HIP_TRY(hipMemset(b->p, s->poisonByte, b->bytes));
+    HIP_TRY(hipDeviceSynchronize());
+    return HPRT_OK;
+}
+
 // Host-side grouping of the irregular samples into per-destination lists, in the exact
 // order the reference's tile loop would have added them (core/integrator.cpp:267-333).
 struct ExtraEntry { uint32_t dest; uint32_t srcTile; uint32_t srcPos; uint32_t sample; uint32_t srcPix; uint8_t pre; };
@@ -958,6 +969,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     rc = EnsureWorkspace(s, maxSlots, &ps, &qa, &qb, &bins);
     if (rc != HPRT_OK) return rc;
     HIP_TRY(s->Lall.alloc(lallBytes));
+    if ((rc = PoisonWorkspace(s)) != HPRT_OK) return rc;
     float *LallR = s->Lall.as<float>(), *LallG = LallR + (size_t)spp * nPix, *LallB = LallG + (size_t)spp * nPix;
     HIP_TRY(upload(s->pixelXY, f.pixelXY)); HIP_TRY(upload(s->pixelOffset, f.pixelOffset));
     RenderParams rp;
@@ -1130,6 +1142,7 @@ int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, c
     if (rc != HPRT_OK) return rc;
     HIP_TRY(upload(s->pixelXY, xy)); HIP_TRY(upload(s->pixelOffset, off));
     HIP_TRY(s->Lall.alloc(12 * n));
+    if ((rc = PoisonWorkspace(s)) != HPRT_OK) return rc;
     RenderParams rp;
     MakeCamera(*opt, &rp.cam);
     rp.hal.baseScale1 = f.hal.baseScales[1]; rp.hal.baseExp0 = f.hal.baseExponents[0]; rp.hal.sampleStride = f.hal.sampleStride;

@@ -45,6 +45,7 @@ struct HprtScene {
     hprt::DevBuf textures, mipLevels, texels, weightLut;
     hprt::DevBuf nodes, tris, primVtx, primN, vUV, vS, shapes, materials, lights, spheres, instances, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
     hprt::DevBuf counters, workCounter, deepStack;
+    int poisonByte = -1;      // hprt_debug_poison_workspace (tests): fill every stream, queue and stack with this byte before each render
     hprt::DevBuf voxFunc, voxCdf, voxFuncInt, voxRi;      // SpatialLightDistribution tables (lightsamplestrategy "spatial")
     hprt::DevBuf rayStats, pixelStatsLocal, pixelStatsFilm; bool pixelStatsValid = false;   // HPRT_RENDER_PIXEL_STATS
     // render-time state
