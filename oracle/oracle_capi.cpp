@@ -307,7 +307,23 @@ void orc_sincosf_vs_libm(uint32_t first, uint32_t stride, uint64_t count, uint64
 }
 double orc_det_sin(double x) { return det::sin_d(x); }
 double orc_det_cos(double x) { return det::cos_d(x); }
-float orc_det_atan2f(float y, float x) { return (float)det::atan2_d((double)y, (double)x); }
-float orc_det_acosf(float x) { return (float)det::acos_d((double)x); }
+float orc_det_atan2f(float y, float x) { return det::atan2f_glibc(y, x); }
+float orc_det_acosf(float x) { return det::acosf_glibc(x); }
+// as orc_sincosf_vs_libm: out[0] = acosf mismatches (|x| <= 1), out[1] = atanf mismatches, out[2] = atan2f(y, x) mismatches with x
+// taken from a second pattern sequence
+void orc_atan_acos_vs_libm(uint32_t first, uint32_t stride, uint64_t count, uint64_t out[3]) {
+    uint64_t ba = 0, bt = 0, b2 = 0;
+    uint32_t u = first, v = first * 2654435761u + 12345u;
+    for (uint64_t i = 0; i < count; ++i, u += stride, v = v * 1664525u + 1013904223u) {
+        float y, x; memcpy(&y, &u, 4); memcpy(&x, &v, 4);
+        if (y != y) continue;
+        volatile float yy = y, xx = x;
+        float a, b;
+        if (std::fabs(y) <= 1.f) { a = acosf(yy); b = det::acosf_glibc(y); if (memcmp(&a, &b, 4)) ++ba; }
+        a = atanf(yy); b = det::atanf_glibc(y); if (memcmp(&a, &b, 4)) ++bt;
+        if (x == x && !std::isinf(x) && !std::isinf(y)) { a = atan2f(yy, xx); b = det::atan2f_glibc(y, x); if (memcmp(&a, &b, 4)) ++b2; }
+    }
+    out[0] = ba; out[1] = bt; out[2] = b2;
+}
 
 }  // extern "C"

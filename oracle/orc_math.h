@@ -275,11 +275,117 @@ inline float cosf_glibc(float y) {
 }
 }  // namespace det
 
+// ---------------------------------------------------------------------------
+// acosf / atanf / atan2f as glibc 2.35 computes them (sysdeps/ieee754/flt-32/e_acosf.c, s_atanf.c, e_atan2f.c: fdlibm's
+// float routines; a dependency of the reference through std::acos(float) / std::atan2(float, float) in shapes/sphere.cpp).
+// Plain float arithmetic, one rounding per operation.  Checked against the libm of this machine: acosf on all
+// 2,130,706,434 floats of [-1, 1], atanf on every float, atan2f on 480 M pairs — no difference
+// (tools/debug/atanf_acosf_exhaustive.c); tests/test_oracle_pins.py re-checks a sample.
+// ---------------------------------------------------------------------------
+
+namespace det {
+inline int f2i(float x) { int i; memcpy(&i, &x, 4); return i; }
+inline float i2f(int i) { float x; memcpy(&x, &i, 4); return x; }
+// e_acosf.c
+inline float acosf_glibc(float x) {
+    const float one = 1.0f, pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f,
+                pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
+                pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f,
+                qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    const int hx = f2i(x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;       // |x| == 1
+    if (ix > 0x3f800000) return (x - x) / (x - x);                          // |x| > 1: NaN
+    if (ix < 0x3f000000) {                                                  // |x| < 0.5
+        if (ix <= 0x32800000) return pio2_hi + pio2_lo;
+        const float z = x * x;
+        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (hx < 0) {                                                           // x < -0.5
+        const float z = (one + x) * 0.5f;
+        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float s = std::sqrt(z);
+        const float r = p / q;
+        const float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    const float z = (one - x) * 0.5f;                                       // x > 0.5
+    const float s = std::sqrt(z);
+    const float df = i2f(f2i(s) & (int)0xfffff000);
+    const float c = (z - df * df) / (s + df);
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    const float w = r * s + c;
+    return 2.0f * (df + w);
+}
+// s_atanf.c
+inline float atanf_glibc(float x) {
+    const float one = 1.0f;
+    const float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f, hi3 = 1.5707962513e+00f;
+    const float lo0 = 5.0121582440e-09f, lo1 = 3.7748947079e-08f, lo2 = 3.4473217170e-08f, lo3 = 7.5497894159e-08f;
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const int hx = f2i(x), ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {                                                 // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;
+        return hx > 0 ? hi3 + lo3 : -hi3 - lo3;
+    }
+    if (ix < 0x3ee00000) {                                                  // |x| < 0.4375
+        if (ix < 0x31000000) return x;
+        id = -1;
+    } else {
+        x = std::fabs(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - one) / (2.0f + x); }
+            else { id = 1; x = (x - one) / (x + one); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (one + 1.5f * x); }
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float hi = id == 0 ? hi0 : id == 1 ? hi1 : id == 2 ? hi2 : hi3, lo = id == 0 ? lo0 : id == 1 ? lo1 : id == 2 ? lo2 : lo3;
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -r : r;
+}
+// e_atan2f.c (finite arguments; infinities do not occur on the path and return NaN here)
+inline float atan2f_glibc(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int hx = f2i(x), hy = f2i(y), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return atanf_glibc(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000 || iy == 0x7f800000) return (x - x) / (x - x);
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = atanf_glibc(std::fabs(y / x));
+    switch (m) {
+    case 0: return z;
+    case 1: return i2f(f2i(z) ^ (int)0x80000000);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+}  // namespace det
+
 // float-argument versions, as std::sin(float) etc. in the reference.
 inline float m_sinf(float x) { return g_use_libm ? std::sin(x) : det::sinf_glibc(x); }
 inline float m_cosf(float x) { return g_use_libm ? std::cos(x) : det::cosf_glibc(x); }
-inline float m_atan2f(float y, float x) { return g_use_libm ? std::atan2(y, x) : (float)det::atan2_d((double)y, (double)x); }
-inline float m_acosf(float x) { return g_use_libm ? std::acos(x) : (float)det::acos_d((double)x); }
+inline float m_atan2f(float y, float x) { return g_use_libm ? std::atan2(y, x) : det::atan2f_glibc(y, x); }
+inline float m_acosf(float x) { return g_use_libm ? std::acos(x) : det::acosf_glibc(x); }
 inline float m_logf(float x) { return g_use_libm ? std::log(x) : (float)det::log_d((double)x); }
 // double-argument versions: unqualified sin()/cos() in core/microfacet.cpp:241-246
 // resolve to ::sin(double)/::cos(double) under libstdc++ <cmath>.

@@ -398,7 +398,8 @@ struct Frontend {
                 P = *vp;
                 if (name == "trianglemesh") {   // shapes/triangle.cpp:723-819
                     const std::vector<float> *uv = params.point2s("uv"); if (!uv) uv = params.point2s("st");
-                    if (!uv) uv = params.floats("uv"); if (!uv) uv = params.floats("st");
+                    if (!uv) uv = params.floats("uv");
+                    if (!uv) uv = params.floats("st");
                     if (uv) { if (uv->size() / 2 < P.size() / 3) warn("Not enough \"uv\"s for triangle mesh; discarded"); else UV = *uv; }
                     const std::vector<float> *s = params.vectors("S"); if (s && s->size() == P.size()) S = *s;
                     const std::vector<float> *n = params.normals("N"); if (n && n->size() == P.size()) N = *n;
