@@ -309,6 +309,18 @@ double orc_det_sin(double x) { return det::sin_d(x); }
 double orc_det_cos(double x) { return det::cos_d(x); }
 float orc_det_atan2f(float y, float x) { return det::atan2f_glibc(y, x); }
 float orc_det_acosf(float x) { return det::acosf_glibc(x); }
+// logf mismatches against libm over positive finite float bit patterns first, first+stride, ...
+uint64_t orc_logf_vs_libm(uint32_t first, uint32_t stride, uint64_t count) {
+    uint64_t bad = 0; uint32_t u = first;
+    for (uint64_t i = 0; i < count; ++i, u += stride) {
+        if (u == 0 || u >= 0x7f800000u) continue;
+        float x; memcpy(&x, &u, 4);
+        volatile float xx = x;
+        float a = logf(xx), b = det::logf_glibc(x);
+        if (memcmp(&a, &b, 4)) ++bad;
+    }
+    return bad;
+}
 // as orc_sincosf_vs_libm: out[0] = acosf mismatches (|x| <= 1), out[1] = atanf mismatches, out[2] = atan2f(y, x) mismatches with x
 // taken from a second pattern sequence
 void orc_atan_acos_vs_libm(uint32_t first, uint32_t stride, uint64_t count, uint64_t out[3]) {

@@ -197,6 +197,18 @@ def test_acosf_atanf_atan2f_are_glibcs(orc):
     assert [sum(r[i] for r in res) for i in range(3)] == [0, 0, 0], res
 
 
+def test_logf_is_glibcs(orc):
+    """glibc 2.35's table-driven logf restated (texture level of detail: Log2, core/pbrt.h:328-331) against this machine's libm on
+    every 16th positive finite float."""
+    from concurrent.futures import ThreadPoolExecutor
+    fn = orc.lib.orc_logf_vs_libm
+    fn.restype = C.c_uint64
+    fn.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(lambda k: fn(2 * k + 1, 16, (1 << 31) // 16), range(8)))
+    assert sum(res) == 0, res
+
+
 def test_detmath_accuracy(orc):
     x = np.linspace(-7.0, 7.0, 200001).astype(np.float32)
     got_s = np.array([orc.lib.orc_det_sinf(C.c_float(float(v))) for v in x[::40]], np.float32)
