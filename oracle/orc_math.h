@@ -73,14 +73,14 @@ inline Float Lerp(Float t, Float v1, Float v2) { return (1 - t) * v1 + t * v2; }
 
 // ---------------------------------------------------------------------------
 // Deterministic transcendental functions ("detmath").
-// The reference calls glibc's sinf/cosf/atan2f/acosf (float) and sin/cos
-// (double).  libm results cannot be reproduced bit-for-bit on the GPU, so the
-// oracle offers two modes: g_use_libm=true follows the reference literally
-// (glibc), false uses these functions, which are built from IEEE-exact double
-// operations only and are restated operation for operation in the HIP path.
-// sinf / cosf are glibc's own algorithm restated (below: bit-identical to it);
-// the other float versions are (float)det_xxx((double)x): correctly rounded
-// except for ~1e-8 of arguments, i.e. NOT always glibc's value.
+// The reference calls glibc's sinf/cosf/atan2f/acosf/logf (float) and sin/cos
+// (double).  The oracle offers two modes: g_use_libm=true follows the
+// reference literally (whatever libm the host has), false uses the functions
+// below, which the HIP path restates operation for operation.  The float ones
+// (further down: sinf_glibc, cosf_glibc, acosf_glibc, atan2f_glibc,
+// logf_glibc) are glibc 2.35's own algorithms and return its values bit for
+// bit; the double sin/cos (one rarely taken branch) are series evaluated with
+// IEEE-exact double operations: accurate to ~1e-16, not always glibc's value.
 // ---------------------------------------------------------------------------
 extern bool g_use_libm;
 
