@@ -1,0 +1,76 @@
+"""The bench workloads at the sizes bench.py runs them (BASELINE.json configs[2] and the conference-room class of
+configs[3]), on the GPU.  A full frame of either is minutes of oracle time, so each is held to
+
+  (1) per-sample parity: the radiance of 40,000 random (pixel, sample) pairs of the full-size sample sequence equals the
+      oracle's bit for bit (hprt_sample_radiance runs the same kernels as hprt_render on those paths), and
+  (2) size-independent properties of the complete frame: film and work counters do not depend on how the samples are cut
+      into wavefront batches, the box-filter weights add up to spp, and two tile shards rendered with
+      HPRT_RENDER_EXPORT_FOREIGN and merged in source-tile order (the N-GPU path) reproduce the unsharded film bit for bit.
+
+killeroo-simple (configs[1]) has the same in test_gpu_parity.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("camera_rays", "rays", "shadow_rays", "nodes_fetched", "nodes_fetched_p", "nodes_entered", "nodes_entered_p",
+        "tri_tests", "tri_tests_p", "sphere_tests", "sphere_tests_p")
+
+
+@pytest.fixture(scope="module")
+def bench_module():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+@pytest.mark.parametrize("name,chunk", [("atrium", 300), ("living-room", 100)])
+def test_bench_workload_at_full_size(hprt, orc, tmp_path, bench_module, name, chunk):
+    spp = bench_module.WORKLOADS[name][1]
+    model = bench_module.build_model(hprt, name)
+    bvh = hprt.Bvh(model)
+    scene = hprt.Scene(model, bvh)
+    opt = model.options.copy()
+    opt.spp = spp
+    W, H = opt.xres, opt.yres
+    assert (W, H, spp) == {"atrium": (700, 700, 1024), "living-room": (1280, 720, 256)}[name]
+
+    # (1) per-sample parity against the oracle on the full-size sample sequence
+    baked = str(tmp_path / "scene.hprt")
+    model.save(baked)
+    oracle = orc.OracleScene(baked)
+    oracle.set_film(xres=W, yres=H, spp=spp)
+    rng = np.random.default_rng(2026)
+    n = 40000
+    px = rng.integers(0, W, n).astype(np.int32); py = rng.integers(0, H, n).astype(np.int32)
+    s = rng.integers(0, spp, n).astype(np.int64)
+    L0 = oracle.sample_radiance(px, py, s)
+    L1 = scene.sample_radiance(px, py, s, opt)
+    bad = (L0.view(np.uint32) != L1.view(np.uint32)).any(axis=1)
+    assert not bad.any(), "%d of %d samples differ, max |d| %g" % (int(bad.sum()), n, float(np.abs(L0 - L1).max()))
+    assert (L0.sum(axis=1) > 0).mean() > 0.5      # lit samples, not a black frame
+
+    # (2) the complete frame
+    film_a, st_a = scene.render(opt, count_work=True)                       # automatic batching
+    film_b, st_b = scene.render(opt, count_work=True, spp_chunk=chunk)
+    assert st_a["camera_rays"] == W * H * spp
+    assert [st_b[k] for k in KEYS] == [st_a[k] for k in KEYS]
+    assert np.array_equal(film_a.view(np.uint32), film_b.view(np.uint32))
+    film_p, st_p = scene.render(opt)                                         # the plain render bench.py times
+    assert np.array_equal(film_p.view(np.uint32), film_a.view(np.uint32)) and st_p["rays"] <= st_a["rays"]
+    w = film_a[..., 3]
+    assert np.isfinite(film_a).all() and (np.abs(w - spp) <= 3).all() and (w == spp).mean() > 0.85, (float(w.min()), float(w.max()), float((w == spp).mean()))
+    merged = np.zeros_like(film_a)
+    records = []
+    for r in range(2):
+        part, _ = scene.render(opt, tile_begin=r, tile_stride=2, export_foreign=True)
+        merged += part
+        records.append(scene.film_records())
+    assert sum(len(r) for r in records) > 0
+    hprt.film_records_merge(merged, np.concatenate(records[::-1]))            # any order of arrival: the merge sorts by (pixel, tile)
+    assert np.array_equal(merged.view(np.uint32), film_a.view(np.uint32))
