@@ -1,5 +1,5 @@
 """The bench workloads at the sizes bench.py runs them (BASELINE.json configs[2] and the conference-room class of
-configs[3]), on the GPU.  A full frame of either is minutes of oracle time, so each is held to
+configs[3]) and the 10-million-triangle instanced scene of configs[4], on the GPU.  A full frame of either is minutes of oracle time, so each is held to
 
   (1) per-sample parity: the radiance of 40,000 random (pixel, sample) pairs of the full-size sample sequence equals the
       oracle's bit for bit (hprt_sample_radiance runs the same kernels as hprt_render on those paths), and
@@ -29,16 +29,28 @@ def bench_module():
     return bench
 
 
-@pytest.mark.parametrize("name,chunk", [("atrium", 300), ("living-room", 100)])
+@pytest.mark.parametrize("name,chunk", [("atrium", 300), ("living-room", 100), ("instanced-10m", 24)])
 def test_bench_workload_at_full_size(hprt, orc, tmp_path, bench_module, name, chunk):
-    spp = bench_module.WORKLOADS[name][1]
-    model = bench_module.build_model(hprt, name)
+    if name == "instanced-10m":
+        # configs[4]'s shape of scene on one GPU: 10,323,970 instanced triangles (a 10,082-triangle patch x 1,024 transforms)
+        # + floor + sphere emitter, two-level BVH; 64 of its 4,096 spp (the sample sequence is the same, only shorter)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import scene_gen
+        text, ntri = scene_gen.instanced(xres=700, yres=700, spp=64)
+        assert ntri > 10 ** 7
+        path = tmp_path / "instanced.pbrt"
+        path.write_text(text)
+        model = hprt.Model.parse(str(path))
+        spp = 64
+    else:
+        spp = bench_module.WORKLOADS[name][1]
+        model = bench_module.build_model(hprt, name)
     bvh = hprt.Bvh(model)
     scene = hprt.Scene(model, bvh)
     opt = model.options.copy()
     opt.spp = spp
     W, H = opt.xres, opt.yres
-    assert (W, H, spp) == {"atrium": (700, 700, 1024), "living-room": (1280, 720, 256)}[name]
+    assert (W, H, spp) == {"atrium": (700, 700, 1024), "living-room": (1280, 720, 256), "instanced-10m": (700, 700, 64)}[name]
 
     # (1) per-sample parity against the oracle on the full-size sample sequence
     baked = str(tmp_path / "scene.hprt")
