@@ -481,7 +481,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     // ---- child-pair layout of the BVHs (device/dev_scene.h): one run of pairs per aggregate ----
     std::vector<DevPair> pairs((size_t)pairBase[aggs.size()]);
     // The ordered walk keeps at most one pending sibling per level, plus the sentinel of an instance: the kernel's
-    // stack has HPRT_LDS_STACK + HPRT_SPILL_STACK = 64 entries, as the reference's nodesToVisit[64]
+    // stack has HPRT_STACK_TOTAL = 64 entries (LDS + HBM part), as the reference's nodesToVisit[64]
     // (accelerators/bvh.cpp:365).  Deeper trees are refused here rather than walked wrongly.
     int topDepth = 0, objectDepth = 0;
     for (size_t ai = 0; ai < aggs.size(); ++ai) {
@@ -525,7 +525,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
             fill(pairs[(size_t)ref[i]], c[0], c[1], nd[i].countAxis & 3u);
         }
     }
-    if (topDepth + (d->n_instances ? 1 + objectDepth : 0) > HPRT_LDS_STACK + HPRT_SPILL_STACK)
+    if (topDepth + (d->n_instances ? 1 + objectDepth : 0) > HPRT_STACK_TOTAL)
         return SetError(HPRT_E_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack (accelerators/bvh.cpp:365 reserves the same)");
     std::vector<DevInstance> instances(d->n_instances);
     for (uint32_t i = 0; i < d->n_instances; ++i) {

@@ -203,9 +203,15 @@ __device__ __noinline__ bool sphere_test(const DevSphere &s, const DRay &r, DRay
 // accelerators/bvh.cpp:362).  Only children whose slabs are hit are pushed, so the depth in
 // use stays well below the tree depth.
 #define HPRT_LDS_STACK 16
-#define HPRT_SPILL_STACK 48
-// threads of the largest trace grid (256 CUs x 5 workgroups x 256 threads): stride of the deep-stack area, DevScene::deepStack
-#define HPRT_DEEP_THREADS 327680u
+// the plain any-hit kernel of triangle-only scenes needs 66 registers: with a 10-entry LDS stack (20 KB per workgroup) seven
+// workgroups fit a CU instead of five
+#ifndef HPRT_LDS_STACK_ANY
+#define HPRT_LDS_STACK_ANY 10
+#endif
+#define HPRT_STACK_TOTAL 64
+#define HPRT_SPILL_STACK (HPRT_STACK_TOTAL - HPRT_LDS_STACK_ANY)      // deepest HBM part any kernel can need
+// threads of the largest trace grid (256 CUs x 7 workgroups x 256 threads): stride of the deep-stack area, DevScene::deepStack
+#define HPRT_DEEP_THREADS 458752u
 #ifndef HPRT_TRACE_BLOCK
 #define HPRT_TRACE_BLOCK 256
 #endif

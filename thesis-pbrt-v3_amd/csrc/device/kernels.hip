@@ -24,6 +24,15 @@
 #include <string>
 #include "dev_shading.h"
 #include "kernels.h"
+#ifndef HPRT_ANY_WAVES
+#define HPRT_ANY_WAVES 7
+#endif
+#ifndef HPRT_CLOSEST_WAVES
+#define HPRT_CLOSEST_WAVES 6
+#endif
+#ifndef HPRT_LDS_STACK_CLOSEST
+#define HPRT_LDS_STACK_CLOSEST 12
+#endif
 
 namespace hprt {
 
@@ -199,7 +208,7 @@ __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31
 // QUAD: the scene has quadrics (spheres).  Their interval-arithmetic test is a call of 99 VGPRs that every value the walk
 // keeps must sit above; triangle-only scenes (the Sponza-class and living-room workloads) get the kernel without it.
 template <bool ANY_HIT, int MODE, bool INST, bool QUAD>
-__global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
+__global__ __launch_bounds__(HPRT_TRACE_BLOCK, (MODE == 0 && !INST && !QUAD) ? (ANY_HIT ? HPRT_ANY_WAVES : HPRT_CLOSEST_WAVES) : 1024 / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ,
                                                             DevCounters *counters, uint4 *rayStats, uint32_t *workCounter, uint32_t chunk,
                                                             TraceTune tune) {
@@ -215,7 +224,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
     unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned int pfPush = 0u, pfSpill = 0u;      // PROF: stack pushes, and those beyond the LDS entries (scratch)
     const unsigned long long pfStart = PROF ? clock64() : 0ull;
-    __shared__ uint2 stackMem[HPRT_LDS_STACK * HPRT_TRACE_BLOCK];     // [entry][thread]: {ref, tMin}
+    constexpr int LDS_N = (MODE == 0 && !INST && !QUAD) ? (ANY_HIT ? HPRT_LDS_STACK_ANY : HPRT_LDS_STACK_CLOSEST) : HPRT_LDS_STACK;
+    __shared__ uint2 stackMem[LDS_N * HPRT_TRACE_BLOCK];     // [entry][thread]: {ref, tMin}
     uint2 *const ldsStack = &stackMem[threadIdx.x];
     // INST: the world-space ray stays in LDS ([component][thread]) while the lane walks an instance with the transformed one
     __shared__ float worldRayMem[INST ? 6 * HPRT_TRACE_BLOCK : 1];
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
     // (volatile: keeps hipcc from folding the LDS and the HBM access into one access through a generic pointer)
     // (the address is formed where it is used: the pointer would otherwise hold two registers for the whole walk)
     auto deepSlot = [&](int entry) -> volatile unsigned long long * {
-        return (volatile unsigned long long *)sc.deepStack + (size_t)(entry - HPRT_LDS_STACK) * HPRT_DEEP_THREADS + (blockIdx.x * HPRT_TRACE_BLOCK + threadIdx.x);
+        return (volatile unsigned long long *)sc.deepStack + (size_t)(entry - LDS_N) * HPRT_DEEP_THREADS + (blockIdx.x * HPRT_TRACE_BLOCK + threadIdx.x);
     };
     bool moreWork = n > 0 && sc.nPairs > 0;
 
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
         while (sp > 0) {
             --sp;
             uint2 e;
-            if (sp < HPRT_LDS_STACK) e = ldsStack[sp * HPRT_TRACE_BLOCK]; else { const unsigned long long w = *deepSlot(sp); e = make_uint2((uint32_t)w, (uint32_t)(w >> 32)); }
+            if (sp < LDS_N) e = ldsStack[sp * HPRT_TRACE_BLOCK]; else { const unsigned long long w = *deepSlot(sp); e = make_uint2((uint32_t)w, (uint32_t)(w >> 32)); }
             if (INST && (int)e.x == REF_EXIT) { savedTMax = __uint_as_float(e.y); return REF_EXIT; }     // the instance's walk is over
             if (COUNT) ++cnt.fetched;
             // (an any-hit ray's tMax never shrinks: what was pushed with tMin < tMax still passes)
@@ -395,9 +405,9 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                         cur = refN;
                         if (COUNT ? !single : (slabF && tF < rayTMax)) {
                             const uint2 e = make_uint2((uint32_t)refF, __float_as_uint(slabF ? tF : HPRT_INF));
-                            if (PROF) { ++pfPush; if (sp >= HPRT_LDS_STACK) ++pfSpill; }
-                            if (sp < HPRT_LDS_STACK) { ldsStack[sp * HPRT_TRACE_BLOCK] = e; ++sp; }
-                            else if (sp < HPRT_LDS_STACK + HPRT_SPILL_STACK) { *deepSlot(sp) = (unsigned long long)e.x | ((unsigned long long)e.y << 32); ++sp; }
+                            if (PROF) { ++pfPush; if (sp >= LDS_N) ++pfSpill; }
+                            if (sp < LDS_N) { ldsStack[sp * HPRT_TRACE_BLOCK] = e; ++sp; }
+                            else if (sp < HPRT_STACK_TOTAL) { *deepSlot(sp) = (unsigned long long)e.x | ((unsigned long long)e.y << 32); ++sp; }
                         }
                     } else {
                         const bool hitF = slabF && tF < rayTMax;
@@ -478,8 +488,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, 1024 / HPRT_TRACE_BLOCK) void k_t
                                 tm -= dt;
                             }
                             const uint2 e = make_uint2((uint32_t)REF_EXIT, __float_as_uint(rayTMax));
-                            if (sp < HPRT_LDS_STACK) ldsStack[sp * HPRT_TRACE_BLOCK] = e;
-                            else if (sp < HPRT_LDS_STACK + HPRT_SPILL_STACK) *deepSlot(sp) = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
+                            if (sp < LDS_N) ldsStack[sp * HPRT_TRACE_BLOCK] = e;
+                            else if (sp < HPRT_STACK_TOTAL) *deepSlot(sp) = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
                             ++sp;       // a full stack cannot take the sentinel: such depths are outside what the reference supports either (64 entries)
                             ro = o2; rayTMax = tm;
                             invDir = vec3(1 / d2.x, 1 / d2.y, 1 / d2.z);
@@ -1200,7 +1210,13 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     // persistent waves: enough blocks to fill 256 CUs at this kernel's occupancy, never more than the rays need
     // (HPRT_TRACE_MAX_BLOCKS: test hook — a handful of waves working through many queue chunks each, tests/test_gpu_parity.py)
     static const uint32_t blockCap = [] { const char *e = getenv("HPRT_TRACE_MAX_BLOCKS"); return e ? (uint32_t)std::max(1, atoi(e)) : 0xffffffffu; }();
-    const uint32_t maxBlocks = std::min(HPRT_DEEP_THREADS / HPRT_TRACE_BLOCK, blockCap);      // 256 CUs x 5 workgroups of 256 threads
+    // workgroups per CU: five (LDS stack 32 KB, or four by registers in the kernels with the quadric code); seven for the plain
+    // any-hit kernel of triangle-only scenes (66 registers, 20 KB)
+    static const uint32_t anyPerCu = [] { const char *e = getenv("HPRT_TRACE_ANY_PER_CU"); return e ? (uint32_t)std::min(8, std::max(1, atoi(e))) : (uint32_t)HPRT_ANY_WAVES; }();
+    const bool slimAny = anyHit && !count && sc.nInstances == 0u && sc.nSpheres == 0u && getenv("HPRT_TRACE_PROFILE") == nullptr;
+    static const uint32_t closestPerCu = [] { const char *e = getenv("HPRT_TRACE_CLOSEST_PER_CU"); return e ? (uint32_t)std::min(7, std::max(1, atoi(e))) : (uint32_t)HPRT_CLOSEST_WAVES; }();
+    const bool slimClosest = !anyHit && !count && sc.nInstances == 0u && sc.nSpheres == 0u && getenv("HPRT_TRACE_PROFILE") == nullptr;
+    const uint32_t maxBlocks = std::min(256u * (slimAny ? anyPerCu : slimClosest ? closestPerCu : 5u), blockCap);
     dim3 grid(std::min(blocks_for(gridItems, HPRT_TRACE_BLOCK), maxBlocks)), block(HPRT_TRACE_BLOCK);
     // rays per queue-head atomic: large launches take 512 at a time, small ones keep every wave busy
     const uint32_t nWaves = grid.x * (HPRT_TRACE_BLOCK / 64);
