@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhprt.so")
+LIB_PATH = os.environ.get("HPRT_LIB") or os.path.join(_HERE, "lib", "libhprt.so")      # HPRT_LIB: another build of the same library (tools/build_variant.sh, A/B measurements)
 
 
 class HprtError(RuntimeError):
