@@ -50,11 +50,11 @@ COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")
 WORKLOADS = {
     # name: (description, how to build the model, spp, cpu sample spp, data label)
     "atrium": ("Sponza-class atrium STAND-IN (311,728 tris, matte+plastic, point light; the reference ships no Sponza geometry) 700x700, "
-               "halton %d spp, path maxdepth 5, bvh", 1024, 32, "synthetic (procedural stand-in geometry, tools/scene_gen.py)"),
-    "killeroo-simple": ("killeroo-simple (66,532 tris + sphere area light) 700x700, halton %d spp, path maxdepth 5, bvh", 256, 64,
+               "halton %d spp, path maxdepth 5, bvh", 1024, 64, "synthetic (procedural stand-in geometry, tools/scene_gen.py)"),
+    "killeroo-simple": ("killeroo-simple (66,532 tris + sphere area light) 700x700, halton %d spp, path maxdepth 5, bvh", 256, 128,
                         "reference asset scenes/killeroo-simple, baked (tests/golden/killeroo_simple.hprt)"),
     "living-room": ("living room (143,163 tris of the reference's scenes/living-room meshes with its matte / OrenNayar / substrate / metal / mirror / glass materials; uber as matte, textures as constants, point light for its missing sky map) "
-                    "1280x720, halton %d spp, path maxdepth 5, bvh", 256, 16, "reference meshes, baked (tests/golden/living_room.hprt)"),
+                    "1280x720, halton %d spp, path maxdepth 5, bvh", 256, 32, "reference meshes, baked (tests/golden/living_room.hprt)"),
 }
 
 
