@@ -86,16 +86,24 @@ __device__ __forceinline__ efloat ef(float v, float err) {
     if (err == 0.f) { r.lo = v; r.hi = v; } else { r.lo = next_down(v - err); r.hi = next_up(v + err); }
     return r;
 }
-__device__ __forceinline__ efloat ef_add(efloat a, efloat b) { efloat r; r.v = a.v + b.v; r.lo = next_down(a.lo + b.lo); r.hi = next_up(a.hi + b.hi); return r; }
-__device__ __forceinline__ efloat ef_sub(efloat a, efloat b) { efloat r; r.v = a.v - b.v; r.lo = next_down(a.lo - b.hi); r.hi = next_up(a.hi - b.lo); return r; }
-__device__ __forceinline__ efloat ef_mul(efloat a, efloat b) {
+// The interval operations are calls of their own: sphere_test then needs 56 registers instead of 99, and its callers (a caller
+// keeps its live values above its callee's registers) fit five waves per SIMD where that pays (kernels.hip).  The test itself is
+// slower that way, but it runs for few rays: the pre-test below settles most.  (HPRT_EF_INLINE: the inlined form, for A/B builds.)
+#ifdef HPRT_EF_INLINE
+#define HPRT_EF_FN __device__ __forceinline__
+#else
+#define HPRT_EF_FN __device__ __noinline__
+#endif
+HPRT_EF_FN efloat ef_add(efloat a, efloat b) { efloat r; r.v = a.v + b.v; r.lo = next_down(a.lo + b.lo); r.hi = next_up(a.hi + b.hi); return r; }
+HPRT_EF_FN efloat ef_sub(efloat a, efloat b) { efloat r; r.v = a.v - b.v; r.lo = next_down(a.lo - b.hi); r.hi = next_up(a.hi - b.lo); return r; }
+HPRT_EF_FN efloat ef_mul(efloat a, efloat b) {
     efloat r; r.v = a.v * b.v;
     float p0 = a.lo * b.lo, p1 = a.hi * b.lo, p2 = a.lo * b.hi, p3 = a.hi * b.hi;
     r.lo = next_down(sel_min(sel_min(p0, p1), sel_min(p2, p3)));
     r.hi = next_up(sel_max(sel_max(p0, p1), sel_max(p2, p3)));
     return r;
 }
-__device__ __forceinline__ efloat ef_div(efloat a, efloat b) {
+HPRT_EF_FN efloat ef_div(efloat a, efloat b) {
     efloat r; r.v = a.v / b.v;
     if (b.lo < 0 && b.hi > 0) { r.lo = -HPRT_INF; r.hi = HPRT_INF; }
     else {

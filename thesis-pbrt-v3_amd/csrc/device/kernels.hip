@@ -24,6 +24,13 @@
 #include <string>
 #include "dev_shading.h"
 #include "kernels.h"
+#ifndef HPRT_QUAD_ANY_WAVES
+#define HPRT_QUAD_ANY_WAVES 5
+#endif
+#define HPRT_QUAD_CLOSEST_WAVES 4
+#ifndef HPRT_LDS_STACK_QUAD_ANY
+#define HPRT_LDS_STACK_QUAD_ANY 12
+#endif
 #ifndef HPRT_ANY_WAVES
 #define HPRT_ANY_WAVES 7
 #endif
@@ -208,11 +215,12 @@ __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31
 // QUAD: the scene has quadrics (spheres).  Their interval-arithmetic test is a call of 99 VGPRs that every value the walk
 // keeps must sit above; triangle-only scenes (the Sponza-class and living-room workloads) get the kernel without it.
 template <bool ANY_HIT, int MODE, bool INST, bool QUAD>
-__global__ __launch_bounds__(HPRT_TRACE_BLOCK, (MODE == 0 && !INST && !QUAD) ? (ANY_HIT ? HPRT_ANY_WAVES : HPRT_CLOSEST_WAVES) : 1024 / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
+__global__ __launch_bounds__(HPRT_TRACE_BLOCK, (MODE == 0 && !INST) ? (QUAD ? (ANY_HIT ? HPRT_QUAD_ANY_WAVES : HPRT_QUAD_CLOSEST_WAVES) : ANY_HIT ? HPRT_ANY_WAVES : HPRT_CLOSEST_WAVES) : 1024 / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ,
                                                             DevCounters *counters, uint4 *rayStats, uint32_t *workCounter, uint32_t chunk,
                                                             TraceTune tune) {
     constexpr bool COUNT = MODE == 1, PROF = MODE == 2;
+    constexpr bool PACKED = !QUAD;      // both children's slab test as packed two-float operations (the kernels with the quadric code keep the scalar form: no gain there)
     // An any-hit ray's answer does not depend on the order of the walk (its tMax never shrinks, every primitive test is
     // independent of the others), so the plain any-hit kernel visits children in storage order and skips the re-test of
     // popped entries: 8-11 % more rays per second than the reference's front-to-back order (bvh.cpp:381-388), which the
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, (MODE == 0 && !INST && !QUAD) ? (
     unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned int pfPush = 0u, pfSpill = 0u;      // PROF: stack pushes, and those beyond the LDS entries (scratch)
     const unsigned long long pfStart = PROF ? clock64() : 0ull;
-    constexpr int LDS_N = (MODE == 0 && !INST && !QUAD) ? (ANY_HIT ? HPRT_LDS_STACK_ANY : HPRT_LDS_STACK_CLOSEST) : HPRT_LDS_STACK;
+    constexpr int LDS_N = (MODE == 0 && !INST) ? (QUAD ? (ANY_HIT ? HPRT_LDS_STACK_QUAD_ANY : HPRT_LDS_STACK) : ANY_HIT ? HPRT_LDS_STACK_ANY : HPRT_LDS_STACK_CLOSEST) : HPRT_LDS_STACK;
     __shared__ uint2 stackMem[LDS_N * HPRT_TRACE_BLOCK];     // [entry][thread]: {ref, tMin}
     uint2 *const ldsStack = &stackMem[threadIdx.x];
     // INST: the world-space ray stays in LDS ([component][thread]) while the lane walks an instance with the transformed one
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, (MODE == 0 && !INST && !QUAD) ? (
                         rayTMax = ra.w;
                         invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
                                                 ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
-                        if (!QUAD) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
+                        if (PACKED) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
                         shear = ray_shear(rd);
                         sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
                         wait = 0u; inst = -1; hitInst = -1; instHit = false;
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, (MODE == 0 && !INST && !QUAD) ? (
                     // dirIsNeg picks, per axis, the bounds that give tMin ("near") and tMax ("far"), as {child 0, child 1}
                     float t0, t1;
                     bool s0, s1;
-                    if (QUAD) {
+                    if (!PACKED) {
                         s0 = slab_test(__uint_as_float(q0.x), __uint_as_float(q0.z), __uint_as_float(q1.x), __uint_as_float(q1.z),
                                        __uint_as_float(q2.x), __uint_as_float(q2.z), ro, invDir, ngX, ngY, ngZ, robust, &t0);
                         s1 = slab_test(__uint_as_float(q0.y), __uint_as_float(q0.w), __uint_as_float(q1.y), __uint_as_float(q1.w),
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, (MODE == 0 && !INST && !QUAD) ? (
                     const uint32_t axis = meta & 3u;
                     const bool single = (meta & PAIR_SINGLE) != 0u;
                     // second child first when the ray is negative along the split axis (bvh.cpp:381-388)
-                    const bool isNeg = FREE_ORDER ? false : QUAD ? (axis == 0 ? ngX : (axis == 1 ? ngY : ngZ)) : ((negMask >> axis) & 1u) != 0u;
+                    const bool isNeg = FREE_ORDER ? false : !PACKED ? (axis == 0 ? ngX : (axis == 1 ? ngY : ngZ)) : ((negMask >> axis) & 1u) != 0u;
                     const int refN = (int)(isNeg ? q3.y : q3.x), refF = (int)(isNeg ? q3.x : q3.y);
                     const float tN = isNeg ? t1 : t0, tF = isNeg ? t0 : t1;
                     const bool hitN = (isNeg ? s1 : s0) && tN < rayTMax;
@@ -440,7 +448,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, (MODE == 0 && !INST && !QUAD) ? (
                         const vec3 rd(worldRay[3 * HPRT_TRACE_BLOCK], worldRay[4 * HPRT_TRACE_BLOCK], worldRay[5 * HPRT_TRACE_BLOCK]);
                         invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
                                                 ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
-                        if (!QUAD) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
+                        if (PACKED) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
                         shear = ray_shear(rd);
                         rayTMax = worldT;
                         inst = -1; instHit = false;
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, (MODE == 0 && !INST && !QUAD) ? (
                             ro = o2; rayTMax = tm;
                             invDir = vec3(1 / d2.x, 1 / d2.y, 1 / d2.z);
                                                     ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
-                        if (!QUAD) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
+                        if (PACKED) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
                             shear = ray_shear(d2);
                             cur = in.root;
                         } else if (QUAD) {
@@ -1216,7 +1224,8 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     const bool slimAny = anyHit && !count && sc.nInstances == 0u && sc.nSpheres == 0u && getenv("HPRT_TRACE_PROFILE") == nullptr;
     static const uint32_t closestPerCu = [] { const char *e = getenv("HPRT_TRACE_CLOSEST_PER_CU"); return e ? (uint32_t)std::min(7, std::max(1, atoi(e))) : (uint32_t)HPRT_CLOSEST_WAVES; }();
     const bool slimClosest = !anyHit && !count && sc.nInstances == 0u && sc.nSpheres == 0u && getenv("HPRT_TRACE_PROFILE") == nullptr;
-    const uint32_t maxBlocks = std::min(256u * (slimAny ? anyPerCu : slimClosest ? closestPerCu : 5u), blockCap);
+    const bool plainQuadAny = anyHit && !count && sc.nInstances == 0u && sc.nSpheres != 0u && getenv("HPRT_TRACE_PROFILE") == nullptr;
+    const uint32_t maxBlocks = std::min(256u * (slimAny ? anyPerCu : slimClosest ? closestPerCu : plainQuadAny ? (uint32_t)HPRT_QUAD_ANY_WAVES : 5u), blockCap);
     dim3 grid(std::min(blocks_for(gridItems, HPRT_TRACE_BLOCK), maxBlocks)), block(HPRT_TRACE_BLOCK);
     // rays per queue-head atomic: large launches take 512 at a time, small ones keep every wave busy
     const uint32_t nWaves = grid.x * (HPRT_TRACE_BLOCK / 64);
