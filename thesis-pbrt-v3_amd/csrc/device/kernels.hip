@@ -209,6 +209,13 @@ __device__ __forceinline__ void slab_test_pair(f32x2 nx, f32x2 fx, f32x2 ny, f32
 // batches [5] pair iterations [6] pair lanes [7] primitive iterations [8] primitive lanes
 // [9] refills [10] refilled lanes [11] quadric batches [12] quadric lanes [13] waves [14] stack pushes [15] pushes beyond the LDS entries.
 __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31] any hit
+// HPRT_SHADE_PROF (variant builds only, tools/build_variant.sh): wave clocks between program points of k_shade, per MODE
+#ifdef HPRT_SHADE_PROF
+__device__ unsigned long long g_shadeProf[3 * 8];
+#define SP_MARK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); spT[k] += t_ - spLast; spLast = t_; } while (0)
+#else
+#define SP_MARK(k) do { } while (0)
+#endif
 
 // MODE 0: plain; 1: work counters (HprtRenderStats); 2: phase profile (diagnostics only).
 // INST: the scene has object instances (two-level walk); without them that code and its registers are compiled out.
@@ -709,6 +716,10 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
     if (blockIdx.x * blockDim.x >= n) return;      // whole block beyond the bin (grids are sized for the upper bound)
     halton_lds_load(sc, &hl);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+#ifdef HPRT_SHADE_PROF
+    unsigned long long spT[8] = {0, 0, 0, 0, 0, 0, 0, 0}, spLast = clock64();
+    bool spFull = false;
+#endif
     bool wantNext = false, wantShadow = false, wantMis = false, wantResolve = false, defer = false;
     uint32_t slot = 0;          // index in the input streams
     uint32_t j = 0;             // index in the output streams
@@ -720,6 +731,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
         // a fresh path's throughput and radiance are constants (k_generate does not store them)
         const float4 beta4 = firstBounce ? make_float4(1.f, 1.f, 1.f, __uint_as_float(slot)) : in.beta[slot];
         const float4 L4 = firstBounce ? make_float4(0.f, 0.f, 0.f, 1.f) : in.L[slot];
+        SP_MARK(6);      // queue entry + path streams
         const uint32_t st = __float_as_uint(rayB.w);
         int dim = (int)(st & 0xffffu);
         const int bounces = (int)((st >> 16) & 0x7fffu);
@@ -787,7 +799,11 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                 }
             }
         }
+        SP_MARK(0);      // loads + surface interaction
         if (found && bounces < rp.maxDepth) {
+#ifdef HPRT_SHADE_PROF
+            spFull = true;
+#endif
             DevBsdf bsdf;
             bool useKd = false, useKs = false;
             rgb kdTex, ksTex;
@@ -817,6 +833,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
             bsdf_init(sc, si, &bsdf, useKd ? &kdTex : nullptr, useKs ? &ksTex : nullptr);
             if (MODE == 0) { bsdf.hasS = false; bsdf.Rs = rgb(0.f); bsdf.alpha = 0.f; }   // matte: no microfacet lobe (matte.cpp:45-62)
             if (MODE != 2) { bsdf.hasR = false; bsdf.oren = false; bsdf.kind = 0; }      // mirror, substrate, metal and OrenNayar surfaces are shaded by the generic variant
+            SP_MARK(1);      // textures + bsdf_init
             // ---- direct lighting (UniformSampleOneLight + EstimateDirect) ----
             if (bsdf_num(bsdf) > 0 && sc.nLights > 0) {
                 // The reference draws five sample values here (light pick, uLight, uScattering: core/integrator.cpp:96-104); a value
@@ -844,6 +861,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                     // material-specialised variants hand such a vertex to the generic variant.
                     // (likewise a vertex lit by a triangle emitter: Triangle::Sample / Shape::Pdf live in the generic variant only)
                     if (MODE != 2 && !isDelta && (light.type == 3 || sphere_ref_inside(sc.spheres[light.sphere], it))) defer = true;
+                    SP_MARK(2);      // light pick + the four sample values
                     if (!defer) {
                     rgb Li = light_sample<MODE == 2>(sc, light, it, ul0, ul1, &wi, &lightPdf, &pl);
                     rgb pendLight(0.f), pendMis(0.f);
@@ -862,6 +880,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                             wantShadow = true;
                         }
                     }
+                    SP_MARK(3);      // light sample + f + pdf + shadow ray
                     if (!isDelta) {
                         int sampledType = 0;
                         rgb f = bsdf_sample(bsdf, si.wo, &wi, us0, us1, &scatteringPdf, &sampledType);
@@ -903,6 +922,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                     }
                 }
             }
+            SP_MARK(4);      // BSDF-sampled light term + pending stores
             // ---- sample the BSDF for the next path segment (path.cpp:141-164) ----
             if (!defer) {
             const float ub0 = halton_dim(sc, rp.hal, index, dim, &hl), ub1 = halton_dim(sc, rp.hal, index, dim + 1, &hl);
@@ -949,6 +969,16 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
             else Lfinal[pathId] = make_float4(L.r, L.g, L.b, 0.f);
         }
     }
+    SP_MARK(5);      // next segment: sample values, bsdf_sample, roulette, stream stores
+#ifdef HPRT_SHADE_PROF
+    {
+        const unsigned long long m = __ballot(spFull);
+        if (m != 0ull && __lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) {
+            for (int k = 0; k < 7; ++k) atomicAdd(&g_shadeProf[MODE * 8 + k], spT[k]);
+            atomicAdd(&g_shadeProf[MODE * 8 + 7], 1ull);
+        }
+    }
+#endif
     // queue appends in block-uniform control flow
     if (MODE != 2) {   // (almost) never
         const uint32_t p2 = wave_append(bins.count + 2 * BIN_STRIDE, defer);
@@ -1253,6 +1283,11 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
 #undef HPRT_TRACE_PICK
 #undef HPRT_TRACE_LAUNCH
 }
+#ifdef HPRT_SHADE_PROF
+extern "C" __attribute__((visibility("default"))) int hprt_debug_shade_profile(unsigned long long out[24]) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_shadeProf), sizeof(unsigned long long) * 24) == hipSuccess ? 0 : -1;
+}
+#endif
 // diagnostics hook (not part of include/hprt.h): read and optionally clear the phase profile
 extern "C" __attribute__((visibility("default"))) int hprt_debug_trace_profile(unsigned long long out[32], int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_traceProf), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
