@@ -16,7 +16,9 @@ hprt_film_gather: one RCCL reduce over xGMI plus the ordered merge of the cross-
 
 `python bench.py --gpus N` without WORLD_SIZE in the environment starts N fresh rank processes itself (before this
 process touches the GPU) and relays rank 0's line; under torch.distributed.run it reads RANK/LOCAL_RANK/WORLD_SIZE.
-`n_gpus` is the size the RCCL communicator reports, never the flag (a --rehearse-on-one-gpu run says 1, with `world_size` ranks).
+`n_gpus` is the size the RCCL communicator reports, never the flag (a --rehearse-on-one-gpu run says 1, with `world_size` ranks;
+if the library's communicator cannot be created the films are merged through torch.distributed's RCCL group instead, `n_gpus` is
+the number of distinct devices the ranks sit on, and `config.film_merge` says what happened).
 
 Rays = closest-hit + shadow rays, as the reference counts them (core/scene.cpp:40-55), TRACED rays only.
 
@@ -171,17 +173,34 @@ def main():
 
     # ---- the film gather's communicator: RCCL through the C ABI (hprt_comm_*); the id travels over torch.distributed ----
     comm, transport, rccl_ranks = None, "none (single GPU)", None
+    n_gpus = 1
     if world > 1 and not args.rehearse_on_one_gpu:
-        idt = torch.zeros(hprt.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(hprt.Comm.unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, src=0)
-        comm = hprt.Comm(bytes(idt.cpu().numpy().tobytes()), rank, world, device=dev.index)
-        info = comm.info()
-        rccl_ranks, transport = info["n_ranks"], "RCCL (hprt_film_gather: ncclReduce + grouped send/recv)"
+        err = ""
+        try:
+            idt = torch.zeros(hprt.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(hprt.Comm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            comm = hprt.Comm(bytes(idt.cpu().numpy().tobytes()), rank, world, device=dev.index)
+            rccl_ranks = comm.info()["n_ranks"]
+        except Exception as e:      # e.g. the library's own communicator cannot be set up in this environment
+            comm, rccl_ranks, err = None, None, "%s: %s" % (type(e).__name__, e)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            n_gpus, transport = rccl_ranks, "RCCL (hprt_film_gather: ncclReduce + grouped send/recv)"
+        else:
+            # Every rank still owns a GPU and torch.distributed's own RCCL group works (the all_reduce above ran on it): merge
+            # the films through it (tiles.gather_film: reduce + ordered record merge on the root) and say so in the line.
+            comm, rccl_ranks = None, None
+            devs = [None] * world
+            dist.all_gather_object(devs, int(dev.index))
+            n_gpus = len(set(devs))
+            transport = "torch.distributed RCCL group (tiles.gather_film) — hprt_comm_create failed: " + (err or "on another rank")
+            if rank == 0:
+                sys.stderr.write("bench.py: " + transport + "\n")
     elif world > 1:
-        transport = "gloo rehearsal on one GPU (tiles.gather_film)"
-    n_gpus = rccl_ranks if rccl_ranks is not None else 1   # a rehearsal is world ranks on ONE card
+        transport = "gloo rehearsal on one GPU (tiles.gather_film)"      # world ranks on ONE card: n_gpus stays 1
 
     def merge(w):
         """Film::MergeFilmTile across ranks; part of the timed step."""
