@@ -273,6 +273,7 @@ int orc_selftest_scrambled_radical_inverse() { return SelfTestScrambledRadicalIn
 int orc_selftest_sphere_reintersect(int nSpheres, int nRays, int *nTested) { return SelfTestSphereReintersect(nSpheres, nRays, nTested); }
 int orc_selftest_next_float() { return SelfTestNextFloat(); }
 int orc_selftest_efloat(int iters) { return SelfTestEFloat(iters); }
+int orc_selftest_bsdf_sampling(int which, double *minPval) { return SelfTestBSDFSampling(which, minPval); }
 int orc_selftest_distribution1d() { return SelfTestDistribution1D(); }
 // inputs of the reference's property tests for the batched device queries (tests/test_gpu_reference_unit_tests.py)
 void orc_watertight_case(int nIter, float *P, int *idx, float *o, float *d, float *tBrute) { WatertightCase(nIter, P, idx, o, d, tBrute); }

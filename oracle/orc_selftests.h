@@ -407,4 +407,155 @@ inline int SelfTestDistribution1D() {
     return failures;
 }
 
+
+// ---------------------------------------------------------------------------
+// BSDFSampling.* of src/tests/bsdfs.cpp: the chi-square test that a BxDF's Sample_f() draws directions with the density its
+// Pdf() reports — a 10 x 20 histogram over (theta, phi) of a million sampled directions against the density integrated over
+// each cell by nested adaptive Simpson quadrature, five random outgoing directions, significance 0.01 with the Sidak
+// correction.  Restated for the cases inside the path's scope (the visible-area Trowbridge-Reitz sampling the reference uses by
+// default): Lambertian (:484), TR_VA_0p5 (:492-496), TR_VA_0p3_0p15 (:516-520), TR_VA_0p3 = FresnelBlend (:540-544).  The
+// reference's microfacet cases use FresnelNoOp; the oracle's microfacet lobe carries plastic's dielectric Fresnel, which
+// changes f() only by a factor that is never zero, and the test reads f() only to skip zero samples (:190).
+// RNG: the reference's default-seeded PCG32 (`RNG rng;`, :372), so the directions and samples are the reference's.
+// ---------------------------------------------------------------------------
+namespace chi2 {
+// Regularized lower incomplete gamma function (:44-113, after Cephes)
+inline double RLGamma(double a, double x) {
+    const double epsilon = 0.000000000000001, big = 4503599627370496.0, bigInv = 2.22044604925031308085e-16;
+    if (a < 0 || x < 0) return 0.0;      // (the reference throws; never reached)
+    if (x == 0) return 0;
+    double ax = (a * std::log(x)) - x - std::lgamma(a);
+    if (ax < -709.78271289338399) return a < x ? 1.0 : 0.0;
+    if (x <= 1 || x <= a) {
+        double r2 = a, c2 = 1, ans2 = 1;
+        do { r2 = r2 + 1; c2 = c2 * x / r2; ans2 += c2; } while ((c2 / ans2) > epsilon);
+        return std::exp(ax) * ans2 / a;
+    }
+    int c = 0;
+    double y = 1 - a, z = x + y + 1, p3 = 1, q3 = x, p2 = x + 1, q2 = z * x, ans = p2 / q2, error;
+    do {
+        c++; y += 1; z += 2;
+        double yc = y * c, p = (p2 * z) - (p3 * yc), q = (q2 * z) - (q3 * yc);
+        if (q != 0) { double nextans = p / q; error = std::abs((ans - nextans) / nextans); ans = nextans; }
+        else error = 1;
+        p3 = p2; p2 = p; q3 = q2; q2 = q;
+        if (std::abs(p) > big) { p3 *= bigInv; p2 *= bigInv; q3 *= bigInv; q2 *= bigInv; }
+    } while (error > epsilon);
+    return 1.0 - (std::exp(ax) * ans);
+}
+inline double Chi2CDF(double x, int dof) {      // :116-124
+    if (dof < 1 || x < 0) return 0.0;
+    if (dof == 2) return 1.0 - std::exp(-0.5 * x);
+    return (Float)RLGamma(0.5 * dof, 0.5 * x);
+}
+template <typename F> Float SimpsonRec(const F &f, Float a, Float b, Float c, Float fa, Float fb, Float fc, Float I, Float eps, int depth) {   // :131-152
+    Float d = 0.5f * (a + b), e = 0.5f * (b + c), fd = f(d), fe = f(e);
+    Float h = c - a, I0 = (Float)(1.0 / 12.0) * h * (fa + 4 * fd + fb), I1 = (Float)(1.0 / 12.0) * h * (fb + 4 * fe + fc), Ip = I0 + I1;
+    if (depth <= 0 || std::abs(Ip - I) < 15 * eps) return Ip + (Float)(1.0 / 15.0) * (Ip - I);
+    return SimpsonRec(f, a, d, b, fa, fd, fb, I0, .5f * eps, depth - 1) + SimpsonRec(f, b, e, c, fb, fe, fc, I1, .5f * eps, depth - 1);
+}
+template <typename F> Float AdaptiveSimpson(const F &f, Float x0, Float x1, Float eps = 1e-6f, int depth = 6) {   // :127-159
+    Float a = x0, b = 0.5f * (x0 + x1), c = x1;
+    Float fa = f(a), fb = f(b), fc = f(c);
+    Float I = (c - a) * (Float)(1.0 / 6.0) * (fa + 4 * fb + fc);
+    return SimpsonRec(f, a, b, c, fa, fb, fc, I, eps, depth);
+}
+template <typename F> Float AdaptiveSimpson2D(const F &f, Float x0, Float y0, Float x1, Float y1, Float eps = 1e-6f, int depth = 6) {   // :162-173
+    auto integrate = [&](Float y) { return AdaptiveSimpson([&](Float x) { return f(x, y); }, x0, x1, eps, depth); };
+    return AdaptiveSimpson(integrate, y0, y1, eps, depth);
+}
+// :248-345
+inline bool Chi2Test(const Float *frequencies, const Float *expFrequencies, int thetaRes, int phiRes, int sampleCount, Float minExpFrequency,
+                     Float significanceLevel, int numTests, double *pvalOut) {
+    struct Cell { Float expFrequency; size_t index; };
+    std::vector<Cell> cells((size_t)thetaRes * phiRes);
+    for (size_t i = 0; i < cells.size(); ++i) { cells[i].expFrequency = expFrequencies[i]; cells[i].index = i; }
+    std::sort(cells.begin(), cells.end(), [](const Cell &a, const Cell &b) { return a.expFrequency < b.expFrequency; });
+    Float pooledFrequencies = 0, pooledExpFrequencies = 0, chsq = 0;
+    int pooledCells = 0, dof = 0;
+    for (const Cell &c : cells) {
+        if (expFrequencies[c.index] == 0) {
+            if (frequencies[c.index] > sampleCount * 1e-5f) { *pvalOut = -1; return false; }
+        } else if (expFrequencies[c.index] < minExpFrequency) {
+            pooledFrequencies += frequencies[c.index]; pooledExpFrequencies += expFrequencies[c.index]; pooledCells++;
+        } else if (pooledExpFrequencies > 0 && pooledExpFrequencies < minExpFrequency) {
+            pooledFrequencies += frequencies[c.index]; pooledExpFrequencies += expFrequencies[c.index]; pooledCells++;
+        } else {
+            Float diff = frequencies[c.index] - expFrequencies[c.index];
+            chsq += (diff * diff) / expFrequencies[c.index];
+            ++dof;
+        }
+    }
+    if (pooledExpFrequencies > 0 || pooledFrequencies > 0) {
+        Float diff = pooledFrequencies - pooledExpFrequencies;
+        chsq += (diff * diff) / pooledExpFrequencies;
+        ++dof;
+    }
+    (void)pooledCells;
+    dof -= 1;
+    if (dof <= 0) { *pvalOut = -2; return false; }
+    Float pval = 1 - (Float)Chi2CDF(chsq, dof);
+    Float alpha = 1.0f - std::pow(1.0f - significanceLevel, 1.0f / numTests);
+    *pvalOut = pval;
+    return !(pval < alpha || !std::isfinite(pval));
+}
+}  // namespace chi2
+
+// which: 0 Lambertian, 1 TR_VA_0p5, 2 TR_VA_0p3_0p15, 3 TR_VA_0p3 (FresnelBlend).  Returns the number of runs (of 5) whose null
+// hypothesis was rejected; minPval: the smallest p-value met.
+inline int SelfTestBSDFSampling(int which, double *minPval) {
+    const int thetaRes = 10, phiRes = 20, sampleCount = 1000000, runs = 5;      // CHI2_* (:20-41)
+    // the frame of the reference's disk hit (RotateX(-90) disk at y = 0 hit from above, :377-392): any orthonormal frame gives the
+    // same local-space statistics; ns = +y with dpdu along the disk's tangent at (0.1, 0, 0)
+    BSDF bsdf;
+    bsdf.eta = 1; bsdf.ns = V3(0, 1, 0); bsdf.ng = V3(0, 1, 0); bsdf.ss = V3(0, 0, -1); bsdf.ts = Cross(bsdf.ns, bsdf.ss); bsdf.nBxDFs = 1;
+    BxDF &b = bsdf.bxdfs[0];
+    b = BxDF();
+    if (which == 0) { b.kind = BXDF_LAMBERT; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.R = Spec(1.f); }
+    else if (which == 1 || which == 2) {
+        b.kind = BXDF_MICROFACET; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.R = Spec(1.f);
+        b.dist.alphax = RoughnessToAlpha(which == 1 ? 0.5f : 0.3f); b.dist.alphay = RoughnessToAlpha(which == 1 ? 0.5f : 0.15f);
+    } else {
+        b.kind = BXDF_FRESNEL_BLEND; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.R = Spec(0.5f); b.S = Spec(0.5f);
+        b.dist.alphax = RoughnessToAlpha(0.3f); b.dist.alphay = RoughnessToAlpha(0.3f);
+    }
+    std::vector<Float> frequencies((size_t)thetaRes * phiRes), expFrequencies((size_t)thetaRes * phiRes);
+    RNG rng;
+    int rejected = 0;
+    *minPval = 1;
+    for (int k = 0; k < runs; ++k) {
+        P2 sample; sample.x = rng.UniformFloat(); sample.y = rng.UniformFloat();
+        V3 wo = bsdf.LocalToWorld(CosineSampleHemisphere(sample));
+        // FrequencyTable (:176-201)
+        std::fill(frequencies.begin(), frequencies.end(), (Float)0);
+        const Float factorTheta = thetaRes / Pi, factorPhi = phiRes / (2 * Pi);
+        for (int i = 0; i < sampleCount; ++i) {
+            P2 u; u.x = rng.UniformFloat(); u.y = rng.UniformFloat();
+            V3 wi; Float pdf; int flags = 0;
+            Spec f = bsdf.Sample_f(wo, &wi, u, &pdf, BSDF_ALL, &flags);
+            if (f.IsBlack() || (flags & BSDF_SPECULAR)) continue;
+            V3 wiL = bsdf.WorldToLocal(wi);
+            Float cx = std::acos(Clamp(wiL.z, -1, 1)) * factorTheta, cy = std::atan2(wiL.y, wiL.x) * factorPhi;
+            if (cy < 0) cy += 2 * Pi * factorPhi;
+            int thetaBin = std::min(std::max(0, (int)std::floor(cx)), thetaRes - 1);
+            int phiBin = std::min(std::max(0, (int)std::floor(cy)), phiRes - 1);
+            frequencies[(size_t)thetaBin * phiRes + phiBin] += 1;
+        }
+        // IntegrateFrequencyTable (:205-229)
+        const Float cellTheta = Pi / thetaRes, cellPhi = (2 * Pi) / phiRes;
+        for (int i = 0; i < thetaRes; ++i)
+            for (int j = 0; j < phiRes; ++j)
+                expFrequencies[(size_t)i * phiRes + j] = sampleCount * chi2::AdaptiveSimpson2D(
+                    [&](Float theta, Float phi) -> Float {
+                        Float cosTheta = std::cos(theta), sinTheta = std::sin(theta), cosPhi = std::cos(phi), sinPhi = std::sin(phi);
+                        V3 wiL(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+                        return bsdf.Pdf(wo, bsdf.LocalToWorld(wiL), BSDF_ALL) * sinTheta;
+                    }, i * cellTheta, j * cellPhi, (i + 1) * cellTheta, (j + 1) * cellPhi);
+        double pval;
+        if (!chi2::Chi2Test(frequencies.data(), expFrequencies.data(), thetaRes, phiRes, sampleCount, 5, 0.01f, runs, &pval)) ++rejected;
+        if (pval < *minPval) *minPval = pval;
+    }
+    return rejected;
+}
+
 }  // namespace orc

@@ -11,6 +11,9 @@ way a BVHAccel-shaped adapter inside pbrt would.
   Distribution1D.Discrete        src/tests/sampling.cpp:231-282
   FloatingPoint.NextUpDownFloat  src/tests/fp_tests.cpp:29-47
   EFloat.Add/Sub/Mul/Div         src/tests/fp_tests.cpp:107-262   1,000,000 trials each
+  BSDFSampling.Lambertian, TR_VA_0p5, TR_VA_0p3_0p15, TR_VA_0p3   src/tests/bsdfs.cpp:484-544   chi-square of Sample_f against Pdf,
+                                 5 directions x 1,000,000 samples each, the reference's RNG stream (the Beckmann and the
+                                 non-visible-area cases are distributions the path never uses)
 """
 import ctypes as C
 
@@ -29,6 +32,16 @@ def test_oracle_numeric_unit_tests(orc):
     assert orc.lib.orc_selftest_next_float() == 0
     assert orc.lib.orc_selftest_efloat(1000000) == 0
     assert orc.lib.orc_selftest_distribution1d() == 0
+
+
+@pytest.mark.parametrize("which,name", [(0, "Lambertian"), (1, "TR_VA_0p5"), (2, "TR_VA_0p3_0p15"), (3, "TR_VA_0p3 (FresnelBlend)")])
+def test_oracle_bsdf_sampling_chi_square(orc, which, name):
+    fn = orc.lib.orc_selftest_bsdf_sampling
+    fn.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    p = C.c_double()
+    rejected = fn(which, C.byref(p))
+    assert rejected == 0, "%s: null hypothesis rejected in %d of 5 runs (min p-value %g)" % (name, rejected, p.value)
+    assert 0 < p.value <= 1
 
 
 def test_product_host_math_unit_tests(hprt):
