@@ -4,13 +4,14 @@
 // t mod N (core/integrator.cpp:237-244), hprt_film_gather_local as Film::MergeFilmTile, hprt_film_resolve +
 // hprt_write_pfm as Film::WriteImage.  No Python, no torch: the library allocates its own device memory.
 //
-//   g++ -O2 -std=c++17 -Iinclude examples/hprt_render.cpp -o hprt_render -Lthesis-pbrt-v3_amd/lib -lhprt -Wl,-rpath,$PWD/thesis-pbrt-v3_amd/lib
+//   g++ -O2 -std=c++17 -pthread -Iinclude examples/hprt_render.cpp -o hprt_render -Lthesis-pbrt-v3_amd/lib -lhprt -Wl,-rpath,$PWD/thesis-pbrt-v3_amd/lib
 //   ./hprt_render scene.pbrt|scene.hprt out.pfm [--spp N] [--gpus N] [--crop x0 x1 y0 y1]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hprt.h"
@@ -59,14 +60,25 @@ int main(int argc, char **argv) {
     // one scene per GPU; rank r renders tiles r, r + N, ...
     std::vector<HprtScene *> scenes((size_t)gpus, nullptr);
     for (int g = 0; g < gpus; ++g) TRY(hprt_scene_create_from_model(model, bvh, g, &scenes[(size_t)g]));
+    // one host thread per GPU (the renders are independent; errors are thread-local in the library, so each thread keeps its own)
+    std::vector<HprtRenderStats> stats((size_t)gpus);
+    std::vector<int> rcs((size_t)gpus, HPRT_OK);
+    std::vector<std::string> errs((size_t)gpus);
+    std::vector<std::thread> workers;
+    for (int g = 0; g < gpus; ++g)
+        workers.emplace_back([&, g] {
+            HprtRenderDesc desc; std::memset(&desc, 0, sizeof(desc));
+            desc.opt = opt; desc.tile_begin = g; desc.tile_end = 0; desc.tile_stride = gpus;
+            desc.flags = gpus > 1 ? HPRT_RENDER_EXPORT_FOREIGN : 0;
+            rcs[(size_t)g] = hprt_render(scenes[(size_t)g], &desc, nullptr, nullptr, &stats[(size_t)g]);      // the library-owned film of this scene
+            if (rcs[(size_t)g] != HPRT_OK) errs[(size_t)g] = hprt_last_error();
+        });
+    for (std::thread &t : workers) t.join();
     HprtRenderStats total; std::memset(&total, 0, sizeof(total));
     double seconds = 0;
-    for (int g = 0; g < gpus; ++g) {      // (a production adapter drives the GPUs from one thread each; the renders are independent)
-        HprtRenderDesc desc; std::memset(&desc, 0, sizeof(desc));
-        desc.opt = opt; desc.tile_begin = g; desc.tile_end = 0; desc.tile_stride = gpus;
-        desc.flags = gpus > 1 ? HPRT_RENDER_EXPORT_FOREIGN : 0;
-        HprtRenderStats st;
-        TRY(hprt_render(scenes[(size_t)g], &desc, nullptr, nullptr, &st));      // the library-owned film of this scene
+    for (int g = 0; g < gpus; ++g) {
+        if (rcs[(size_t)g] != HPRT_OK) { std::fprintf(stderr, "hprt_render on GPU %d failed (%d): %s\n", g, rcs[(size_t)g], errs[(size_t)g].c_str()); return 1; }
+        const HprtRenderStats &st = stats[(size_t)g];
         total.camera_rays += st.camera_rays; total.rays += st.rays; total.shadow_rays += st.shadow_rays;
         if (st.render_seconds > seconds) seconds = st.render_seconds;
     }

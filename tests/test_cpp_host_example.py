@@ -16,7 +16,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden", "killeroo_simple.hprt")
 def exe(hprt, tmp_path_factory):
     out = str(tmp_path_factory.mktemp("cpp") / "hprt_render")
     lib = os.path.join(ROOT, "thesis-pbrt-v3_amd", "lib")
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "hprt_render.cpp"),
+    cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "hprt_render.cpp"),
            "-o", out, "-L" + lib, "-lhprt", "-Wl,-rpath," + lib]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
