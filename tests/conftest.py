@@ -4,6 +4,12 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 next to /opt/rocm's, which libhprt.so links against; one process can
+# hold both, but only if torch's are loaded first (a torch.cuda call after libhprt has opened the device reports "No HIP GPUs are
+# available").  Tests that hand torch device buffers to the library (as bench.py does) need both, so torch is imported before
+# anything loads libhprt.so — whatever subset of the test files runs.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

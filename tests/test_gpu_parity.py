@@ -374,6 +374,26 @@ np.save(sys.argv[3], film)
 """
 
 
+def test_irregular_sample_buffer_grows_on_demand(tmp_path, killeroo_oracle):
+    """The list of camera samples whose box-filter footprint is not their own pixel is written with a guessed capacity; when the
+    count exceeds it (very high spp) the pass is repeated with the counted size.  HPRT_IRREGULAR_CAP=16 makes a small render
+    take that second pass; the film must be the oracle's."""
+    import os, subprocess, sys
+    from conftest import KILLEROO, ROOT
+    out = str(tmp_path / "film.npy")
+    env = dict(os.environ, HPRT_IRREGULAR_CAP="16")
+    r = subprocess.run([sys.executable, "-c", _FEW_WAVES_SCRIPT.replace("opt.spp = 1", "opt.spp = 16"), ROOT, KILLEROO, out], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    killeroo_oracle.set_film(crop=(0.3, 0.6, 0.3, 0.6), spp=16)
+    try:
+        _, film0, _, _, _ = killeroo_oracle.render(spp=16, threads=16)
+    finally:
+        killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
+    assert (film0[..., 3] != 16).sum() > 16          # more irregular samples than the forced capacity
+    assert np.array_equal(got.view(np.uint32), film0.view(np.uint32))
+
+
 def test_few_waves_working_through_many_queue_chunks(tmp_path, killeroo_oracle):
     """The persistent traversal waves draw rays from the queue head in chunks and prefetch the next queue entries while the
     current rays load.  A wave that exhausts its chunk and then draws the ADJACENT chunk (nobody else drew in between) must

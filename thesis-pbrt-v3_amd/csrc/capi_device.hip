@@ -997,15 +997,23 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
 
     auto wall0 = std::chrono::high_resolution_clock::now();
     // ---- film footprint pre-pass ----
-    const uint32_t irrCap = (uint32_t)std::min<uint64_t>((uint64_t)nPix * spp, 1u << 24);
-    HIP_TRY(s->irregular.alloc((size_t)irrCap * sizeof(IrregularSample)));
+    // (capacity: a first guess — a few samples per pixel have a zero Halton offset — and a second pass with the counted size if
+    // the guess was too small; HPRT_IRREGULAR_CAP: test hook for that second pass)
+    static const uint32_t capHint = [] { const char *e = getenv("HPRT_IRREGULAR_CAP"); return e ? (uint32_t)std::max(1, atoi(e)) : (1u << 24); }();
+    uint32_t irrCap = (uint32_t)std::min<uint64_t>((uint64_t)nPix * spp, capHint);
     HIP_TRY(s->irregularCount.alloc(16));
-    HIP_TRY(hipMemsetAsync(s->irregularCount.p, 0, 16, st));
-    LaunchFindIrregular(st, s->dev, rp, f.fg, spp, s->irregularCount.as<uint32_t>(), irrCap, s->irregular.as<IrregularSample>());
-    HIP_TRY(hipMemcpyAsync(s->hostCounts + 8, s->irregularCount.p, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const uint32_t nIrr = s->hostCounts[8];
-    if (nIrr > irrCap) return SetError(HPRT_E_UNSUPPORTED, "too many irregular film samples");
+    uint32_t nIrr = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        HIP_TRY(s->irregular.alloc((size_t)irrCap * sizeof(IrregularSample)));
+        HIP_TRY(hipMemsetAsync(s->irregularCount.p, 0, 16, st));
+        LaunchFindIrregular(st, s->dev, rp, f.fg, spp, s->irregularCount.as<uint32_t>(), irrCap, s->irregular.as<IrregularSample>());
+        HIP_TRY(hipMemcpyAsync(s->hostCounts + 8, s->irregularCount.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        nIrr = s->hostCounts[8];
+        if (nIrr <= irrCap) break;
+        if (pass == 1 || (uint64_t)nIrr * sizeof(IrregularSample) > (8ull << 30)) return SetError(HPRT_E_UNSUPPORTED, "too many irregular film samples");
+        irrCap = nIrr;
+    }
     std::vector<IrregularSample> irr(nIrr);
     if (nIrr) HIP_TRY(hipMemcpy(irr.data(), s->irregular.p, (size_t)nIrr * sizeof(IrregularSample), hipMemcpyDeviceToHost));
     std::vector<ExtraEntry> own, foreign;
