@@ -1250,12 +1250,14 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     static const uint32_t blockCap = [] { const char *e = getenv("HPRT_TRACE_MAX_BLOCKS"); return e ? (uint32_t)std::max(1, atoi(e)) : 0xffffffffu; }();
     // workgroups per CU: five (LDS stack 32 KB, or four by registers in the kernels with the quadric code); seven for the plain
     // any-hit kernel of triangle-only scenes (66 registers, 20 KB)
-    static const uint32_t anyPerCu = [] { const char *e = getenv("HPRT_TRACE_ANY_PER_CU"); return e ? (uint32_t)std::min(8, std::max(1, atoi(e))) : (uint32_t)HPRT_ANY_WAVES; }();
+    static const uint32_t anyPerCu = [] { const char *e = getenv("HPRT_TRACE_ANY_PER_CU"); return e ? (uint32_t)std::min((int)(HPRT_DEEP_THREADS / (256u * HPRT_TRACE_BLOCK)), std::max(1, atoi(e))) : (uint32_t)HPRT_ANY_WAVES; }();      // (the deep-stack area is laid out for that many workgroups per CU)
     const bool slimAny = anyHit && !count && sc.nInstances == 0u && sc.nSpheres == 0u && getenv("HPRT_TRACE_PROFILE") == nullptr;
     static const uint32_t closestPerCu = [] { const char *e = getenv("HPRT_TRACE_CLOSEST_PER_CU"); return e ? (uint32_t)std::min(7, std::max(1, atoi(e))) : (uint32_t)HPRT_CLOSEST_WAVES; }();
     const bool slimClosest = !anyHit && !count && sc.nInstances == 0u && sc.nSpheres == 0u && getenv("HPRT_TRACE_PROFILE") == nullptr;
     const bool plainQuadAny = anyHit && !count && sc.nInstances == 0u && sc.nSpheres != 0u && getenv("HPRT_TRACE_PROFILE") == nullptr;
     const uint32_t maxBlocks = std::min(256u * (slimAny ? anyPerCu : slimClosest ? closestPerCu : plainQuadAny ? (uint32_t)HPRT_QUAD_ANY_WAVES : 5u), blockCap);
+    static_assert(HPRT_DEEP_THREADS >= 256u * HPRT_TRACE_BLOCK * HPRT_ANY_WAVES && HPRT_DEEP_THREADS >= 256u * HPRT_TRACE_BLOCK * HPRT_CLOSEST_WAVES &&
+                  HPRT_DEEP_THREADS >= 256u * HPRT_TRACE_BLOCK * HPRT_QUAD_ANY_WAVES, "the deep-stack area must cover the largest trace grid");
     dim3 grid(std::min(blocks_for(gridItems, HPRT_TRACE_BLOCK), maxBlocks)), block(HPRT_TRACE_BLOCK);
     // rays per queue-head atomic: large launches take 512 at a time, small ones keep every wave busy
     const uint32_t nWaves = grid.x * (HPRT_TRACE_BLOCK / 64);
