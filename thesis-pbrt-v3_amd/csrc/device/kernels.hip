@@ -212,7 +212,9 @@ __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31
 // HPRT_SHADE_PROF (variant builds only, tools/build_variant.sh): wave clocks between program points of k_shade, per MODE
 #ifdef HPRT_SHADE_PROF
 __device__ unsigned long long g_shadeProf[3 * 8];
-#define SP_MARK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); spT[k] += t_ - spLast; spLast = t_; } while (0)
+__device__ unsigned long long g_shadeLanes[3 * 8 * 2];      // per MODE and mark: sum of active lanes, number of times reached
+#define SP_MARK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); spT[k] += t_ - spLast; spLast = t_; \
+                        const unsigned long long m_ = __ballot(1); if (__lane_id() == (uint32_t)(__ffsll((long long)m_) - 1)) { atomicAdd(&g_shadeLanes[(MODE * 8 + k) * 2], (unsigned long long)__popcll(m_)); atomicAdd(&g_shadeLanes[(MODE * 8 + k) * 2 + 1], 1ull); } } while (0)
 #else
 #define SP_MARK(k) do { } while (0)
 #endif
@@ -1286,8 +1288,9 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
 #undef HPRT_TRACE_LAUNCH
 }
 #ifdef HPRT_SHADE_PROF
-extern "C" __attribute__((visibility("default"))) int hprt_debug_shade_profile(unsigned long long out[24]) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_shadeProf), sizeof(unsigned long long) * 24) == hipSuccess ? 0 : -1;
+extern "C" __attribute__((visibility("default"))) int hprt_debug_shade_profile(unsigned long long out[24 + 48]) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_shadeProf), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out + 24, HIP_SYMBOL(g_shadeLanes), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : -1;
 }
 #endif
 // diagnostics hook (not part of include/hprt.h): read and optionally clear the phase profile
