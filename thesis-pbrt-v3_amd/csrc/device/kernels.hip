@@ -143,7 +143,8 @@ struct TraceTune { int refillBelow, parkLimit, stepLimit, sphereLimit, primMin; 
 static TraceTune DefaultTraceTune(bool anyHit) {
     // closest-hit and any-hit rays want different schedules: shadow rays mostly cross the scene unoccluded, with
     // few primitive tests each, so their tests should not wait for company (full-frame sweeps, tools/sweep_bench.sh)
-    TraceTune t = anyHit ? TraceTune{52, 24, 10, 4, 3} : TraceTune{52, 24, 6, 4, 8};      // (sphereLimit: flat between 1 and 16 since the pre-test)
+    // (any hit: refill below 40 busy lanes since the seven-wave kernels, tools/sweep_tune3.sh: atrium shadow rays +5 %, the others +-0)
+    TraceTune t = anyHit ? TraceTune{40, 24, 10, 4, 3} : TraceTune{52, 24, 6, 4, 8};      // (sphereLimit: flat between 1 and 16 since the pre-test)
     if (const char *e = getenv(anyHit ? "HPRT_TRACE_TUNE_ANY" : "HPRT_TRACE_TUNE"))
         sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin);
     return t;
