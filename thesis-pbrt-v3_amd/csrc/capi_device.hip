@@ -947,10 +947,10 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     const size_t lallBytes = 3ull * spp * nPix * sizeof(float);
     if (lallBytes > (96ull << 30)) return SetError(HPRT_E_UNSUPPORTED, "per-sample radiance store would exceed 96 GiB; render in several tile ranges");
     // Paths per wavefront batch.  Every launch ends with a tail of half-empty waves and every bounce with a host
-    // read-back, so batches are as large as memory allows: up to 128 M paths (345 B per path of streams and
-    // queues = 46 GB of the 288 GB), less if the device has less free (a third of what is free now).  killeroo-simple
-    // at 256 spp is one batch of 125 M paths: 6.5 % faster than two batches of 64 M.  (HPRT_BATCH_MPATHS raises the cap; the
-    // living room's 236 M paths in one batch instead of two: +1.1 %.)
+    // read-back, so batches are as large as memory allows: up to 256 M paths (393 B per path of streams and queues = 100 GB
+    // of the 288 GB), less if the device has less free (half of what is free now), and of EQUAL size (1,024 spp of the atrium:
+    // two batches of 512 instead of 522 + 502 or, at the old 128 M cap, four of 256: -1 % per frame).  killeroo-simple
+    // at 256 spp is one batch of 125 M paths: 6.5 % faster than two batches of 64 M.  (HPRT_BATCH_MPATHS changes the cap.)
     uint32_t chunk;
     if (desc->spp_chunk > 0) chunk = (uint32_t)desc->spp_chunk;
     else {
@@ -958,9 +958,13 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
         HIP_TRY(hipMemGetInfo(&freeB, &totalB));
         freeB += s->planes.bytes + s->queues.bytes;                 // this scene's previous workspace is reused or released
         const size_t perPath = kPlaneBytesPerSlot + 12 * sizeof(uint32_t);
-        static const size_t capM = [] { const char *e = getenv("HPRT_BATCH_MPATHS"); return e ? (size_t)atoi(e) : (size_t)128; }();
-        const size_t budget = std::min<size_t>(capM << 20, std::max<size_t>(freeB / 3 / perPath, 1ull << 20));
+        static const size_t capM = [] { const char *e = getenv("HPRT_BATCH_MPATHS"); return e ? (size_t)atoi(e) : (size_t)256; }();
+        const size_t budget = std::min<size_t>(capM << 20, std::max<size_t>(freeB / 2 / perPath, 1ull << 20));
         chunk = std::max<uint32_t>(1u, (uint32_t)(budget / std::max<uint32_t>(nPix, 1u)));
+        if ((uint64_t)chunk * nPix > 0x7fffffffull) chunk = (uint32_t)(0x7fffffffull / nPix);
+        chunk = std::max(1u, std::min(chunk, spp));
+        const uint32_t nBatches = (spp + chunk - 1) / chunk;
+        chunk = (spp + nBatches - 1) / nBatches;                    // equal batches
     }
     chunk = std::min(chunk, spp);
     if ((uint64_t)chunk * nPix > 0x7fffffffull) chunk = (uint32_t)(0x7fffffffull / nPix);
