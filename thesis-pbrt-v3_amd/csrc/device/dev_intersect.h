@@ -217,7 +217,7 @@ __device__ __noinline__ bool sphere_test(const DevSphere &s, const DRay &r, DRay
 #define HPRT_LDS_STACK_ANY 10
 #endif
 #define HPRT_STACK_TOTAL 64
-#define HPRT_SPILL_STACK (HPRT_STACK_TOTAL - HPRT_LDS_STACK_ANY)      // deepest HBM part any kernel can need
+#define HPRT_SPILL_STACK (HPRT_STACK_TOTAL - 7)      // deepest HBM part any kernel can need (the shortest LDS stack, instanced any-hit, keeps 7 entries)
 // threads of the largest trace grid (256 CUs x 7 workgroups x 256 threads): stride of the deep-stack area, DevScene::deepStack
 #define HPRT_DEEP_THREADS 458752u
 #ifndef HPRT_TRACE_BLOCK

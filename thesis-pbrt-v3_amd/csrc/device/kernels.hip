@@ -31,6 +31,8 @@
 #ifndef HPRT_LDS_STACK_QUAD_ANY
 #define HPRT_LDS_STACK_QUAD_ANY 12
 #endif
+#define HPRT_LDS_STACK_INST_ANY 7
+#define HPRT_LDS_STACK_INST_CLOSEST 9
 #ifndef HPRT_ANY_WAVES
 #define HPRT_ANY_WAVES 7
 #endif
@@ -225,7 +227,7 @@ __device__ unsigned long long g_shadeLanes[3 * 8 * 2];      // per MODE and mark
 // QUAD: the scene has quadrics (spheres).  Their interval-arithmetic test is a call of 99 VGPRs that every value the walk
 // keeps must sit above; triangle-only scenes (the Sponza-class and living-room workloads) get the kernel without it.
 template <bool ANY_HIT, int MODE, bool INST, bool QUAD>
-__global__ __launch_bounds__(HPRT_TRACE_BLOCK, (MODE == 0 && !INST) ? (QUAD ? (ANY_HIT ? HPRT_QUAD_ANY_WAVES : HPRT_QUAD_CLOSEST_WAVES) : ANY_HIT ? HPRT_ANY_WAVES : HPRT_CLOSEST_WAVES) : 1024 / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
+__global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HPRT_QUAD_ANY_WAVES : HPRT_QUAD_CLOSEST_WAVES) : ANY_HIT ? HPRT_ANY_WAVES : HPRT_CLOSEST_WAVES) : 1024 / HPRT_TRACE_BLOCK) void k_trace(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
                                                             uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ,
                                                             DevCounters *counters, uint4 *rayStats, uint32_t *workCounter, uint32_t chunk,
                                                             TraceTune tune) {
@@ -242,7 +244,10 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, (MODE == 0 && !INST) ? (QUAD ? (A
     unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned int pfPush = 0u, pfSpill = 0u;      // PROF: stack pushes, and those beyond the LDS entries (scratch)
     const unsigned long long pfStart = PROF ? clock64() : 0ull;
-    constexpr int LDS_N = (MODE == 0 && !INST) ? (QUAD ? (ANY_HIT ? HPRT_LDS_STACK_QUAD_ANY : HPRT_LDS_STACK) : ANY_HIT ? HPRT_LDS_STACK_ANY : HPRT_LDS_STACK_CLOSEST) : HPRT_LDS_STACK;
+    // (instanced scenes: the world-space ray takes another 6 KB of LDS per workgroup, so their stacks keep fewer entries for the same occupancy)
+    constexpr int LDS_N = MODE != 0 ? HPRT_LDS_STACK
+                        : !INST ? (QUAD ? (ANY_HIT ? HPRT_LDS_STACK_QUAD_ANY : HPRT_LDS_STACK) : ANY_HIT ? HPRT_LDS_STACK_ANY : HPRT_LDS_STACK_CLOSEST)
+                                : (QUAD ? HPRT_LDS_STACK_QUAD_ANY : ANY_HIT ? HPRT_LDS_STACK_INST_ANY : HPRT_LDS_STACK_INST_CLOSEST);
     __shared__ uint2 stackMem[LDS_N * HPRT_TRACE_BLOCK];     // [entry][thread]: {ref, tMin}
     uint2 *const ldsStack = &stackMem[threadIdx.x];
     // INST: the world-space ray stays in LDS ([component][thread]) while the lane walks an instance with the transformed one
@@ -1254,11 +1259,12 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     // workgroups per CU: five (LDS stack 32 KB, or four by registers in the kernels with the quadric code); seven for the plain
     // any-hit kernel of triangle-only scenes (66 registers, 20 KB)
     static const uint32_t anyPerCu = [] { const char *e = getenv("HPRT_TRACE_ANY_PER_CU"); return e ? (uint32_t)std::min((int)(HPRT_DEEP_THREADS / (256u * HPRT_TRACE_BLOCK)), std::max(1, atoi(e))) : (uint32_t)HPRT_ANY_WAVES; }();      // (the deep-stack area is laid out for that many workgroups per CU)
-    const bool slimAny = anyHit && !count && sc.nInstances == 0u && sc.nSpheres == 0u && getenv("HPRT_TRACE_PROFILE") == nullptr;
+    const bool plain = !count && getenv("HPRT_TRACE_PROFILE") == nullptr;
+    const bool hasQuad = sc.nSpheres != 0u;
     static const uint32_t closestPerCu = [] { const char *e = getenv("HPRT_TRACE_CLOSEST_PER_CU"); return e ? (uint32_t)std::min(7, std::max(1, atoi(e))) : (uint32_t)HPRT_CLOSEST_WAVES; }();
-    const bool slimClosest = !anyHit && !count && sc.nInstances == 0u && sc.nSpheres == 0u && getenv("HPRT_TRACE_PROFILE") == nullptr;
-    const bool plainQuadAny = anyHit && !count && sc.nInstances == 0u && sc.nSpheres != 0u && getenv("HPRT_TRACE_PROFILE") == nullptr;
-    const uint32_t maxBlocks = std::min(256u * (slimAny ? anyPerCu : slimClosest ? closestPerCu : plainQuadAny ? (uint32_t)HPRT_QUAD_ANY_WAVES : 5u), blockCap);
+    // workgroups per CU = waves per SIMD the variant is compiled for (instanced scenes included: their LDS stacks are shorter)
+    const uint32_t perCu = !plain ? 4u : hasQuad ? (anyHit ? (uint32_t)HPRT_QUAD_ANY_WAVES : (uint32_t)HPRT_QUAD_CLOSEST_WAVES) : (anyHit ? anyPerCu : closestPerCu);
+    const uint32_t maxBlocks = std::min(256u * perCu, blockCap);
     static_assert(HPRT_DEEP_THREADS >= 256u * HPRT_TRACE_BLOCK * HPRT_ANY_WAVES && HPRT_DEEP_THREADS >= 256u * HPRT_TRACE_BLOCK * HPRT_CLOSEST_WAVES &&
                   HPRT_DEEP_THREADS >= 256u * HPRT_TRACE_BLOCK * HPRT_QUAD_ANY_WAVES, "the deep-stack area must cover the largest trace grid");
     dim3 grid(std::min(blocks_for(gridItems, HPRT_TRACE_BLOCK), maxBlocks)), block(HPRT_TRACE_BLOCK);
