@@ -249,6 +249,57 @@ def test_rccl_film_gather_through_the_c_abi(hprt, killeroo_model, killeroo_scene
     del comm
 
 
+def _rccl_rank_worker(rank, world, port, out_path, spp):
+    """One process per GPU, as bench.py runs them: tile shard rendered with EXPORT_FOREIGN on device `rank`, films merged by
+    hprt_film_gather over a communicator whose id travelled through a gloo store."""
+    import importlib, os
+    import torch
+    import torch.distributed as dist
+    from conftest import KILLEROO
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    hprt = importlib.import_module("thesis-pbrt-v3_amd")
+    tiles = importlib.import_module("thesis-pbrt-v3_amd.tiles")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(rank)
+    ids = [hprt.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    model = hprt.Model.load(KILLEROO); bvh = hprt.Bvh(model); scene = hprt.Scene(model, bvh, device=rank)
+    opt = model.options.copy(); opt.spp = spp
+    x0, y0, x1, y1 = opt.film_bounds()
+    film = torch.zeros((y1 - y0, x1 - x0, 4), dtype=torch.float32, device="cuda:%d" % rank)
+    comm = hprt.Comm(ids[0], rank, world, device=rank)
+    info = comm.info()
+    assert (info["rank"], info["n_ranks"], info["device"]) == (rank, world, rank)
+    scene.render(opt, film_ptr=film.data_ptr(), export_foreign=True, **tiles.shard(rank, world))
+    comm.film_gather(scene, film.data_ptr(), (x1 - x0) * (y1 - y0), root=0)
+    torch.cuda.synchronize(rank)
+    if rank == 0:
+        np.save(out_path, film.cpu().numpy())
+    dist.barrier()
+    del comm
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, "all"])
+def test_rccl_film_gather_one_process_per_gpu(tmp_path, killeroo_scene, killeroo_model, world):
+    """hprt_film_gather between processes that own one GPU each (RCCL over xGMI): world = every GPU of the box (at most 4),
+    skipped on a 1-GPU box — where the same worker still runs as a world of one, so that the code of the multi-GPU case is
+    exercised wherever the suite runs.  The merged film must equal the unsharded film bit for bit."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    if world == "all":
+        world = min(torch.cuda.device_count(), 4)
+        if world < 2:
+            pytest.skip("one GPU: RCCL refuses two ranks on one device (the N > 1 path runs on gloo in test_ranks_sharing_the_gpu_*)")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "film.npy")
+    mp.spawn(_rccl_rank_worker, args=(world, port, out, 2), nprocs=world, join=True)
+    opt = killeroo_model.options.copy(); opt.spp = 2
+    plain, _ = killeroo_scene.render(opt)
+    assert np.array_equal(np.load(out).view(np.uint32), plain.view(np.uint32))
+
+
 def test_bench_launches_its_own_ranks(tmp_path, killeroo_oracle):
     """`python bench.py --gpus 2` without WORLD_SIZE starts two fresh rank processes itself (before touching the GPU) and
     reports the world size the merge actually ran over.  On the 1-GPU box the ranks share cuda:0 (--rehearse-on-one-gpu,
