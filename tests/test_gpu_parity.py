@@ -300,6 +300,28 @@ def test_rccl_film_gather_one_process_per_gpu(tmp_path, killeroo_scene, killeroo
     assert np.array_equal(np.load(out).view(np.uint32), plain.view(np.uint32))
 
 
+def test_film_gather_local_over_every_gpu_of_the_box(hprt, killeroo_model, killeroo_scene):
+    """hprt_film_gather_local — ONE process driving several GPUs, the way examples/hprt_render.cpp and a pbrt-side adapter do: one
+    scene per device, tiles dealt round-robin, ncclCommInitAll + ncclReduce, records merged on the root.  Needs two GPUs (the
+    one-GPU form of the call is part of test_rccl_film_gather_through_the_c_abi)."""
+    import torch
+    n = min(torch.cuda.device_count(), 4)
+    if n < 2:
+        pytest.skip("one GPU")
+    bvh = hprt.Bvh(killeroo_model)
+    scenes = [hprt.Scene(killeroo_model, bvh, device=g) for g in range(n)]
+    opt = killeroo_model.options.copy(); opt.spp = 2
+    x0, y0, x1, y1 = opt.film_bounds()
+    n_pix = (x1 - x0) * (y1 - y0)
+    for g, sc in enumerate(scenes):
+        sc.render(opt, export_foreign=True, tile_begin=g, tile_stride=n)      # library-owned films
+    hprt.film_gather_local(scenes, None, n_pix, root=0)
+    merged = np.zeros((y1 - y0, x1 - x0, 4), np.float32)
+    hprt._check(hprt.lib.hprt_film_read(scenes[0]._h, hprt._ptr(merged), n_pix))
+    plain, _ = killeroo_scene.render(opt)
+    assert np.array_equal(merged.view(np.uint32), plain.view(np.uint32))
+
+
 def test_bench_launches_its_own_ranks(tmp_path, killeroo_oracle):
     """`python bench.py --gpus 2` without WORLD_SIZE starts two fresh rank processes itself (before touching the GPU) and
     reports the world size the merge actually ran over.  On the 1-GPU box the ranks share cuda:0 (--rehearse-on-one-gpu,
