@@ -1,4 +1,5 @@
 #!/bin/bash
+# Sweep of the any-hit walk knobs (refill threshold x step limit) on the three bench workloads; round 2 took 40,24,10,4,3 from it.  usage: bash tools/sweep_tune3.sh
 R=$GRAFT_REPO_ROOT; cd $R
 for W in atrium living-room killeroo-simple; do
 python3 bench.py --profile-step --workload $W > /dev/null 2>&1
