@@ -155,6 +155,24 @@ def test_frontend_rejects_and_warns(hprt, tmp_path):
     assert "translucent" in w and "rough glass" in w and "cone" in w
 
 
+def test_spectra_in_other_forms_are_converted_or_reported(hprt, tmp_path):
+    """core/paramset.cpp:168-215: "xyz" values are RGB after RGBSpectrum::FromXYZ's fixed matrix (core/spectrum.h:52-56) — the
+    same scene written with the converted "rgb" bakes to the same bytes; a blackbody or sampled spectrum is outside the scope and
+    must be reported, not silently replaced by the default (scenes/triangles has a "blackbody L")."""
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n'
+    xyz = np.array([0.3, 0.4, 0.2], np.float32)
+    M = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]], np.float32)
+    rgb = [np.float32(np.float32(np.float32(M[r, 0] * xyz[0]) + np.float32(M[r, 1] * xyz[1])) + np.float32(M[r, 2] * xyz[2])) for r in range(3)]
+    a = _parse_text(hprt, tmp_path, HEADER + 'Material "matte" "xyz Kd" [0.3 0.4 0.2]\n' + tri, name="xyz.pbrt")
+    b = _parse_text(hprt, tmp_path, HEADER + 'Material "matte" "rgb Kd" [%r %r %r]\n' % tuple(float(v) for v in rgb) + tri, name="rgb.pbrt")
+    assert a.warnings() == [] and b.warnings() == []
+    a.save(str(tmp_path / "a.hprt")); b.save(str(tmp_path / "b.hprt"))
+    assert open(str(tmp_path / "a.hprt"), "rb").read() == open(str(tmp_path / "b.hprt"), "rb").read()
+    c = _parse_text(hprt, tmp_path, HEADER + 'LightSource "distant" "blackbody L" [3000 1.5]\nMaterial "matte" "spectrum Kd" [400 .5 700 .5]\n' + tri, name="bb.pbrt")
+    w = " ".join(c.warnings())
+    assert "blackbody L" in w and "spectrum Kd" in w and len(c.warnings()) == 2
+
+
 def test_loop_subdivision_of_a_closed_and_an_open_mesh(hprt, tmp_path):
     # octahedron (closed, valence-4 vertices) and a single quad (boundary rules)
     octa = ('Shape "loopsubdiv" "integer nlevels" [2] "integer indices" [0 2 4 2 1 4 1 3 4 3 0 4 2 0 5 1 2 5 3 1 5 0 3 5] '

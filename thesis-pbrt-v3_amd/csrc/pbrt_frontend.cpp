@@ -201,6 +201,20 @@ struct Frontend {
                     p.nums.push_back(f);
                 }
             }
+            // spectra given in other forms (core/paramset.cpp:168-215).  "xyz" is a fixed matrix away from RGB (RGBSpectrum::FromXYZ ->
+            // XYZToRGB, core/spectrum.h:52-56); blackbody and sampled spectra need the CIE matching tables, which are outside the
+            // hot-path scope: the directive then uses its default, and says so.
+            if (p.type == "xyz" && p.nums.size() % 3 == 0) {
+                for (size_t k = 0; k + 2 < p.nums.size(); k += 3) {
+                    const float x = p.nums[k], y = p.nums[k + 1], z = p.nums[k + 2];
+                    p.nums[k] = 3.240479f * x - 1.537150f * y - 0.498535f * z;
+                    p.nums[k + 1] = -0.969256f * x + 1.875991f * y + 0.041556f * z;
+                    p.nums[k + 2] = 0.055648f * x - 0.204043f * y + 1.057311f * z;
+                }
+                p.type = "rgb";
+            } else if (p.type == "blackbody" || (p.type == "spectrum" && p.name != "eta" && p.name != "k"))
+                warn("parameter \"" + p.type + " " + p.name + "\": spectra given as " + (p.type == "blackbody" ? "blackbody temperatures" : "sampled data or files") +
+                     " are outside the hot-path scope; the default value is used");
             pl->items.push_back(p);
         }
         return true;
