@@ -173,6 +173,24 @@ def test_spectra_in_other_forms_are_converted_or_reported(hprt, tmp_path):
     assert "blackbody L" in w and "spectrum Kd" in w and len(c.warnings()) == 2
 
 
+def test_parameters_nobody_reads_are_reported(hprt, tmp_path):
+    """ParamSet::ReportUnused (core/paramset.cpp:443-459, called after every Make* in core/api.cpp): a parameter that was not looked
+    up is reported — here also when the REFERENCE would have read it and this front-end does not (alpha masks, bump maps, texture
+    mappings), so nothing is dropped silently.  Parameters the path has no use for but the reference reads (film file name, sample
+    counts) are not reported."""
+    tri = '"integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]'
+    m = _parse_text(hprt, tmp_path, 'Film "image" "string filename" "x.exr" "integer xresolution" [8] "integer yresolution" [8] "float diagonal" [35]\n'
+                    'Sampler "halton" "integer pixelsamples" [2] "integer bogus" [1]\nWorldBegin\n'
+                    'Texture "a" "float" "constant" "float value" [.5]\n'
+                    'Material "matte" "rgb Kd" [.5 .5 .5] "texture bumpmap" "a"\n'
+                    'LightSource "point" "rgb I" [1 1 1] "integer nsamples" [4] "float cone" [3]\n'
+                    'AreaLightSource "diffuse" "rgb L" [1 1 1] "integer samples" [2]\n'
+                    'Shape "trianglemesh" ' + tri + ' "texture alpha" "a"\nWorldEnd\n', name="unused.pbrt")
+    w = m.warnings()
+    assert sorted(w) == sorted(['Parameter "integer bogus" of Sampler not used', 'Parameter "texture bumpmap" of Material "matte" not used',
+                                'Parameter "float cone" of LightSource "point" not used', 'alpha masks are outside the hot-path scope; ignored']), w
+
+
 def test_loop_subdivision_of_a_closed_and_an_open_mesh(hprt, tmp_path):
     # octahedron (closed, valence-4 vertices) and a single quad (boundary rules)
     octa = ('Shape "loopsubdiv" "integer nlevels" [2] "integer indices" [0 2 4 2 1 4 1 3 4 3 0 4 2 0 5 1 2 5 3 1 5 0 3 5] '

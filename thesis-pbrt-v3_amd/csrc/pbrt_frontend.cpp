@@ -4,7 +4,9 @@
 // state, named coordinate systems, shape/light/material creation) and produces a
 // SceneModel: world-space shapes in creation order, exactly what MakeScene() hands
 // to the accelerator (core/api.cpp:1883-1892).
+#include <algorithm>
 #include <cstdio>
+#include <initializer_list>
 #include <cstdlib>
 #include <cstring>
 #include <strings.h>
@@ -121,7 +123,18 @@ struct Frontend {
         if (!files.empty()) o << files.back().file << ":" << files.back().line << ": ";
         o << m; err = o.str(); return false;
     }
-    void warn(const std::string &m) { sc->warnings.push_back(m); }
+    void warn(const std::string &m) { if (std::find(sc->warnings.begin(), sc->warnings.end(), m) == sc->warnings.end()) sc->warnings.push_back(m); }
+    // ParamSet::ReportUnused (core/paramset.cpp:443-459): a parameter nobody looked up.  Here that also covers what the reference
+    // WOULD have read but this front-end does not (alpha textures, bump maps, ...): never silently dropped.  `ignored`: names the
+    // reference reads and this path has no use for (file names, sample counts of other integrators).
+    void reportUnused(const ParamList &pl, const std::string &what, std::initializer_list<const char *> ignored = {}) {
+        for (const Param &p : pl.items) {
+            if (p.used) continue;
+            bool skip = false;
+            for (const char *n : ignored) if (p.name == n) skip = true;
+            if (!skip) warn("Parameter \"" + p.type + " " + p.name + "\" of " + what + " not used");
+        }
+    }
 
     bool nextToken(std::string *t) {
         if (hasPending) { *t = pending; hasPending = false; return true; }
@@ -212,9 +225,11 @@ struct Frontend {
                     p.nums[k + 2] = 0.055648f * x - 0.204043f * y + 1.057311f * z;
                 }
                 p.type = "rgb";
-            } else if (p.type == "blackbody" || (p.type == "spectrum" && p.name != "eta" && p.name != "k"))
+            } else if (p.type == "blackbody" || (p.type == "spectrum" && p.name != "eta" && p.name != "k")) {
+                p.used = true;      // (reported here, not again as unused)
                 warn("parameter \"" + p.type + " " + p.name + "\": spectra given as " + (p.type == "blackbody" ? "blackbody temperatures" : "sampled data or files") +
                      " are outside the hot-path scope; the default value is used");
+            }
             pl->items.push_back(p);
         }
         return true;
@@ -309,6 +324,7 @@ struct Frontend {
             m.roughness = hasEta ? floatParam(geom, *mp, "eta", 1.5f) : floatParam(geom, *mp, "index", 1.5f);
             if (floatParam(geom, *mp, "uroughness", 0.f) != 0.f || floatParam(geom, *mp, "vroughness", 0.f) != 0.f)
                 warn("rough glass (MicrofacetTransmission) is outside the hot-path scope; rendered as smooth glass");
+            (void)(mp->find("remaproughness", "bool") || geom.find("remaproughness", "bool"));      // (read by the reference; only rough glass uses it)
         } else if (name == "mirror") {      // CreateMirrorMaterial, materials/mirror.cpp:58-64
             const float dk[3] = {0.9f, 0.9f, 0.9f};
             m.type = kMirror;
@@ -321,6 +337,7 @@ struct Frontend {
             spectrumParam(geom, *mp, "Kd", dk, m.Kd, &m.KdTex);
             m.sigma = floatParam(geom, *mp, "sigma", 0.f);      // != 0: OrenNayar (materials/matte.cpp:55-61)
         }
+        reportUnused(*mp, "Material \"" + name + "\"", {"type"});
         std::string key((const char *)&m, sizeof(m));
         auto it = materialCache.find(key);
         if (it != materialCache.end()) return it->second;
@@ -340,6 +357,7 @@ struct Frontend {
         gs.areaLightParams.rgb3("scale", scv);
         for (int i = 0; i < 3; ++i) l.I[i] = L[i] * scv[i];
         l.twoSided = gs.areaLightParams.oneBool("twosided", false) ? 1 : 0;
+        reportUnused(gs.areaLightParams, "AreaLightSource", {"nsamples", "samples"});
         return l;
     }
 
@@ -555,6 +573,12 @@ struct Frontend {
         o.maxNodePrims = accelParams.oneInt("maxnodeprims", 4);
         o.isectCost = accelParams.oneInt("intersectcost", 8);
         o.travCost = accelParams.oneInt("traversalcost", 1);
+        reportUnused(filmParams, "Film", {"diagonal"});
+        reportUnused(filterParams, "PixelFilter");
+        reportUnused(cameraParams, "Camera");
+        reportUnused(samplerParams, "Sampler");
+        reportUnused(integratorParams, "Integrator", {"pixelbounds"});
+        reportUnused(accelParams, "Accelerator", {"nbDirections", "splitmethod"});
     }
 
     bool run() {
@@ -653,10 +677,16 @@ struct Frontend {
                     }
                     TexConst tc; tc.isFloat = false; tc.v[0] = tc.v[1] = tc.v[2] = 0.f; tc.image = id;
                     gs.textures[name] = tc;
+                    reportUnused(pl, "Texture \"" + name + "\"");
                 } else warn("texture class \"" + tclass + "\" is outside the hot-path scope (constant, spectrum imagemap)");
             } else if (tok == "AreaLightSource") { if (!readQuoted(&gs.areaLight) || !readParams(&gs.areaLightParams)) return false; }
-            else if (tok == "LightSource") { if (!readQuoted(&name) || !readParams(&pl) || !doLight(name, pl)) return false; }
-            else if (tok == "Shape") { if (!readQuoted(&name) || !readParams(&pl) || !doShape(name, pl)) return false; }
+            else if (tok == "LightSource") {
+                if (!readQuoted(&name) || !readParams(&pl) || !doLight(name, pl)) return false;
+                if (name == "point" || name == "distant") reportUnused(pl, "LightSource \"" + name + "\"", {"nsamples", "samples"});
+            } else if (tok == "Shape") {
+                if (!readQuoted(&name) || !readParams(&pl) || !doShape(name, pl)) return false;
+                if (name == "trianglemesh" || name == "loopsubdiv" || name == "plymesh" || name == "sphere") reportUnused(pl, "Shape \"" + name + "\"");
+            }
             else if (tok == "Include") {
                 if (!readQuoted(&name)) return false;
                 if (!pushFile(resolve(name))) return false;
