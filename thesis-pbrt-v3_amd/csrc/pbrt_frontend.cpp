@@ -530,6 +530,7 @@ struct Frontend {
     void finishOptions() {
         RenderOptions &o = sc->opt;
         // CreateFilm, core/film.cpp:310-349
+        if (filmName != "image") warn("Film \"" + filmName + "\" unknown (core/api.cpp:1004-1014); \"image\" used");
         o.filename = filmParams.oneString("filename", "pbrt.exr");
         o.xres = filmParams.oneInt("xresolution", 1280);
         o.yres = filmParams.oneInt("yresolution", 720);
