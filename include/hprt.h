@@ -149,12 +149,16 @@ typedef struct HprtTextureDesc {
     const float *weight_lut;         /* MIPMap::weightLut, 128 floats */
 } HprtTextureDesc;
 
-typedef struct HprtLightDesc {       /* lights/point.cpp, lights/distant.cpp, lights/diffuse.cpp */
-    int32_t type;                    /* 0 point, 1 distant, 2 diffuse area */
+typedef struct HprtLightDesc {       /* lights/point.cpp, lights/distant.cpp, lights/diffuse.cpp, lights/infinite.cpp */
+    int32_t type;                    /* 0 point, 1 distant, 2 diffuse area, 3 infinite */
     float pos[3];                    /* point: pLight (world); distant: wLight (world, normalised) */
     float I[3];                      /* I / L / Lemit */
     int32_t shape;                   /* area light: shape index */
     int32_t two_sided;
+    /* infinite: the radiance map is textures[texture] — its texels as InfiniteAreaLight holds them (ReadImage order, not flipped,
+     * already multiplied by L * scale; 1x1 for a constant light) — and the light <-> world transform, row-major */
+    int32_t texture;
+    float light_to_world[16], world_to_light[16];
 } HprtLightDesc;
 
 /* Object instancing (pbrtObjectBegin/End/Instance, core/api.cpp:1752-1820; TransformedPrimitive,

@@ -334,6 +334,46 @@ struct Distribution1D {
     }
 };
 
+// Distribution1D::SampleContinuous (core/sampling.h:85-103) and Distribution2D (core/sampling.h:128-151, core/sampling.cpp:97-108)
+inline Float SampleContinuous1D(const Distribution1D &d, Float u, Float *pdf, int *off = nullptr) {
+    int size = (int)d.cdf.size();
+    int first = 0, len = size;    // FindInterval, pbrt.h:403-415
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (d.cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    int offset = Clamp(first - 1, 0, size - 2);
+    if (off) *off = offset;
+    Float du = u - d.cdf[offset];
+    if ((d.cdf[offset + 1] - d.cdf[offset]) > 0) du /= (d.cdf[offset + 1] - d.cdf[offset]);
+    if (pdf) *pdf = (d.funcInt > 0) ? d.func[offset] / d.funcInt : 0;
+    return (offset + du) / d.Count();
+}
+struct Distribution2D {
+    std::vector<Distribution1D> conditional;
+    Distribution1D marginal;
+    void Init(const Float *func, int nu, int nv) {
+        conditional.resize(nv);
+        for (int v = 0; v < nv; ++v) conditional[v].Init(&func[(size_t)v * nu], nu);
+        std::vector<Float> m(nv);
+        for (int v = 0; v < nv; ++v) m[v] = conditional[v].funcInt;
+        marginal.Init(m.data(), nv);
+    }
+    P2 SampleContinuous(const P2 &u, Float *pdf) const {
+        Float pdfs[2]; int v;
+        Float d1 = SampleContinuous1D(marginal, u.y, &pdfs[1], &v);
+        Float d0 = SampleContinuous1D(conditional[v], u.x, &pdfs[0]);
+        *pdf = pdfs[0] * pdfs[1];
+        P2 r; r.x = d0; r.y = d1; return r;
+    }
+    Float Pdf(const P2 &p) const {
+        int iu = Clamp(int(p.x * conditional[0].Count()), 0, conditional[0].Count() - 1);
+        int iv = Clamp(int(p.y * marginal.Count()), 0, marginal.Count() - 1);
+        return conditional[iv].func[iu] / marginal.funcInt;
+    }
+};
+
 struct Renderer {
     Scene scene;
     BVH bvh;                       // top-level aggregate
@@ -350,6 +390,8 @@ struct Renderer {
     mutable std::mutex voxelMutex;
     mutable std::unordered_map<uint64_t, std::unique_ptr<Distribution1D>> voxelDist;
     Float worldRadius = 0; V3 worldCenter;
+    std::vector<Distribution2D> envDist;      // per light; filled for infinite lights (lights/infinite.cpp:66-85)
+    bool hasInfinite = false;
     int nThreads = 1;
     Counters total;
     double renderSeconds = 0;
@@ -381,6 +423,29 @@ struct Renderer {
         bool inside = worldCenter.x >= wb.pMin.x && worldCenter.x <= wb.pMax.x && worldCenter.y >= wb.pMin.y &&
                       worldCenter.y <= wb.pMax.y && worldCenter.z >= wb.pMin.z && worldCenter.z <= wb.pMax.z;
         worldRadius = inside ? Distance(worldCenter, wb.pMax) : 0;
+        // InfiniteAreaLight's sampling distribution: a (2w x 2h) image of the map's luminance times sin(theta) (lights/infinite.cpp:66-85)
+        envDist.resize(scene.lights.size());
+        for (size_t li = 0; li < scene.lights.size(); ++li) {
+            const Light &l = scene.lights[li];
+            if (l.type != LIGHT_INFINITE) continue;
+            if (l.tex < 0 || l.tex >= (int)scene.textures.size()) { *err = "infinite light without a map"; return false; }
+            hasInfinite = true;
+            const Texture &tx = scene.textures[l.tex];
+            const int width = 2 * tx.levels[0].w, height = 2 * tx.levels[0].h;
+            std::vector<Float> img((size_t)width * height);
+            const float fwidth = 0.5f / smin(width, height);
+            for (int v = 0; v < height; ++v) {
+                Float vp = (v + .5f) / (Float)height;
+                Float sinTheta = m_sinf(Pi * (v + .5f) / height);
+                for (int u = 0; u < width; ++u) {
+                    Float up = (u + .5f) / (Float)width;
+                    P2 st; st.x = up; st.y = vp;
+                    img[u + (size_t)v * width] = MipLookupWidth(tx, st, fwidth).y();
+                    img[u + (size_t)v * width] *= sinTheta;
+                }
+            }
+            envDist[li].Init(img.data(), width, height);
+        }
         // CreateLightSampleDistribution, core/lightdistrib.cpp:48-66
         const int strategy = scene.lights.size() <= 1 ? 0 : scene.prm.lightStrategy;
         std::vector<Float> prob(smax<size_t>(1, scene.lights.size()), Float(1));
@@ -421,10 +486,21 @@ struct Renderer {
         int al = AreaLightOf(isect);
         return al >= 0 ? AreaL(scene.lights[al], isect.n, w) : Spec(0.f);
     }
+    // SphericalTheta / SphericalPhi, core/geometry.h:1816-1824
+    static Float SphericalTheta(const V3 &v) { return m_acosf(Clamp(v.z, -1, 1)); }
+    static Float SphericalPhi(const V3 &v) { Float p = m_atan2f(v.y, v.x); return (p < 0) ? (p + 2 * Pi) : p; }
+    // Light::Le(ray): radiance an escaped ray picks up (core/light.cpp:66; InfiniteAreaLight::Le, lights/infinite.cpp:93-97)
+    Spec LightLe(const Light &l, const V3 &d) const {
+        if (l.type != LIGHT_INFINITE) return Spec(0.f);
+        V3 w = Normalize(XfVector(l.w2l, d));
+        P2 st; st.x = SphericalPhi(w) * Inv2Pi; st.y = SphericalTheta(w) * InvPi;
+        return MipLookupWidth(scene.textures[l.tex], st, 0.f);
+    }
     // Light::Power: lights/point.cpp:55, lights/distant.cpp:61-63, lights/diffuse.cpp:64-66 (area = shape->Area())
     Spec LightPower(const Light &l) const {
         if (l.type == LIGHT_POINT) return 4 * Pi * l.I;
         if (l.type == LIGHT_DISTANT) return l.I * Pi * worldRadius * worldRadius;
+        if (l.type == LIGHT_INFINITE) { P2 c; c.x = .5f; c.y = .5f; return Pi * worldRadius * worldRadius * MipLookupWidth(scene.textures[l.tex], c, .5f); }   // lights/infinite.cpp:87-91
         const ShapeRec &sh = scene.shapes[l.shape];
         Float area;
         if (sh.kind == SHAPE_MESH) {
@@ -490,6 +566,18 @@ struct Renderer {
             V3 pOutside = ref.p + l.pos * (2 * worldRadius);
             pLight->p = pOutside; pLight->pError = V3(); pLight->n = V3();
             return l.I;
+        } else if (l.type == LIGHT_INFINITE) { // lights/infinite.cpp:99-124
+            Float mapPdf;
+            P2 uv = envDist[&l - scene.lights.data()].SampleContinuous(u, &mapPdf);
+            if (mapPdf == 0) { *pdf = 0; return Spec(0.f); }      // (the reference leaves *pdf untouched: its caller initialised it to 0)
+            Float theta = uv.y * Pi, phi = uv.x * 2 * Pi;
+            Float cosTheta = m_cosf(theta), sinTheta = m_sinf(theta);
+            Float sinPhi = m_sinf(phi), cosPhi = m_cosf(phi);
+            *wi = XfVector(l.l2w, V3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
+            *pdf = mapPdf / (2 * Pi * Pi * sinTheta);
+            if (sinTheta == 0) *pdf = 0;
+            pLight->p = ref.p + *wi * (2 * worldRadius); pLight->pError = V3(); pLight->n = V3();
+            return MipLookupWidth(scene.textures[l.tex], uv, 0.f);
         } else {                              // lights/diffuse.cpp:68-81
             const ShapeRec &sh = scene.shapes[l.shape];
             Interaction pShape;
@@ -506,6 +594,14 @@ struct Renderer {
     }
     // Light::Pdf_Li: point/distant 0; area -> Sphere::Pdf (shapes/sphere.cpp:294-306)
     Float Pdf_Li(const Light &l, const Interaction &ref, const V3 &wi, Counters &ctr) const {
+        if (l.type == LIGHT_INFINITE) {       // lights/infinite.cpp:126-134
+            V3 w = XfVector(l.w2l, wi);
+            Float theta = SphericalTheta(w), phi = SphericalPhi(w);
+            Float sinTheta = m_sinf(theta);
+            if (sinTheta == 0) return 0;
+            P2 st; st.x = phi * Inv2Pi; st.y = theta * InvPi;
+            return envDist[&l - scene.lights.data()].Pdf(st) / (2 * Pi * Pi * sinTheta);
+        }
         if (l.type != LIGHT_AREA) return 0;
         const ShapeRec &sh = scene.shapes[l.shape];
         if (sh.kind == SHAPE_MESH) {
@@ -551,7 +647,7 @@ struct Renderer {
         Interaction it{isect.p, isect.pError, isect.n};
         Interaction pLight;
         Spec Li = Sample_Li(light, it, uLight, &wi, &lightPdf, &pLight);
-        bool isDelta = (light.type == LIGHT_POINT || light.type == LIGHT_DISTANT);
+        bool isDelta = (light.type == LIGHT_POINT || light.type == LIGHT_DISTANT);      // IsDeltaLight(flags): an infinite light is not
         if (lightPdf > 0 && !Li.IsBlack()) {
             Spec f = bsdf.f(isect.wo, wi, bsdfFlags) * AbsDot(wi, isect.shading.n);
             scatteringPdf = bsdf.Pdf(isect.wo, wi, bsdfFlags);
@@ -586,7 +682,7 @@ struct Renderer {
                 Spec Li2(0.f);
                 if (found) {
                     if (AreaLightOf(lightIsect) == lightNum) Li2 = Le(lightIsect, -wi);
-                }   // else light.Le(ray) == 0 for area lights (core/light.cpp:66)
+                } else Li2 = LightLe(light, ray.d);      // light.Le(ray): zero except for infinite lights (core/light.cpp:66, lights/infinite.cpp:93-97)
                 if (!Li2.IsBlack()) Ld += f * Li2 * Spec(1.f) * weight / scatteringPdf;
             }
         }
@@ -619,6 +715,7 @@ struct Renderer {
             bool foundIntersection = SceneIntersect(ray, &isect, ctr);
             if (bounces == 0 || specularBounce) {
                 if (foundIntersection) L += beta * Le(isect, -ray.d);
+                else for (const Light &l : scene.lights) if (l.type == LIGHT_INFINITE) L += beta * LightLe(l, ray.d);      // scene.infiniteLights, path.cpp:104-106
             }
             if (!foundIntersection || bounces >= maxDepth) break;
             BSDF bsdf;

@@ -14,7 +14,7 @@ namespace orc {
 
 enum { MAT_MATTE = 0, MAT_PLASTIC = 1, MAT_MIRROR = 2, MAT_SUBSTRATE = 3, MAT_METAL = 4, MAT_GLASS = 5 };      // glass: Kd = Kt, Ks = Kr, roughness = eta
 // mirror: Kr travels in Ks; substrate: roughness = uroughness, sigma = vroughness; metal: Kd = eta, Ks = k, roughness / sigma likewise
-enum { LIGHT_POINT = 0, LIGHT_DISTANT = 1, LIGHT_AREA = 2 };
+enum { LIGHT_POINT = 0, LIGHT_DISTANT = 1, LIGHT_AREA = 2, LIGHT_INFINITE = 3 };
 enum { SHAPE_MESH = 0, SHAPE_SPHERE = 1 };
 
 struct Material {
@@ -55,6 +55,10 @@ struct Light {
     Spec I;      // point: I; distant: L; area: Lemit
     int shape;   // area: shape index
     int twoSided;
+    // infinite (lights/infinite.cpp): the radiance map is texture `tex` (texels already multiplied by L * scale, a 1x1 map for a
+    // constant light); light <-> world
+    int tex = -1;
+    M44 l2w, w2l;
 };
 struct SceneParams {
     int xres, yres;
@@ -103,7 +107,7 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
     char magic[8]; r.raw(magic, 8);
     if (!r.ok || memcmp(magic, "HPRTSCN1", 8) != 0) { *err = "bad magic"; return false; }
     uint32_t version = r.u32();
-    if (version < 1 || version > 3) { *err = "bad version"; return false; }
+    if (version < 1 || version > 4) { *err = "bad version"; return false; }
     SceneParams &p = sc->prm;
     p.xres = r.i32(); p.yres = r.i32();
     for (int i = 0; i < 4; ++i) p.crop[i] = r.f32();
@@ -211,6 +215,14 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
         for (auto &m : sc->materials)
             if (m.KdTex >= (int)nTex || m.KsTex >= (int)nTex) { *err = "bad material texture index"; return false; }
     }
+    if (version >= 4) {      // infinite lights: map + transform
+        for (auto &l : sc->lights)
+            if (l.type == LIGHT_INFINITE) {
+                l.tex = r.i32(); r.raw(l.l2w.m, 64); r.raw(l.w2l.m, 64);
+                if (!r.ok || l.tex < 0 || l.tex >= (int)sc->textures.size()) { *err = "bad infinite light"; return false; }
+            }
+    } else
+        for (auto &l : sc->lights) if (l.type == LIGHT_INFINITE) { *err = "infinite light in a container older than version 4"; return false; }
     if (!r.ok) { *err = "truncated file"; return false; }
     return true;
 }

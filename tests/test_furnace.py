@@ -8,8 +8,9 @@ asserts that the mean over all pixels and channels is within 0.02 of 1.0 (CheckS
 written as the .pbrt text that builds exactly those objects through the front-end, are held to the same bound over the
 oracle (CPU test) and over the HIP path, which must also equal the oracle's film bit for bit (GPU test).  Scene 3 shades
 points that lie INSIDE their own emitter (Sphere::Sample's uniform-area branch, shapes/sphere.cpp:236-252), the path the
-material-specialised shading kernels hand over to the generic one.  Scene 2 (four point lights) needs the spatial light
-distribution and scene 4 UberMaterial: both outside the hot-path scope."""
+material-specialised shading kernels hand over to the generic one.  Scene 2 (:100-133) is scene 1 with four point lights of pi/4
+each: more than one light, so the reference's default SpatialLightDistribution picks among them.  Scenes 4 and 5 use UberMaterial
+(outside the hot-path scope)."""
 import numpy as np
 import pytest
 
@@ -35,6 +36,15 @@ SCENES["box_triangle_area_lights"] = (
     'Material "matte" "color Kd" [.5 .5 .5]\nAreaLightSource "diffuse" "color L" [.5 .5 .5]\n'
     'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3  4 6 5 4 7 6  0 4 5 0 5 1  1 5 6 1 6 2  2 6 7 2 7 3  3 7 4 3 4 0] '
     '"point P" [-1 -1 -1  1 -1 -1  1 1 -1  -1 1 -1  -1 -1 1  1 -1 1  1 1 1  -1 1 1]\nWorldEnd\n')
+# scene 2 (:100-133): PointLight(Transform(), nullptr, Spectrum(Pi / 4)) four times; float(Pi / 4) = 0.785398185
+SCENES["sphere_four_point_lights"] = (HEAD + 4 * 'LightSource "point" "color I" [0.78539819 0.78539819 0.78539819]\n' +
+                                      'Material "matte" "color Kd" [.5 .5 .5]\nReverseOrientation\nShape "sphere" "float radius" [1]\nWorldEnd\n')
+# Not one of the reference's scenes: its analytic set has no infinite light.  The same furnace lit by the environment alone cannot
+# work (the closed sphere hides it), so the check is the open counterpart: a convex matte object (Kd = 0.5) floating in a constant
+# environment of radiance 1 reflects exactly Kd * 1 towards every viewer — no inter-reflection, every bounce escapes — and the
+# background is 1.  The camera sits close enough that the unit sphere fills the 10x10 film.
+ENV_SCENE = ('LookAt 0 0 1.6  0 0 0  0 1 0\n' + HEAD + 'LightSource "infinite" "rgb L" [1 1 1]\n'
+             'Material "matte" "color Kd" [.5 .5 .5]\nShape "sphere" "float radius" [1]\nWorldEnd\n')
 DELTA = 0.02      # analytic_scenes.cpp:59
 
 
@@ -73,3 +83,31 @@ def test_device_furnace_equals_oracle(hprt, orc, tmp_path, name):
     assert np.array_equal(rgb0.view(np.uint32), rgb1.view(np.uint32))
     assert abs(float(rgb1.mean(dtype=np.float64)) - 1.0) < DELTA
     assert st["rays"] == c0["rays"] and st["shadow_rays"] == c0["shadow_rays"]      # (the oracle's sphere_tests also counts the quadric tests inside Shape::Pdf)
+
+
+def test_oracle_matte_sphere_in_a_white_environment(hprt, orc, tmp_path):
+    p = tmp_path / "env.pbrt"
+    p.write_text(ENV_SCENE)
+    model = hprt.Model.parse(str(p))
+    assert model.warnings() == []
+    baked = str(tmp_path / "env.hprt")
+    model.save(baked)
+    rgb = orc.OracleScene(baked).render(threads=4)[0]
+    assert abs(float(rgb.mean(dtype=np.float64)) - 0.5) < DELTA, float(rgb.mean())
+    assert 0.4 < rgb.min() and rgb.max() < 0.6
+
+
+@pytest.mark.gpu
+def test_device_white_environment_equals_oracle(hprt, orc, tmp_path):
+    p = tmp_path / "env.pbrt"
+    p.write_text(ENV_SCENE)
+    model = hprt.Model.parse(str(p))
+    baked = str(tmp_path / "env.hprt")
+    model.save(baked)
+    _, film0, c0, _, _ = orc.OracleScene(baked).render(threads=4)
+    scene = hprt.Scene(model, hprt.Bvh(model))
+    film1, st = scene.render(count_work=True)
+    assert np.array_equal(film0.view(np.uint32), film1.view(np.uint32))
+    assert st["rays"] == c0["rays"] and st["shadow_rays"] == c0["shadow_rays"]
+    rgb1 = hprt.film_resolve(film1, model.options.film_scale)
+    assert abs(float(rgb1.mean(dtype=np.float64)) - 0.5) < DELTA

@@ -141,6 +141,16 @@ CASES = {
     "emissive_mesh_power": _scene(MATTE + 'Shape "trianglemesh" ' + FLOOR + '\nAttributeBegin\nTranslate 0 0 1.5\nScale .3 .3 .6\nAreaLightSource "diffuse" "color L" [4 4 4]\n' +
                                   PLASTIC + 'Shape "trianglemesh" ' + _grid_mesh(5, 5, lambda x, y: 0.25 * np.sin(2.3 * x) * np.cos(1.7 * y)) + "\nAttributeEnd\n" + PLASTIC +
                                   'Shape "trianglemesh" ' + BUMPY + "\n", integ='"string lightsamplestrategy" "power"', maxdepth=4),
+    # InfiniteAreaLight with a constant radiance (scenes/triangles of the reference): a 1x1 map; alone (escaped camera rays show it),
+    # with a mirror and a glass sphere (specular segments that escape pick it up), and as one of three lights of every strategy
+    "infinite_constant": _scene('LightSource "infinite" "rgb L" [.4 .45 .5]\n' + GEOM),
+    "infinite_mirror_glass": _scene('AttributeBegin\nRotate 30 1 0 0\nLightSource "infinite" "rgb L" [.9 .8 .6] "rgb scale" [.5 .5 1]\nAttributeEnd\n' + MATTE +
+                                    'Shape "trianglemesh" ' + FLOOR + '\nMaterial "mirror"\nShape "trianglemesh" ' + BUMPY + '\nAttributeBegin\nMaterial "glass"\n'
+                                    'Translate -1.0 -.2 .55\nShape "sphere" "float radius" [.5]\nAttributeEnd\n', spp=8),
+    "infinite_point_sphere_uniform": _scene('LightSource "infinite" "rgb L" [.2 .25 .3]\nLightSource "point" "point from" [1 -2 4] "color I" [20 5 5]\n' + SPHERE_LIGHT + GEOM, integ=UNIFORM),
+    "infinite_point_sphere_power": _scene('LightSource "infinite" "rgb L" [.2 .25 .3]\nLightSource "point" "point from" [1 -2 4] "color I" [20 5 5]\n' + SPHERE_LIGHT + GEOM,
+                                          integ='"string lightsamplestrategy" "power"'),
+    "infinite_point_sphere_spatial": _scene('LightSource "infinite" "rgb L" [.2 .25 .3]\nLightSource "point" "point from" [1 -2 4] "color I" [20 5 5]\n' + SPHERE_LIGHT + GEOM),
     "no_lights": _scene(GEOM),
     "empty_scene": _scene(""),
     "light_only": _scene(SPHERE_LIGHT),

@@ -63,6 +63,11 @@ CASES = {
                                     'AttributeBegin\nTranslate 1.1 -.3 .1\nRotate -40 .2 .1 1\nScale 1.2 .8 1\nObjectInstance "o"\nAttributeEnd\n'
                                     'AttributeBegin\nTranslate 0 1.4 .3\nScale 1 -1 1\nObjectInstance "o"\nAttributeEnd\n',
                                     cam='"float lensradius" [0.08] "float focaldistance" [6.5]', spp=4, maxdepth=4),
+    # InfiniteAreaLight with a radiance map (lights/infinite.cpp): a 57 x 33 PFM (resampled to 64 x 64, NOT flipped), rotated, scaled;
+    # importance-sampled through its Distribution2D, seen directly, through a mirror, and by BSDF-sampled rays that escape
+    "infinite_map": _scene('AttributeBegin\nRotate -90 1 0 0\nRotate 40 0 0 1\nLightSource "infinite" "string mapname" "%(dir)s/hdr.pfm" "rgb L" [.8 .8 1] "rgb scale" [1.5 1.5 1.5]\nAttributeEnd\n' +
+                           MATTE + 'Shape "trianglemesh" ' + FLOOR + '\nMaterial "plastic" "color Kd" [.2 .3 .5] "color Ks" [.6 .6 .6] "float roughness" [.08]\nShape "trianglemesh" ' + BUMPY +
+                           '\nAttributeBegin\nMaterial "mirror"\nTranslate 1.2 .4 .6\nShape "sphere" "float radius" [.45]\nAttributeEnd\n', xres=128, yres=96, spp=8),
     # one sample per pixel (differential scale 1), and far minification (grazing floor up to the horizon)
     "spp1_grazing": """LookAt 0 -3.9 -0.25  0 4 -0.45  0 0 1
 Camera "perspective" "float fov" [55]

@@ -98,7 +98,8 @@ class MaterialDesc(C.Structure):
 
 
 class LightDesc(C.Structure):
-    _fields_ = [("type", C.c_int32), ("pos", C.c_float * 3), ("I", C.c_float * 3), ("shape", C.c_int32), ("two_sided", C.c_int32)]
+    _fields_ = [("type", C.c_int32), ("pos", C.c_float * 3), ("I", C.c_float * 3), ("shape", C.c_int32), ("two_sided", C.c_int32),
+                ("texture", C.c_int32), ("light_to_world", C.c_float * 16), ("world_to_light", C.c_float * 16)]
 
 
 class SceneDesc(C.Structure):

@@ -202,6 +202,38 @@ void AddTilePixels(FrameSetup *f, int tile) {
 
 extern "C" {
 
+// MIPMap<RGBSpectrum>::Lookup(st, width) on the host, over an HprtTextureDesc (core/mipmap.h:203-260; repeat wrap): the same
+// float operations as the device's mip_triangle / the oracle's MipLookupWidth.  Used once per infinite light for the scalar image
+// of its Distribution2D (lights/infinite.cpp:66-85) and for Power() (:87-91).
+namespace {
+inline int HostModI(int a, int b) { const int r = a - (a / b) * b; return r < 0 ? r + b : r; }
+inline rgb HostMipTexel(const HprtTextureDesc &tx, int level, int s, int t) {
+    const HprtTextureLevel &l = tx.levels[level];
+    s = HostModI(s, l.w); t = HostModI(t, l.h);
+    const float *p = l.rgb + 3 * ((size_t)t * (size_t)l.w + (size_t)s);
+    return rgb(p[0], p[1], p[2]);
+}
+inline rgb HostMipTriangle(const HprtTextureDesc &tx, int level, float su, float sv) {
+    level = level < 0 ? 0 : (level > (int)tx.n_levels - 1 ? (int)tx.n_levels - 1 : level);
+    const HprtTextureLevel &l = tx.levels[level];
+    const float s = su * l.w - 0.5f, t = sv * l.h - 0.5f;
+    const int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
+    const float ds = s - s0, dt = t - t0;
+    return (1 - ds) * (1 - dt) * HostMipTexel(tx, level, s0, t0) + (1 - ds) * dt * HostMipTexel(tx, level, s0, t0 + 1) +
+           ds * (1 - dt) * HostMipTexel(tx, level, s0 + 1, t0) + ds * dt * HostMipTexel(tx, level, s0 + 1, t0 + 1);
+}
+inline rgb HostMipLookupWidth(const HprtTextureDesc &tx, float su, float sv, float width) {
+    const int nLevels = (int)tx.n_levels;
+    const float invLog2 = 1.442695040888963387004650940071;
+    const float level = nLevels - 1 + det_logf(sel_max(width, (float)1e-8)) * invLog2;
+    if (level < 0) return HostMipTriangle(tx, 0, su, sv);
+    else if (level >= nLevels - 1) return HostMipTexel(tx, nLevels - 1, 0, 0);
+    const int iLevel = (int)std::floor(level);
+    const float delta = level - iLevel;
+    return (1 - delta) * HostMipTriangle(tx, iLevel, su, sv) + delta * HostMipTriangle(tx, iLevel + 1, su, sv);
+}
+}  // namespace
+
 int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     if (!d || !out) return SetError(HPRT_E_INVALID, "hprt_scene_create: null argument");
     if ((d->n_nodes && !d->nodes) || (d->n_prims && !d->prim_order) || (d->n_shapes && !d->shapes) ||
@@ -302,7 +334,13 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     const uint32_t totalPrims = primBase[aggs.size()];
     for (uint32_t l = 0; l < d->n_lights; ++l) {
         const HprtLightDesc &L = d->lights[l];
-        if (L.type < 0 || L.type > 2) return SetError(HPRT_E_INVALID, "unknown light type");
+        if (L.type < 0 || L.type > 3) return SetError(HPRT_E_INVALID, "unknown light type");
+        if (L.type == 3) {
+            if (L.texture < 0 || (uint32_t)L.texture >= d->n_textures) return SetError(HPRT_E_INVALID, "infinite light: map index out of range");
+            const HprtTextureDesc &mt = d->textures[L.texture];
+            if (!mt.levels || mt.n_levels == 0 || mt.n_levels > 26 || mt.wrap != 0) return SetError(HPRT_E_INVALID, "infinite light: its map must be a repeat-wrapped pyramid of at most 26 levels");
+            if ((uint64_t)mt.levels[0].w * (uint64_t)mt.levels[0].h > (1ull << 26)) return SetError(HPRT_E_UNSUPPORTED, "infinite light: map larger than 2^26 texels");
+        }
         if (L.type == 2) {
             if (L.shape < 0 || (uint32_t)L.shape >= d->n_shapes) return SetError(HPRT_E_INVALID, "area light shape out of range");
             const HprtShapeDesc &ls = d->shapes[L.shape];
@@ -440,6 +478,41 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
         o.sphere = in.type == 2 && !onMesh ? sphereOfShape[in.shape] : -1;
         o.shapeFlags = in.type == 2 ? shapes[in.shape].flags : 0u;
     }
+    // infinite lights: the scalar image of lights/infinite.cpp:66-85 (2w x 2h: luminance of the filtered map times sin theta) and
+    // its Distribution2D, built with the float operations of Distribution1D's constructor (hprt_math.h dist1d_build)
+    std::vector<DevEnvLight> envLights;
+    std::vector<float> envData;
+    for (uint32_t l = 0; l < d->n_lights; ++l) {
+        const HprtLightDesc &in = d->lights[l];
+        if (in.type != 3) continue;
+        const HprtTextureDesc &tx = d->textures[in.texture];
+        DevEnvLight e; memset(&e, 0, sizeof(e));
+        memcpy(&e.l2w, in.light_to_world, 64); memcpy(&e.w2l, in.world_to_light, 64);
+        e.tex = in.texture;
+        const int width = 2 * tx.levels[0].w, height = 2 * tx.levels[0].h;
+        e.nu = width; e.nv = height; e.off = (uint32_t)envData.size();
+        const size_t nFloats = (size_t)height * width + (size_t)height * (width + 1) + (size_t)height + (size_t)height + 1;
+        if (envData.size() + nFloats > 0x7fffffffull) return SetError(HPRT_E_UNSUPPORTED, "infinite light maps too large");
+        envData.resize(envData.size() + nFloats);
+        float *condFunc = envData.data() + e.off, *condCdf = condFunc + (size_t)height * width, *condInt = condCdf + (size_t)height * (width + 1),
+              *margCdf = condInt + height;
+        const float fwidth = 0.5f / std::min(width, height);
+        for (int v = 0; v < height; ++v) {
+            const float vp = (v + .5f) / (float)height;
+            const float sinTheta = det_sinf(HPRT_PI * (v + .5f) / height);
+            for (int u = 0; u < width; ++u) {
+                const float up = (u + .5f) / (float)width;
+                float y = luminance(HostMipLookupWidth(tx, up, vp, fwidth));
+                y *= sinTheta;
+                condFunc[(size_t)v * width + u] = y;
+            }
+            dist1d_build(condFunc + (size_t)v * width, width, condCdf + (size_t)v * (width + 1), &condInt[v]);
+        }
+        dist1d_build(condInt, height, margCdf, &e.margFuncInt);
+        DevLight &o = lights[l];
+        o.type = 4; o.shape = (int32_t)envLights.size();
+        envLights.push_back(e);
+    }
     // Scene::worldBound + Bounds3::BoundingSphere (core/scene.h:56-66, core/geometry.h:980-983)
     float worldRadius = 0.f;
     vec3 wbLo, wbHi;
@@ -460,6 +533,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
             rgb power;
             if (in.type == 0) power = I * (4 * HPRT_PI);                                      // lights/point.cpp:55
             else if (in.type == 1) power = I * HPRT_PI * worldRadius * worldRadius;          // lights/distant.cpp:61-63
+            else if (in.type == 3) power = HPRT_PI * worldRadius * worldRadius * HostMipLookupWidth(d->textures[in.texture], .5f, .5f, .5f);   // lights/infinite.cpp:87-91
             else {                                                                            // lights/diffuse.cpp:64-66, area = shape->Area()
                 const HprtShapeDesc &ls = d->shapes[in.shape];
                 float area;
@@ -563,6 +637,8 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     dv.materials = sc->materials.as<DevMaterial>();
     dv.lights = sc->lights.as<DevLight>(); dv.nLights = d->n_lights;
     dv.spheres = sc->spheres.as<DevSphere>(); dv.nSpheres = (uint32_t)spheres.size();
+    HIP_TRY(upload(sc->envLights, envLights)); HIP_TRY(upload(sc->envData, envData));
+    dv.envLights = sc->envLights.as<DevEnvLight>(); dv.envData = sc->envData.as<float>(); dv.nEnvLights = (uint32_t)envLights.size();
     dv.textures = d->n_textures ? sc->textures.as<DevTexture>() : nullptr; dv.mipLevels = sc->mipLevels.as<DevMipLevel>();
     dv.texels = sc->texels.as<float>(); dv.weightLut = sc->weightLut.as<float>();
     dv.instances = sc->instances.as<DevInstance>(); dv.nInstances = d->n_instances;
@@ -648,6 +724,7 @@ int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int devic
     for (size_t i = 0; i < lights.size(); ++i) {
         const LightDesc &s = sm.lights[i];
         lights[i].type = s.type; memcpy(lights[i].pos, s.pos, 12); memcpy(lights[i].I, s.I, 12); lights[i].shape = s.shape; lights[i].two_sided = s.twoSided;
+        lights[i].texture = s.texture; memcpy(lights[i].light_to_world, &s.lightToWorld, 64); memcpy(lights[i].world_to_light, &s.worldToLight, 64);
     }
     if (b->objects.size() != sm.nObjects) return SetError(HPRT_E_INVALID, "the BVH was built for another model (object count differs)");
     // object definitions: their shapes are contiguous (no nesting of definitions, core/api.cpp:1755-1756)

@@ -66,6 +66,10 @@ struct DevTexture { uint32_t firstLevel, nLevels; int32_t trilinear, wrap; float
 // every triangle of an emissive mesh is a light of its own, core/api.cpp:1609-1636)
 struct DevLight { int32_t type; float pos[3]; float I[3]; int32_t shape; int32_t twoSided; int32_t sphere; uint32_t shapeFlags; int32_t prim; };
 struct DevSphere { mat4 o2w, w2o; float radius, zMin, zMax, thetaMin, thetaMax, phiMax; };
+// InfiniteAreaLight (lights/infinite.cpp): DevLight type 4, DevLight::shape indexes this table.  Its Distribution2D (core/sampling.h:
+// 128-151) sits in DevScene::envData at `off`: condFunc[nv][nu], condCdf[nv][nu + 1], condFuncInt[nv] (= the marginal's func),
+// margCdf[nv + 1]; margFuncInt here.
+struct DevEnvLight { mat4 l2w, w2l; int32_t tex; int32_t nu, nv; uint32_t off; float margFuncInt; float pad[3]; };
 // ObjectInstance: the wrapped aggregate's entry (pair index, or ~primitive when the object holds a
 // single primitive: no aggregate, no bounds test) and the static instance transform
 struct DevInstance { mat4 i2w, w2i; int32_t root; uint32_t identity; uint32_t pad[2]; };
@@ -81,6 +85,7 @@ struct DevScene {
     const DevLight *lights; uint32_t nLights;
     const DevTexture *textures; const DevMipLevel *mipLevels; const float *texels; const float *weightLut;   // image textures; weightLut: MIPMap::weightLut[128]
     const DevSphere *spheres; uint32_t nSpheres;
+    const DevEnvLight *envLights; const float *envData; uint32_t nEnvLights;      // infinite lights (escaped rays pick up their radiance)
     const DevInstance *instances; uint32_t nInstances;
     const float *lightFunc, *lightCdf; float lightFuncInt;      // Distribution1D (core/sampling.h:55-109): uniform or power strategy
     // SpatialLightDistribution (core/lightdistrib.cpp:77-300), computed for every voxel at scene creation: per voxel v the

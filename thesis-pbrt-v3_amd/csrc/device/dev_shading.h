@@ -867,6 +867,56 @@ __device__ __forceinline__ bool triangle_may_hit(const DevScene &sc, int32_t pri
     const RayShear sh = ray_shear(r.d);
     return tri_test(vec3(v0.x, v0.y, v0.z), vec3(v1.x, v1.y, v1.z), vec3(v2.x, v2.y, v2.z), r.o, r.tMax, sh, b0, b1, b2, t);
 }
+// ---- InfiniteAreaLight (lights/infinite.cpp) -----------------------------------------------------------------------------
+// Distribution1D::SampleContinuous (core/sampling.h:85-103) over a cdf / func pair of n entries
+__device__ __forceinline__ float dist1d_sample_continuous(const float *cdf, const float *func, float funcInt, int n, float u, float *pdf, int *off) {
+    const int size = n + 1;
+    int first = 0, len = size;      // FindInterval, core/pbrt.h:403-415
+    while (len > 0) {
+        const int half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    int offset = first - 1;
+    offset = offset < 0 ? 0 : (offset > size - 2 ? size - 2 : offset);
+    *off = offset;
+    float du = u - cdf[offset];
+    if ((cdf[offset + 1] - cdf[offset]) > 0) du /= (cdf[offset + 1] - cdf[offset]);
+    *pdf = (funcInt > 0) ? func[offset] / funcInt : 0;
+    return (offset + du) / n;
+}
+struct DevEnvTables { const float *condFunc, *condCdf, *condInt, *margCdf; };
+__device__ __forceinline__ DevEnvTables env_tables(const DevScene &sc, const DevEnvLight &e) {
+    DevEnvTables t;
+    t.condFunc = sc.envData + e.off; t.condCdf = t.condFunc + (size_t)e.nv * e.nu; t.condInt = t.condCdf + (size_t)e.nv * (e.nu + 1); t.margCdf = t.condInt + e.nv;
+    return t;
+}
+// Distribution2D::SampleContinuous / Pdf (core/sampling.h:132-145)
+__device__ __forceinline__ void env_sample_uv(const DevScene &sc, const DevEnvLight &e, float u0, float u1, float *su, float *sv, float *pdf) {
+    const DevEnvTables t = env_tables(sc, e);
+    float pdf0, pdf1; int v, dummy;
+    const float d1 = dist1d_sample_continuous(t.margCdf, t.condInt, e.margFuncInt, e.nv, u1, &pdf1, &v);
+    const float d0 = dist1d_sample_continuous(t.condCdf + (size_t)v * (e.nu + 1), t.condFunc + (size_t)v * e.nu, t.condInt[v], e.nu, u0, &pdf0, &dummy);
+    *pdf = pdf0 * pdf1;
+    *su = d0; *sv = d1;
+}
+__device__ __forceinline__ float env_pdf_uv(const DevScene &sc, const DevEnvLight &e, float su, float sv) {
+    const DevEnvTables t = env_tables(sc, e);
+    int iu = (int)(su * e.nu), iv = (int)(sv * e.nv);
+    iu = iu < 0 ? 0 : (iu > e.nu - 1 ? e.nu - 1 : iu); iv = iv < 0 ? 0 : (iv > e.nv - 1 ? e.nv - 1 : iv);
+    return t.condFunc[(size_t)iv * e.nu + iu] / e.margFuncInt;
+}
+// Lmap->Lookup(st): MIPMap::Lookup(st, width = 0) — level = Levels() - 1 + Log2(1e-8) < 0 for every pyramid of at most 26 levels
+// (checked at scene creation), i.e. the bilinear "triangle" filter at level 0 (core/mipmap.h:203-221)
+__device__ __forceinline__ rgb env_lookup(const DevScene &sc, const DevEnvLight &e, float su, float sv) { return mip_triangle(sc, sc.textures[e.tex], 0, su, sv); }
+// InfiniteAreaLight::Le(ray), lights/infinite.cpp:93-97 (SphericalPhi / SphericalTheta, core/geometry.h:1816-1824)
+__device__ __forceinline__ rgb env_Le(const DevScene &sc, const DevEnvLight &e, vec3 d) {
+    const vec3 w = normalize(xf_vector(e.w2l, d));
+    float p = det_atan2f(w.y, w.x);
+    const float phi = (p < 0) ? (p + 2 * HPRT_PI) : p;
+    const float theta = det_acosf(clampf(w.z, -1.f, 1.f));
+    return env_lookup(sc, e, phi * HPRT_INV_2PI, theta * HPRT_INV_PI);
+}
 // Light::Sample_Li (lights/point.cpp:44-53, distant.cpp:49-59, diffuse.cpp:68-81).  GENERIC: the generic shading variant, the
 // only one that carries the code for shading points inside a sphere emitter and for triangle emitters.
 template <bool GENERIC>
@@ -884,6 +934,20 @@ __device__ __forceinline__ rgb light_sample(const DevScene &sc, const DevLight &
         pLight->p = ref.p + lp * (2 * sc.worldRadius); pLight->pErr = vec3(); pLight->n = vec3();
         return rgb(l.I[0], l.I[1], l.I[2]);
     }
+    if (GENERIC && l.type == 4) {      // lights/infinite.cpp:99-124
+        const DevEnvLight &e = sc.envLights[l.shape];
+        float su, sv, mapPdf;
+        env_sample_uv(sc, e, u0, u1, &su, &sv, &mapPdf);
+        if (mapPdf == 0) { *pdf = 0; return rgb(0.f); }
+        const float theta = sv * HPRT_PI, phi = su * 2 * HPRT_PI;
+        float sinTheta, cosTheta, sinPhi, cosPhi;
+        det_sincosf(theta, &sinTheta, &cosTheta); det_sincosf(phi, &sinPhi, &cosPhi);
+        *wi = xf_vector(e.l2w, vec3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
+        *pdf = mapPdf / (2 * HPRT_PI * HPRT_PI * sinTheta);
+        if (sinTheta == 0) *pdf = 0;
+        pLight->p = ref.p + *wi * (2 * sc.worldRadius); pLight->pErr = vec3(); pLight->n = vec3();
+        return env_lookup(sc, e, su, sv);
+    }
     DevIt ps;
     if (GENERIC && l.type == 3) ps = triangle_sample(sc, l.prim, ref, u0, u1, pdf);
     else ps = sphere_sample<GENERIC>(sc.spheres[l.sphere], (l.shapeFlags & SHAPE_REVERSE) != 0, ref, u0, u1, pdf);
@@ -897,6 +961,16 @@ __device__ __forceinline__ rgb light_sample(const DevScene &sc, const DevLight &
 template <bool GENERIC>
 __device__ __forceinline__ float light_pdf(const DevScene &sc, const DevLight &l, const DevIt &ref, vec3 wi) {
     if (l.type < 2) return 0;
+    if (GENERIC && l.type == 4) {      // lights/infinite.cpp:126-134
+        const DevEnvLight &e = sc.envLights[l.shape];
+        const vec3 w = xf_vector(e.w2l, wi);
+        const float theta = det_acosf(clampf(w.z, -1.f, 1.f));
+        float p = det_atan2f(w.y, w.x);
+        const float phi = (p < 0) ? (p + 2 * HPRT_PI) : p;
+        const float sinTheta = det_sinf(theta);
+        if (sinTheta == 0) return 0;
+        return env_pdf_uv(sc, e, phi * HPRT_INV_2PI, theta * HPRT_INV_PI) / (2 * HPRT_PI * HPRT_PI * sinTheta);
+    }
     if (GENERIC && l.type == 3) {
         DRay ray; ray.o = offset_ray_origin(ref.p, ref.pErr, ref.n, wi); ray.d = wi; ray.tMax = HPRT_INF;
         float b0, b1, b2, t;

@@ -673,6 +673,8 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
                 else if (generic) bin[k] = 2;
                 else bin[k] = ((uint32_t)word & HIT_PLASTIC) ? 1 : 0;
             }
+            // an escaped camera or specular segment picks up the infinite lights' radiance (integrators/path.cpp:97-106): the generic variant adds it
+            if (word < 0 && sc.nEnvLights != 0u && (bounces == 0 || (__float_as_uint(in.ray.b[slot[k]].w) >> 31))) bin[k] = 2;
             if (bin[k] < 0) {      // the path ends here
                 if (bounces == 0) Lfinal[slot[k]] = make_float4(0.f, 0.f, 0.f, 1.f);      // fresh path: path id = slot, L = 0 (k_generate)
                 else Lfinal[__float_as_uint(in.beta[slot[k]].w)] = in.L[slot[k]];
@@ -808,6 +810,8 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
             }
         }
         SP_MARK(0);      // loads + surface interaction
+        if (MODE == 2 && !found && (bounces == 0 || specularBounce))
+            for (uint32_t e = 0; e < sc.nEnvLights; ++e) { const rgb add = beta * env_Le(sc, sc.envLights[e], rayD); L = rgb(L.r + add.r, L.g + add.g, L.b + add.b); }
         if (found && bounces < rp.maxDepth) {
 #ifdef HPRT_SHADE_PROF
             spFull = true;
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                     // (Sphere::Sample(u) + Shape::Pdf); nothing has been written yet, so the
                     // material-specialised variants hand such a vertex to the generic variant.
                     // (likewise a vertex lit by a triangle emitter: Triangle::Sample / Shape::Pdf live in the generic variant only)
-                    if (MODE != 2 && !isDelta && (light.type == 3 || sphere_ref_inside(sc.spheres[light.sphere], it))) defer = true;
+                    if (MODE != 2 && !isDelta && (light.type >= 3 || sphere_ref_inside(sc.spheres[light.sphere], it))) defer = true;      // (type 4, an infinite light: generic variant too)
                     SP_MARK(2);      // light pick + the four sample values
                     if (!defer) {
                     rgb Li = light_sample<MODE == 2>(sc, light, it, ul0, ul1, &wi, &lightPdf, &pl);
@@ -903,8 +907,10 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                             DRay mr; mr.o = o; mr.d = wi; mr.tMax = HPRT_INF;
                             // (triangle emitters: the traversal's own triangle test on the emitter with tMax = infinity)
                             float tb0, tb1, tb2, tt;
-                            if (!rp.cullMis || (MODE == 2 && light.type == 3 ? triangle_may_hit(sc, light.prim, mr, &tb0, &tb1, &tb2, &tt)
-                                                                              : sphere_may_hit(sc.spheres[light.sphere], mr))) {
+                            // (an infinite light is reached by every such ray that escapes: nothing to cull)
+                            if (!rp.cullMis || (MODE == 2 && light.type == 4) ||
+                                (MODE == 2 && light.type == 3 ? triangle_may_hit(sc, light.prim, mr, &tb0, &tb1, &tb2, &tt)
+                                                              : sphere_may_hit(sc.spheres[light.sphere], mr))) {
                                 const float lp = light_pdf<MODE == 2>(sc, light, it, wi);
                                 if (lp != 0) {     // "if (lightPdf == 0) return Ld;" keeps the light-sampling term only
                                     const float w = power_heuristic(scatteringPdf, lp);
@@ -912,6 +918,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
                                     vs.mis.b[j] = make_float4(wi.x, wi.y, wi.z, 0.f);
                                     // contribution if the ray reaches the light's emitting side: f * Li * Tr * weight / pdf
                                     rgb Lemit(light.I[0], light.I[1], light.I[2]);
+                                    if (MODE == 2 && light.type == 4) Lemit = env_Le(sc, sc.envLights[light.shape], wi);      // light.Le(ray) of the escaped ray (core/integrator.cpp:201-202)
                                     pendMis = f * Lemit * rgb(1.f) * w / scatteringPdf;
                                     wantMis = true;
                                 }
@@ -1026,7 +1033,9 @@ __global__ __launch_bounds__(256) void k_resolve(DevScene sc, VertexStreams vs, 
     if (info & 0x80000000u) {
         const float4 mh = vs.misHit.a[j];
         const int32_t prim = hit_prim(__float_as_int(mh.y));
-        if (prim >= 0 && prim_area_light(sc, prim) == lightNum) {
+        if (prim < 0) {      // the ray escaped: an infinite light's radiance along it was priced in by k_shade, any other light has none (core/light.cpp:66)
+            if (sc.lights[lightNum].type == 4) Ld = Ld + rgb(pm.x, pm.y, pm.z);
+        } else if (prim_area_light(sc, prim) == lightNum) {
             // lightIsect.Le(-wi): the emitter's normal at the hit
             const float4 ma = vs.mis.a[j], mb = vs.mis.b[j];
             DRay r; r.o = vec3(ma.x, ma.y, ma.z); r.d = vec3(mb.x, mb.y, mb.z); r.tMax = HPRT_INF;

@@ -44,6 +44,7 @@ struct HprtScene {
     hprt::DevScene dev;
     hprt::DevBuf textures, mipLevels, texels, weightLut;
     hprt::DevBuf nodes, tris, primVtx, primN, vUV, vS, shapes, materials, lights, spheres, instances, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
+    hprt::DevBuf envLights, envData;      // infinite lights: DevEnvLight table and their Distribution2D tables
     hprt::DevBuf counters, workCounter, deepStack;
     int poisonByte = -1;      // hprt_debug_poison_workspace (tests): fill every stream, queue and stack with this byte before each render
     hprt::DevBuf voxFunc, voxCdf, voxFuncInt, voxRi;      // SpatialLightDistribution tables (lightsamplestrategy "spatial")

@@ -27,6 +27,7 @@ namespace hprt {
 #define HPRT_SHADOW_EPS 0.0001f
 #define HPRT_PI 3.14159274101257324219f
 #define HPRT_INV_PI 0.31830987334251403809f
+#define HPRT_INV_2PI 0.15915494309189533577f
 #define HPRT_PI_OVER_2 1.57079637050628662109f
 #define HPRT_PI_OVER_4 0.78539818525314331055f
 #define HPRT_ONE_MINUS_EPS 0.99999994039535522461f

@@ -504,6 +504,26 @@ struct Frontend {
             l.type = kDistantLight;
             l.pos[0] = w.x; l.pos[1] = w.y; l.pos[2] = w.z;
             for (int i = 0; i < 3; ++i) l.I[i] = L[i] * scv[i];
+        } else if (name == "infinite" || name == "exinfinite") {      // CreateInfiniteLight, lights/infinite.cpp:176-186 (core/api.cpp:748-752)
+            float L[3] = {1, 1, 1};
+            params.rgb3("L", L);
+            for (int i = 0; i < 3; ++i) L[i] = L[i] * scv[i];
+            const std::string mapname = params.oneString("mapname", "");
+            int w = 1, h = 1; std::vector<float> rgb;
+            std::string e;
+            if (mapname.empty() || !ReadImageFile(resolve(mapname), &w, &h, &rgb, &e)) {
+                // "if (!texels)": a 1x1 map holding L (lights/infinite.cpp:57-61); ReadImage has reported why
+                if (!mapname.empty()) warn(e + "; the infinite light uses its constant L");
+                w = h = 1; rgb.assign(L, L + 3);
+            } else
+                for (size_t i = 0; i + 2 < rgb.size(); i += 3) { rgb[i] *= L[0]; rgb[i + 1] *= L[1]; rgb[i + 2] *= L[2]; }
+            TextureDesc td;      // MIPMap's defaults: EWA tables, max anisotropy 8, repeat (core/mipmap.h:52-55)
+            BuildMipMap(w, h, rgb, 1.f, false, &td, false);
+            l.type = kInfiniteLight;
+            l.texture = (int32_t)sc->textures.size();
+            sc->textures.push_back(std::move(td));
+            l.lightToWorld = ctm.m; l.worldToLight = ctm.inv;
+            l.I[0] = L[0]; l.I[1] = L[1]; l.I[2] = L[2];
         } else {
             warn("light \"" + name + "\" is outside the hot-path scope; skipped");
             return true;
@@ -683,7 +703,7 @@ struct Frontend {
             } else if (tok == "AreaLightSource") { if (!readQuoted(&gs.areaLight) || !readParams(&gs.areaLightParams)) return false; }
             else if (tok == "LightSource") {
                 if (!readQuoted(&name) || !readParams(&pl) || !doLight(name, pl)) return false;
-                if (name == "point" || name == "distant") reportUnused(pl, "LightSource \"" + name + "\"", {"nsamples", "samples"});
+                if (name == "point" || name == "distant" || name == "infinite" || name == "exinfinite") reportUnused(pl, "LightSource \"" + name + "\"", {"nsamples", "samples"});
             } else if (tok == "Shape") {
                 if (!readQuoted(&name) || !readParams(&pl) || !doShape(name, pl)) return false;
                 if (name == "trianglemesh" || name == "loopsubdiv" || name == "plymesh" || name == "sphere") reportUnused(pl, "Shape \"" + name + "\"");

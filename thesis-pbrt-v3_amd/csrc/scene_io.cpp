@@ -39,7 +39,10 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
     const bool instancing = sc.nObjects > 0 || !sc.instances.empty();
     // version 3 = version 2's layout (instancing section always present) followed by the image textures
     const bool textured = !sc.textures.empty();
-    o.raw("HPRTSCN1", 8); o.u32(textured ? 3u : instancing ? 2u : 1u);
+    // version 4 = version 3's layout followed by the map index and the transforms of the infinite lights (in light order)
+    bool infinite = false;
+    for (const LightDesc &l : sc.lights) if (l.type == kInfiniteLight) infinite = true;
+    o.raw("HPRTSCN1", 8); o.u32(infinite ? 4u : textured ? 3u : instancing ? 2u : 1u);
     o.i32(p.xres); o.i32(p.yres);
     o.raw(p.crop, 16);
     o.raw(p.filterRadius, 8); o.i32(p.filterType);
@@ -91,6 +94,9 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
             for (const MipLevel &l : t.levels) { o.i32(l.w); o.i32(l.h); o.raw(l.rgb.data(), 4 * l.rgb.size()); }
         }
     }
+    if (infinite)      // (an infinite light owns a map, so the texture section above is present)
+        for (const LightDesc &l : sc.lights)
+            if (l.type == kInfiniteLight) { o.i32(l.texture); o.raw(&l.lightToWorld, 64); o.raw(&l.worldToLight, 64); }
     bool ok = o.ok;
     if (fclose(fp) != 0) ok = false;
     if (!ok) *err = "write error on " + path;
@@ -108,7 +114,7 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
     char magic[8]; in.raw(magic, 8);
     if (!in.ok || memcmp(magic, "HPRTSCN1", 8) != 0) return fail("not a baked hprt scene");
     const uint32_t version = in.u32();
-    if (version < 1 || version > 3) return fail("unsupported version");
+    if (version < 1 || version > 4) return fail("unsupported version");
     RenderOptions &p = sc->opt;
     p.xres = in.i32(); p.yres = in.i32();
     in.raw(p.crop, 16);
@@ -151,7 +157,10 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
     }
     sc->lights.resize(nLights);
     for (LightDesc &l : sc->lights) {
+        memset(&l, 0, sizeof(l));
         l.type = in.i32(); in.raw(l.pos, 12); in.raw(l.I, 12); l.shape = in.i32(); l.twoSided = in.i32();
+        l.texture = -1;
+        if (l.type < 0 || l.type > kInfiniteLight || (l.type == kInfiniteLight && version < 4)) return fail("light type out of range");
         if (l.type == kDiffuseAreaLight && (l.shape < 0 || (uint32_t)l.shape >= nShapes)) return fail("area light shape out of range");
     }
     sc->nObjects = 0; sc->instances.clear(); sc->top.clear();
@@ -197,6 +206,12 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
         for (const MaterialDesc &m : sc->materials)
             if (m.KdTex >= (int32_t)nTex || m.KsTex >= (int32_t)nTex || m.KdTex < -1 || m.KsTex < -1) return fail("material texture index out of range");
     }
+    if (version >= 4)
+        for (LightDesc &l : sc->lights)
+            if (l.type == kInfiniteLight) {
+                l.texture = in.i32(); in.raw(&l.lightToWorld, 64); in.raw(&l.worldToLight, 64);
+                if (!in.ok || l.texture < 0 || (size_t)l.texture >= sc->textures.size()) return fail("infinite light map out of range");
+            }
     if (!in.ok) return fail("truncated file");
     fclose(fp);
     return true;

@@ -13,7 +13,7 @@ namespace hprt {
 
 enum MaterialType { kMatte = 0, kPlastic = 1, kMirror = 2, kSubstrate = 3, kMetal = 4, kGlass = 5 };
 // mirror: Kr travels in Ks.  substrate: roughness = uroughness, sigma = vroughness.  metal: Kd = eta, Ks = k, roughness / sigma likewise.  glass: Kd = Kt, Ks = Kr, roughness = eta (index).
-enum LightType { kPointLight = 0, kDistantLight = 1, kDiffuseAreaLight = 2 };
+enum LightType { kPointLight = 0, kDistantLight = 1, kDiffuseAreaLight = 2, kInfiniteLight = 3 };
 enum ShapeKind { kTriangleMesh = 0, kSphere = 1 };
 enum LightStrategy { kUniform = 0, kPower = 1, kSpatial = 2 };
 
@@ -57,6 +57,10 @@ struct LightDesc {
     float I[3];       // point: I; distant: L; area: Lemit (already multiplied by "scale")
     int32_t shape;    // area: index into shapes
     int32_t twoSided;
+    // infinite (lights/infinite.cpp): radiance map = textures[texture] (texels already times L * scale, NOT flipped in y: the
+    // light indexes its map as read; a constant light has a 1x1 map), and the light <-> world transform
+    int32_t texture;
+    mat4 lightToWorld, worldToLight;
 };
 // ObjectInstance (core/api.cpp:1778-1820): a TransformedPrimitive over the object's primitives
 struct InstanceDesc { int32_t object; mat4 instanceToWorld, worldToInstance; };
@@ -93,7 +97,7 @@ struct SceneModel {
 // texture_io.cpp: ReadImage (core/imageio.cpp:60-79; .tga .png .pfm), rows top to bottom, RGB floats; and
 // ImageTexture::GetTexture + MIPMap::MIPMap (textures/imagemap.cpp:52-97, core/mipmap.h:113-201)
 bool ReadImageFile(const std::string &path, int *w, int *h, std::vector<float> *rgb, std::string *err);
-void BuildMipMap(int w, int h, const std::vector<float> &rgb, float scale, bool gamma, TextureDesc *tex);
+void BuildMipMap(int w, int h, const std::vector<float> &rgb, float scale, bool gamma, TextureDesc *tex, bool flipY = true);
 
 bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *err);
 bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err);

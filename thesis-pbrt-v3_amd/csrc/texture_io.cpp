@@ -214,9 +214,11 @@ static const float *texelOf(const MipLevel &l, int wrap, int s, int t) {
 }
 
 // ImageTexture::GetTexture + MIPMap::MIPMap.  `rgb` is what ReadImage returned (top row first).
-void BuildMipMap(int w, int h, const std::vector<float> &rgbIn, float scale, bool gamma, TextureDesc *tex) {
+void BuildMipMap(int w, int h, const std::vector<float> &rgbIn, float scale, bool gamma, TextureDesc *tex, bool flipY) {
     std::vector<float> img(rgbIn);
-    // "Flip image in y; texture coordinate space has (0,0) at the lower left corner"
+    // "Flip image in y; texture coordinate space has (0,0) at the lower left corner" (ImageTexture::GetTexture, textures/imagemap.cpp:
+    // 54-60; an InfiniteAreaLight hands its texels to MIPMap as ReadImage returned them: flipY = false)
+    if (flipY)
     for (int y = 0; y < h / 2; ++y)
         for (int x = 0; x < 3 * w; ++x) std::swap(img[(size_t)y * 3 * w + x], img[(size_t)(h - 1 - y) * 3 * w + x]);
     // convertIn: scale * (gamma ? InverseGammaCorrect(v) : v), core/pbrt.h:298-301
