@@ -151,6 +151,12 @@ CASES = {
     "infinite_point_sphere_power": _scene('LightSource "infinite" "rgb L" [.2 .25 .3]\nLightSource "point" "point from" [1 -2 4] "color I" [20 5 5]\n' + SPHERE_LIGHT + GEOM,
                                           integ='"string lightsamplestrategy" "power"'),
     "infinite_point_sphere_spatial": _scene('LightSource "infinite" "rgb L" [.2 .25 .3]\nLightSource "point" "point from" [1 -2 4] "color I" [20 5 5]\n' + SPHERE_LIGHT + GEOM),
+    # two infinite lights (every escaped camera / specular segment adds both, in light order), a point light, instanced geometry
+    # (the instanced traversal kernels' misses) and a mirror, default (spatial) light strategy
+    "infinite_two_lights_instances": _scene('LightSource "infinite" "rgb L" [.3 .1 .1]\nAttributeBegin\nRotate 70 0 1 0\nLightSource "infinite" "rgb L" [.05 .1 .3]\nAttributeEnd\n'
+                                            'LightSource "point" "point from" [1 -2 4] "color I" [10 10 10]\n' + MATTE +
+                                            'ObjectBegin "bump"\nShape "trianglemesh" ' + BUMPY + '\nObjectEnd\n'
+                                            'ObjectInstance "bump"\nAttributeBegin\nTranslate 0 0 -1\nScale 2 2 1\nMaterial "mirror"\nObjectInstance "bump"\nAttributeEnd\n'),
     "no_lights": _scene(GEOM),
     "empty_scene": _scene(""),
     "light_only": _scene(SPHERE_LIGHT),

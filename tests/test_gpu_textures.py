@@ -31,6 +31,9 @@ def _write_images(d):
     _write_tga(str(d / "stripes.tga"), np.repeat(_checker(48, 6, 5)[:, :1], 20, axis=1), rle=True)   # 20 x 48: non power of two
     rng = np.random.default_rng(11)
     _write_pfm(str(d / "hdr.pfm"), (rng.random((33, 57, 3)) * 1.5).astype(np.float32))                # resampled to 64 x 64
+    sky = np.zeros((8, 16, 3), np.float32)                                                              # a power-of-two map with a bright patch
+    sky[...] = [0.1, 0.15, 0.3]; sky[1:3, 10:13] = [30.0, 28.0, 20.0]
+    _write_pfm(str(d / "sky.pfm"), sky)
 
 
 BUMPY_UV = _grid_mesh(24, 24, lambda x, y: 0.25 * np.sin(2.3 * x) * np.cos(1.7 * y), uv=True)
@@ -68,6 +71,10 @@ CASES = {
     "infinite_map": _scene('AttributeBegin\nRotate -90 1 0 0\nRotate 40 0 0 1\nLightSource "infinite" "string mapname" "%(dir)s/hdr.pfm" "rgb L" [.8 .8 1] "rgb scale" [1.5 1.5 1.5]\nAttributeEnd\n' +
                            MATTE + 'Shape "trianglemesh" ' + FLOOR + '\nMaterial "plastic" "color Kd" [.2 .3 .5] "color Ks" [.6 .6 .6] "float roughness" [.08]\nShape "trianglemesh" ' + BUMPY +
                            '\nAttributeBegin\nMaterial "mirror"\nTranslate 1.2 .4 .6\nShape "sphere" "float radius" [.45]\nAttributeEnd\n', xres=128, yres=96, spp=8),
+    # a small power-of-two map with a bright "sun" patch: the Distribution2D concentrates the light samples there; textured floor under it
+    "infinite_sun_patch": _scene('AttributeBegin\nRotate -90 1 0 0\nLightSource "infinite" "string mapname" "%(dir)s/sky.pfm"\nAttributeEnd\n' +
+                                 _tex("chk", "chk.png", '"float uscale" [3] "float vscale" [3]') % {"dir": "%(dir)s"} +
+                                 'Material "matte" "texture Kd" "chk"\nShape "trianglemesh" ' + FLOOR + "\n" + MATTE + 'Shape "trianglemesh" ' + BUMPY + "\n", spp=8),
     # one sample per pixel (differential scale 1), and far minification (grazing floor up to the horizon)
     "spp1_grazing": """LookAt 0 -3.9 -0.25  0 4 -0.45  0 0 1
 Camera "perspective" "float fov" [55]
