@@ -134,3 +134,41 @@ def test_sphere_reintersect_through_the_c_abi(hprt, orc, partial):
             assert (prim2 < 0).all()
         del scene
     assert tested > 30
+
+
+@pytest.mark.gpu
+def test_infinite_light_through_the_scene_description(hprt, tmp_path):
+    """An InfiniteAreaLight handed over the way a pbrt-side adapter would: HprtLightDesc type 3 + its MIPMap as
+    an HprtTextureDesc + the light <-> world matrices, borrowed pointers.  The render must equal, bit for bit, the render of the same
+    scene parsed from .pbrt text by the library's own front-end (whose infinite light is the oracle-checked one)."""
+    text = ('LookAt 0 -4 2  0 0 0  0 0 1\nCamera "perspective" "float fov" [40]\nFilm "image" "integer xresolution" [32] "integer yresolution" [24]\n'
+            'Sampler "halton" "integer pixelsamples" [4]\nIntegrator "path" "integer maxdepth" [3]\nWorldBegin\n'
+            'AttributeBegin\nRotate 25 0 0 1\nLightSource "infinite" "rgb L" [.5 .6 .9]\nAttributeEnd\n'
+            'Material "matte" "color Kd" [.5 .5 .5]\nShape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -1 0 1 -1 0 1 1 0 -1 1 0]\nWorldEnd\n')
+    p = tmp_path / "env.pbrt"; p.write_text(text)
+    model = hprt.Model.parse(str(p))
+    opt = model.options
+    ref, _ = hprt.Scene(model, hprt.Bvh(model)).render(opt)
+    P = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float32); idx = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    tri = P[idx]
+    bvh = hprt.Bvh.from_bounds(tri.min(axis=1), tri.max(axis=1))
+    nodes, order = bvh.arrays()
+    sh = hprt.ShapeDesc(); sh.kind = 0; sh.material = 0; sh.area_light = -1; sh.n_tris = 2; sh.n_verts = 4; sh.indices = idx.ctypes.data; sh.P = P.ctypes.data
+    mat = hprt.MaterialDesc(); mat.type = 0; mat.Kd[:] = [.5, .5, .5]; mat.kd_texture = mat.ks_texture = -1
+    texel = np.array([.5, .6, .9], np.float32); lut = np.zeros(128, np.float32)
+    lv = (hprt.TextureLevel * 1)(); lv[0].w = 1; lv[0].h = 1; lv[0].rgb = texel.ctypes.data
+    tx = hprt.TextureDesc(); tx.levels = lv; tx.n_levels = 1; tx.trilinear = 0; tx.max_anisotropy = 8; tx.wrap = 0; tx.su = tx.sv = 1; tx.weight_lut = lut.ctypes.data
+    a = np.float32(np.deg2rad(np.float32(25.0)))
+    light = hprt.LightDesc(); light.type = 3; light.shape = -1; light.texture = 0; light.I[:] = [.5, .6, .9]
+    # Rotate(25, (0,0,1)) as the front-end builds it is read back from the model instead of rebuilt here: the matrices must be the same floats
+    baked = str(tmp_path / "env.hprt"); model.save(baked)
+    raw = open(baked, "rb").read()
+    m = np.frombuffer(raw[-128:], np.float32)      # container version 4 ends with the infinite light's two matrices
+    light.light_to_world[:] = m[:16].tolist(); light.world_to_light[:] = m[16:].tolist()
+    desc = hprt.SceneDesc()
+    desc.nodes = nodes.ctypes.data; desc.n_nodes = nodes.shape[0]; desc.prim_order = order.ctypes.data; desc.n_prims = order.shape[0]
+    shapes = (hprt.ShapeDesc * 1)(sh); mats = (hprt.MaterialDesc * 1)(mat); lights = (hprt.LightDesc * 1)(light); texs = (hprt.TextureDesc * 1)(tx)
+    desc.shapes = shapes; desc.n_shapes = 1; desc.materials = mats; desc.n_materials = 1; desc.lights = lights; desc.n_lights = 1
+    desc.textures = C.cast(texs, C.c_void_p); desc.n_textures = 1
+    got, _ = hprt.Scene.from_desc(desc).render(opt)
+    assert got[..., :3].max() > 0.3 and np.array_equal(got.view(np.uint32), ref.view(np.uint32))

@@ -97,6 +97,15 @@ class MaterialDesc(C.Structure):
                 ("remap_roughness", C.c_int32), ("kd_texture", C.c_int32), ("ks_texture", C.c_int32)]
 
 
+class TextureLevel(C.Structure):
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("rgb", C.c_void_p)]
+
+
+class TextureDesc(C.Structure):
+    _fields_ = [("levels", C.POINTER(TextureLevel)), ("n_levels", C.c_uint32), ("trilinear", C.c_int32), ("max_anisotropy", C.c_float),
+                ("wrap", C.c_int32), ("su", C.c_float), ("sv", C.c_float), ("du", C.c_float), ("dv", C.c_float), ("weight_lut", C.c_void_p)]
+
+
 class LightDesc(C.Structure):
     _fields_ = [("type", C.c_int32), ("pos", C.c_float * 3), ("I", C.c_float * 3), ("shape", C.c_int32), ("two_sided", C.c_int32),
                 ("texture", C.c_int32), ("light_to_world", C.c_float * 16), ("world_to_light", C.c_float * 16)]
