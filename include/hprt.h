@@ -130,10 +130,13 @@ typedef struct HprtShapeDesc {       /* one Shape directive (core/api.cpp:1561-1
 typedef struct HprtMaterialDesc {    /* materials/matte.cpp:64-72, materials/plastic.cpp:72-84, materials/mirror.cpp:58-64 */
     int32_t type;                    /* 0 matte (sigma != 0: OrenNayar), 1 plastic, 2 mirror (Kr in Ks), 3 substrate (roughness = uroughness,
                                       * sigma = vroughness; materials/substrate.cpp), 4 metal (Kd = eta, Ks = k, roughness / sigma likewise;
-                                      * materials/metal.cpp), 5 smooth glass (Kd = Kt, Ks = Kr, roughness = eta; materials/glass.cpp) */
+                                      * materials/metal.cpp), 5 smooth glass (Kd = Kt, Ks = Kr, roughness = eta; materials/glass.cpp), 6 uber (below) */
     float Kd[3], sigma, Ks[3], roughness;
     int32_t remap_roughness;
     int32_t kd_texture, ks_texture;  /* index into HprtSceneDesc::textures when Kd / Ks is an image texture, else -1 */
+    /* type 6, UberMaterial (materials/uber.cpp): Kd, Ks as named, roughness = uroughness, sigma = vroughness, and the lobes only it
+     * has: Kr (specular reflection), Kt (specular transmission), opacity (1 - opacity passes straight through), eta */
+    float Kr[3], Kt[3], opacity[3], eta;
 } HprtMaterialDesc;
 
 /* ImageTexture<RGBSpectrum, Spectrum> (textures/imagemap.h:71-122) with its built MIPMap (core/mipmap.h):

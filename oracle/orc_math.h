@@ -521,6 +521,7 @@ struct Spec {
     Spec operator/(Float a) const { return Spec(c[0] / a, c[1] / a, c[2] / a); }
     Spec &operator/=(Float a) { c[0] /= a; c[1] /= a; c[2] /= a; return *this; }
     Spec operator-(const Spec &s) const { return Spec(c[0] - s.c[0], c[1] - s.c[1], c[2] - s.c[2]); }      // spectrum.h:110-117
+    Spec operator-() const { return Spec(-c[0], -c[1], -c[2]); }      // spectrum.h:185-189
     Spec operator/(const Spec &s) const { return Spec(c[0] / s.c[0], c[1] / s.c[1], c[2] / s.c[2]); }      // spectrum.h:118-126
     bool IsBlack() const { return c[0] == 0 && c[1] == 0 && c[2] == 0; }
     bool HasNaNs() const { return std::isnan(c[0]) || std::isnan(c[1]) || std::isnan(c[2]); }

@@ -12,7 +12,7 @@
 
 namespace orc {
 
-enum { MAT_MATTE = 0, MAT_PLASTIC = 1, MAT_MIRROR = 2, MAT_SUBSTRATE = 3, MAT_METAL = 4, MAT_GLASS = 5 };      // glass: Kd = Kt, Ks = Kr, roughness = eta
+enum { MAT_MATTE = 0, MAT_PLASTIC = 1, MAT_MIRROR = 2, MAT_SUBSTRATE = 3, MAT_METAL = 4, MAT_GLASS = 5, MAT_UBER = 6 };      // glass: Kd = Kt, Ks = Kr, roughness = eta
 // mirror: Kr travels in Ks; substrate: roughness = uroughness, sigma = vroughness; metal: Kd = eta, Ks = k, roughness / sigma likewise
 enum { LIGHT_POINT = 0, LIGHT_DISTANT = 1, LIGHT_AREA = 2, LIGHT_INFINITE = 3 };
 enum { SHAPE_MESH = 0, SHAPE_SPHERE = 1 };
@@ -21,6 +21,8 @@ struct Material {
     int type;
     Float Kd[3]; Float sigma; Float Ks[3]; Float roughness; int remap;
     int KdTex = -1, KsTex = -1;       // Scene::textures index when the parameter is an ImageTexture
+    // uber (materials/uber.cpp; roughness = uroughness, sigma = vroughness): the lobes the other materials do not have
+    Float Kr[3] = {0, 0, 0}, Kt[3] = {0, 0, 0}, opacity[3] = {1, 1, 1}; Float eta = 1.5f;
 };
 // ImageTexture<RGBSpectrum, Spectrum> with its built MIPMap (textures/imagemap.h, core/mipmap.h).  The pyramid is
 // built once by the product's host code (csrc/texture_io.cpp) and travels in the baked scene; lookups are restated here.
@@ -107,7 +109,7 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
     char magic[8]; r.raw(magic, 8);
     if (!r.ok || memcmp(magic, "HPRTSCN1", 8) != 0) { *err = "bad magic"; return false; }
     uint32_t version = r.u32();
-    if (version < 1 || version > 4) { *err = "bad version"; return false; }
+    if (version < 1 || version > 5) { *err = "bad version"; return false; }
     SceneParams &p = sc->prm;
     p.xres = r.i32(); p.yres = r.i32();
     for (int i = 0; i < 4; ++i) p.crop[i] = r.f32();
@@ -223,6 +225,11 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
             }
     } else
         for (auto &l : sc->lights) if (l.type == LIGHT_INFINITE) { *err = "infinite light in a container older than version 4"; return false; }
+    if (version >= 5) {      // uber materials: Kr, Kt, opacity, eta
+        for (auto &m : sc->materials)
+            if (m.type == MAT_UBER) { r.raw(m.Kr, 12); r.raw(m.Kt, 12); r.raw(m.opacity, 12); m.eta = r.f32(); }
+    } else
+        for (auto &m : sc->materials) if (m.type == MAT_UBER) { *err = "uber material in a container older than version 5"; return false; }
     if (!r.ok) { *err = "truncated file"; return false; }
     return true;
 }

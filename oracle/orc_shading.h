@@ -161,7 +161,7 @@ struct TRDist {
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16,
        BSDF_ALL = 31 };
 enum { BXDF_LAMBERT = 0, BXDF_MICROFACET = 1, BXDF_SPECULAR_REFLECTION = 2, BXDF_OREN_NAYAR = 3, BXDF_FRESNEL_BLEND = 4,
-       BXDF_MICROFACET_CONDUCTOR = 5, BXDF_FRESNEL_SPECULAR = 6 };
+       BXDF_MICROFACET_CONDUCTOR = 5, BXDF_FRESNEL_SPECULAR = 6, BXDF_SPECULAR_TRANSMISSION = 7 };
 
 inline Spec SqrtS(const Spec &s) { return Spec(std::sqrt(s.c[0]), std::sqrt(s.c[1]), std::sqrt(s.c[2])); }
 // FrConductor, core/reflection.cpp:70-95
@@ -191,11 +191,14 @@ struct BxDF {
     TRDist dist;   // microfacet only; Fresnel is FresnelDielectric(1.5, 1) (plastic.cpp:56)
     Float A = 1, B = 0;   // OrenNayar (core/reflection.h:414-420)
     Spec S, K;            // FresnelBlend: S = Rs; conductor microfacet: S = eta, K = k; FresnelSpecular: S = T
-    Float etaA = 1, etaB = 1;      // FresnelSpecular (TransportMode::Radiance)
+    Float etaA = 1, etaB = 1;      // FresnelSpecular, SpecularTransmission (TransportMode::Radiance)
+    // Fresnel term of SpecularReflection / MicrofacetReflection when it is not the kind's usual one (mirror: FresnelNoOp; plastic:
+    // FresnelDielectric(1.5, 1)): UberMaterial's lobes carry FresnelDielectric(1, e) (materials/uber.cpp:73, 95)
+    bool frDielectric = false; Float frEtaI = 1, frEtaT = 1;
     bool MatchesFlags(int t) const { return (type & t) == type; }
     Spec f(const V3 &wo, const V3 &wi) const {
         if (kind == BXDF_LAMBERT) return R * InvPi;       // reflection.cpp:178-180
-        if (kind == BXDF_SPECULAR_REFLECTION || kind == BXDF_FRESNEL_SPECULAR) return Spec(0.f);      // reflection.h:199-201, 527-529
+        if (kind == BXDF_SPECULAR_REFLECTION || kind == BXDF_FRESNEL_SPECULAR || kind == BXDF_SPECULAR_TRANSMISSION) return Spec(0.f);      // reflection.h:199-201, 337-339, 527-529
         if (kind == BXDF_FRESNEL_BLEND) {                 // reflection.cpp:285-298; R = Rd, S = Rs
             auto pow5 = [](Float v) { return (v * v) * (v * v) * v; };
             Spec diffuse = (28.f / (23.f * Pi)) * R * (Spec(1.f) - S) * (1 - pow5(1 - .5f * AbsCosTheta(wi))) * (1 - pow5(1 - .5f * AbsCosTheta(wo)));
@@ -227,11 +230,12 @@ struct BxDF {
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0.);
         wh = Normalize(wh);
         // FresnelDielectric(1.5, 1) (plastic) or FresnelConductor(1, eta = S, k = K) (metal: Evaluate takes |cos|, reflection.cpp:118-120)
-        Spec F = kind == BXDF_MICROFACET_CONDUCTOR ? FrConductor(std::abs(Dot(wi, wh)), Spec(1.), S, K) : Spec(FrDielectric(Dot(wi, wh), 1.5f, 1.f));
+        Spec F = kind == BXDF_MICROFACET_CONDUCTOR ? FrConductor(std::abs(Dot(wi, wh)), Spec(1.), S, K)
+                                                   : Spec(frDielectric ? FrDielectric(Dot(wi, wh), frEtaI, frEtaT) : FrDielectric(Dot(wi, wh), 1.5f, 1.f));
         return R * dist.D(wh) * dist.G(wo, wi) * F / (4 * cosThetaI * cosThetaO);
     }
     Float Pdf(const V3 &wo, const V3 &wi) const {
-        if (kind == BXDF_SPECULAR_REFLECTION || kind == BXDF_FRESNEL_SPECULAR) return 0;               // reflection.h:204, 532
+        if (kind == BXDF_SPECULAR_REFLECTION || kind == BXDF_FRESNEL_SPECULAR || kind == BXDF_SPECULAR_TRANSMISSION) return 0;               // reflection.h:204, 342, 532
         if (kind == BXDF_LAMBERT || kind == BXDF_OREN_NAYAR) return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * InvPi : 0;   // :387-389
         if (kind == BXDF_FRESNEL_BLEND) {                                                        // :470-475
             if (!SameHemisphere(wo, wi)) return 0;
@@ -266,7 +270,17 @@ struct BxDF {
         if (kind == BXDF_SPECULAR_REFLECTION) {            // :136-143, FresnelNoOp::Evaluate == Spectrum(1.)
             *wi = V3(-wo.x, -wo.y, wo.z);
             *pdf = 1;
-            return Spec(1.f) * R / AbsCosTheta(*wi);
+            return (frDielectric ? Spec(FrDielectric(CosTheta(*wi), frEtaI, frEtaT)) : Spec(1.f)) * R / AbsCosTheta(*wi);
+        }
+        if (kind == BXDF_SPECULAR_TRANSMISSION) {          // :145-163 (R = T; fresnel = FresnelDielectric(etaA, etaB); TransportMode::Radiance)
+            bool entering = CosTheta(wo) > 0;
+            Float etaI = entering ? etaA : etaB;
+            Float etaT = entering ? etaB : etaA;
+            if (!Refract(wo, Faceforward(V3(0, 0, 1), wo), etaI / etaT, wi)) return 0;
+            *pdf = 1;
+            Spec ft = R * (Spec(1.) - Spec(FrDielectric(CosTheta(*wi), etaA, etaB)));
+            ft *= (etaI * etaI) / (etaT * etaT);
+            return ft / AbsCosTheta(*wi);
         }
         if (kind == BXDF_FRESNEL_BLEND) {                  // :450-468
             P2 uu = u;
@@ -303,7 +317,7 @@ struct BxDF {
 struct BSDF {
     V3 ns, ng, ss, ts;
     int nBxDFs = 0;
-    BxDF bxdfs[2];
+    BxDF bxdfs[5];      // UberMaterial adds up to five (materials/uber.cpp)
     Float eta = 1;        // BSDF::eta (core/reflection.h:156-157)
     void Init(const SurfaceInteraction &si) {
         eta = 1;
@@ -475,7 +489,41 @@ inline void ComputeScatteringFunctions(const Scene &scene, const Material &m, co
     bsdf->Init(si);
     const Spec Kd = m.KdTex >= 0 ? EvalImageTexture(scene.textures[m.KdTex], si) : Spec(m.Kd[0], m.Kd[1], m.Kd[2]);
     const Spec Ks = m.KsTex >= 0 ? EvalImageTexture(scene.textures[m.KsTex], si) : Spec(m.Ks[0], m.Ks[1], m.Ks[2]);
-    if (m.type == MAT_GLASS) {       // materials/glass.cpp:44-65, smooth case with allowMultipleLobes (Kd = Kt, Ks = Kr, roughness = eta)
+    if (m.type == MAT_UBER) {        // materials/uber.cpp:45-108 (constant e, opacity, Kr, Kt; roughness = uroughness, sigma = vroughness; no bump map)
+        const Float e = m.eta;
+        Spec op = Spec(m.opacity[0], m.opacity[1], m.opacity[2]).Clamp();
+        Spec t = (-op + Spec(1.f)).Clamp();
+        if (!t.IsBlack()) {
+            bsdf->eta = 1.f;
+            BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+            b.kind = BXDF_SPECULAR_TRANSMISSION; b.type = BSDF_TRANSMISSION | BSDF_SPECULAR; b.R = t; b.etaA = 1.f; b.etaB = 1.f;
+        } else bsdf->eta = e;
+        Spec kd = op * Kd.Clamp();
+        if (!kd.IsBlack()) {
+            BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+            b.kind = BXDF_LAMBERT; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.R = kd;
+        }
+        Spec ks = op * Ks.Clamp();
+        if (!ks.IsBlack()) {
+            Float roughu = m.roughness, roughv = m.sigma;
+            if (m.remap) { roughu = RoughnessToAlpha(roughu); roughv = RoughnessToAlpha(roughv); }
+            BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+            b.kind = BXDF_MICROFACET; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.R = ks;
+            b.dist.alphax = roughu; b.dist.alphay = roughv;
+            b.frDielectric = true; b.frEtaI = 1.f; b.frEtaT = e;
+        }
+        Spec kr = op * Spec(m.Kr[0], m.Kr[1], m.Kr[2]).Clamp();
+        if (!kr.IsBlack()) {
+            BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+            b.kind = BXDF_SPECULAR_REFLECTION; b.type = BSDF_REFLECTION | BSDF_SPECULAR; b.R = kr;
+            b.frDielectric = true; b.frEtaI = 1.f; b.frEtaT = e;
+        }
+        Spec kt = op * Spec(m.Kt[0], m.Kt[1], m.Kt[2]).Clamp();
+        if (!kt.IsBlack()) {
+            BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+            b.kind = BXDF_SPECULAR_TRANSMISSION; b.type = BSDF_TRANSMISSION | BSDF_SPECULAR; b.R = kt; b.etaA = 1.f; b.etaB = e;
+        }
+    } else if (m.type == MAT_GLASS) {       // materials/glass.cpp:44-65, smooth case with allowMultipleLobes (Kd = Kt, Ks = Kr, roughness = eta)
         bsdf->eta = m.roughness;
         Spec R = Ks.Clamp(), T = Kd.Clamp();
         if (R.IsBlack() && T.IsBlack()) return;

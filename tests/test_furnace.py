@@ -9,8 +9,8 @@ written as the .pbrt text that builds exactly those objects through the front-en
 oracle (CPU test) and over the HIP path, which must also equal the oracle's film bit for bit (GPU test).  Scene 3 shades
 points that lie INSIDE their own emitter (Sphere::Sample's uniform-area branch, shapes/sphere.cpp:236-252), the path the
 material-specialised shading kernels hand over to the generic one.  Scene 2 (:100-133) is scene 1 with four point lights of pi/4
-each: more than one light, so the reference's default SpatialLightDistribution picks among them.  Scenes 4 and 5 use UberMaterial
-(outside the hot-path scope)."""
+each: more than one light, so the reference's default SpatialLightDistribution picks among them.  Scene 4 (:167-203) is scene 1 with
+an UberMaterial of Kd 0.25 + Kr 0.5 and a light of 3 pi; scene 5 is disabled in the reference (#if 0)."""
 import numpy as np
 import pytest
 
@@ -39,6 +39,13 @@ SCENES["box_triangle_area_lights"] = (
 # scene 2 (:100-133): PointLight(Transform(), nullptr, Spectrum(Pi / 4)) four times; float(Pi / 4) = 0.785398185
 SCENES["sphere_four_point_lights"] = (HEAD + 4 * 'LightSource "point" "color I" [0.78539819 0.78539819 0.78539819]\n' +
                                       'Material "matte" "color Kd" [.5 .5 .5]\nReverseOrientation\nShape "sphere" "float radius" [1]\nWorldEnd\n')
+# scene 4 (:167-203): UberMaterial(Kd .25, Ks 0, Kr .5, Kt 0, roughness 0, opacity 1, eta 1, no bump map, remap false), PointLight(3 pi).
+# With eta = 1 FresnelDielectric(1, 1) is 0, so the Kr lobe reflects nothing: it only takes half of the path samples (which end
+# there), the Lambertian lobe carries 0.25 with weight 2: 0.75 + 0.75 / 4 + ... = 1.  float(3. * Pi) = 9.42477798
+SCENES["sphere_uber_point_light"] = (HEAD + 'LightSource "point" "color I" [9.424778 9.424778 9.424778]\n'
+                                     'Material "uber" "color Kd" [.25 .25 .25] "color Ks" [0 0 0] "color Kr" [.5 .5 .5] "color Kt" [0 0 0] '
+                                     '"float roughness" [0] "color opacity" [1 1 1] "float index" [1] "bool remaproughness" ["false"]\n'
+                                     'ReverseOrientation\nShape "sphere" "float radius" [1]\nWorldEnd\n')
 # Not one of the reference's scenes: its analytic set has no infinite light.  The same furnace lit by the environment alone cannot
 # work (the closed sphere hides it), so the check is the open counterpart: a convex matte object (Kd = 0.5) floating in a constant
 # environment of radiance 1 reflects exactly Kd * 1 towards every viewer — no inter-reflection, every bounce escapes — and the

@@ -157,6 +157,15 @@ CASES = {
                                             'LightSource "point" "point from" [1 -2 4] "color I" [10 10 10]\n' + MATTE +
                                             'ObjectBegin "bump"\nShape "trianglemesh" ' + BUMPY + '\nObjectEnd\n'
                                             'ObjectInstance "bump"\nAttributeBegin\nTranslate 0 0 -1\nScale 2 2 1\nMaterial "mirror"\nObjectInstance "bump"\nAttributeEnd\n'),
+    # UberMaterial (materials/uber.cpp): every lobe at once — 1 - opacity straight through, Lambertian, anisotropic microfacet with
+    # FresnelDielectric(1, e), specular reflection and specular transmission — under a sphere and a point light; then the "leaf" use of
+    # it (diffuse + partial opacity, as scenes/living-room's Leaves) and the reference's furnace material (Kd + Kr, index 1)
+    "uber_all_lobes": _scene(SPHERE_LIGHT + 'LightSource "point" "point from" [-2 -2 3] "color I" [5 5 7]\n' + MATTE + 'Shape "trianglemesh" ' + FLOOR + '\n'
+                             'Material "uber" "color Kd" [.3 .25 .2] "color Ks" [.3 .3 .3] "color Kr" [.2 .2 .25] "color Kt" [.2 .25 .2] "color opacity" [.7 .7 .8] '
+                             '"float uroughness" [.1] "float vroughness" [.25] "float index" [1.4]\nShape "trianglemesh" ' + BUMPY + "\n", spp=8),
+    "uber_leaf_and_furnace_material": _scene(SPHERE_LIGHT + MATTE + 'Shape "trianglemesh" ' + FLOOR + '\nMaterial "uber" "color Kd" [.2 .5 .1] "color Ks" [0 0 0] "color opacity" [.5 .5 .5]\n'
+                                             'Shape "trianglemesh" ' + BUMPY + '\nAttributeBegin\nMaterial "uber" "color Kd" [.25 .25 .25] "color Ks" [0 0 0] "color Kr" [.5 .5 .5] "float index" [1]\n'
+                                             'Translate -1 .5 .6\nShape "sphere" "float radius" [.5]\nAttributeEnd\n', spp=8),
     "no_lights": _scene(GEOM),
     "empty_scene": _scene(""),
     "light_only": _scene(SPHERE_LIGHT),

@@ -94,7 +94,8 @@ class ShapeDesc(C.Structure):
 
 class MaterialDesc(C.Structure):
     _fields_ = [("type", C.c_int32), ("Kd", C.c_float * 3), ("sigma", C.c_float), ("Ks", C.c_float * 3), ("roughness", C.c_float),
-                ("remap_roughness", C.c_int32), ("kd_texture", C.c_int32), ("ks_texture", C.c_int32)]
+                ("remap_roughness", C.c_int32), ("kd_texture", C.c_int32), ("ks_texture", C.c_int32),
+                ("Kr", C.c_float * 3), ("Kt", C.c_float * 3), ("opacity", C.c_float * 3), ("eta", C.c_float)]
 
 
 class TextureLevel(C.Structure):

@@ -424,14 +424,15 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     std::vector<DevMaterial> mats(d->n_materials);
     for (uint32_t m = 0; m < d->n_materials; ++m) {
         const HprtMaterialDesc &in = d->materials[m];
-        if (in.type < 0 || in.type > 5) return SetError(HPRT_E_UNSUPPORTED, "material type outside the hot-path scope (matte, plastic, mirror, substrate, metal, glass)");
+        if (in.type < 0 || in.type > 6) return SetError(HPRT_E_UNSUPPORTED, "material type outside the hot-path scope (matte, plastic, mirror, substrate, metal, glass, uber)");
         if (in.kd_texture >= (int32_t)d->n_textures || in.ks_texture >= (int32_t)d->n_textures) return SetError(HPRT_E_INVALID, "material texture index out of range");
         DevMaterial &o = mats[m];
         o.KdTex = in.kd_texture >= 0 ? in.kd_texture : -1; o.KsTex = in.ks_texture >= 0 ? in.ks_texture : -1;
         o.type = in.type; memcpy(o.Kd, in.Kd, 12); memcpy(o.Ks, in.Ks, 12);
         o.alpha = in.remap_roughness ? RoughnessToAlpha(in.roughness) : in.roughness;
         o.alphaY = o.alpha;
-        if (in.type == 3 || in.type == 4) o.alphaY = in.remap_roughness ? RoughnessToAlpha(in.sigma) : in.sigma;      // substrate / metal: sigma carries vroughness
+        if (in.type == 3 || in.type == 4 || in.type == 6) o.alphaY = in.remap_roughness ? RoughnessToAlpha(in.sigma) : in.sigma;      // substrate / metal / uber: sigma carries vroughness
+        memcpy(o.Kr, in.Kr, 12); memcpy(o.Kt, in.Kt, 12); memcpy(o.opacity, in.opacity, 12); o.eta = in.eta;
         if (in.type == 5) o.alpha = in.roughness;      // glass: the index of refraction, as given
         // MatteMaterial: sig = Clamp(sigma, 0, 90); sig != 0 -> OrenNayar(r, sig) (materials/matte.cpp:55-61, core/reflection.h:414-420)
         const float sig = clampf(in.sigma, 0.f, 90.f);
@@ -710,6 +711,7 @@ int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int devic
         mats[i].type = s.type; memcpy(mats[i].Kd, s.Kd, 12); mats[i].sigma = s.sigma; memcpy(mats[i].Ks, s.Ks, 12);
         mats[i].roughness = s.roughness; mats[i].remap_roughness = s.remapRoughness;
         mats[i].kd_texture = s.KdTex; mats[i].ks_texture = s.KsTex;
+        memcpy(mats[i].Kr, s.Kr, 12); memcpy(mats[i].Kt, s.Kt, 12); memcpy(mats[i].opacity, s.opacity, 12); mats[i].eta = s.eta;
     }
     std::vector<std::vector<HprtTextureLevel>> texLevels(sm.textures.size());
     std::vector<HprtTextureDesc> textures(sm.textures.size());

@@ -320,6 +320,8 @@ struct DevBsdf {
     bool oren; float orenA, orenB;      // the diffuse lobe is OrenNayar, not LambertianReflection
     float alphaY;          // Trowbridge-Reitz alpha along v (== alpha for plastic)
     float eta;             // BSDF::eta (1 unless glass)
+    float frI, frT;        // FresnelDielectric(frI, frT) of the microfacet lobe: (1.5, 1) for plastic, (1, e) for uber
+    const DevMaterial *uber;   // kind 5 (UberMaterial): the material, for the specular lobes only Sample_f(BSDF_ALL) can pick (kr, kt, 1 - opacity)
     int kind;              // 0: the lobes above; 4 (with hasR): ONE FresnelSpecular lobe (glass: Rr = R, Rd = T, eta); 2: ONE FresnelBlend lobe (substrate: Rd, Rs, alpha, alphaY); 3: ONE conductor
                            // microfacet lobe (metal: Rd = eta, Rs = k, R = 1).  Kinds 2 and 3 are flagged hasS (a glossy reflection lobe)
 };
@@ -458,7 +460,7 @@ __device__ __forceinline__ rgb mf_f(const DevBsdf &b, vec3 wo, vec3 wi) {
     wh = normalize(wh);
     // FresnelDielectric(1.5, 1) (plastic), or FresnelConductor(1, eta, k) with R = 1 (metal: Rd = eta, Rs = k)
     if (b.kind == 3) return rgb(1.f) * tr_D(b.alpha, b.alphaY, wh) * tr_G(b.alpha, b.alphaY, wo, wi) * fr_conductor(fabsf(dot(wi, wh)), b.Rd, b.Rs) / (4 * cosThetaI * cosThetaO);
-    rgb F(fr_dielectric(dot(wi, wh), 1.5f, 1.f));
+    rgb F(fr_dielectric(dot(wi, wh), b.frI, b.frT));
     return b.Rs * tr_D(b.alpha, b.alphaY, wh) * tr_G(b.alpha, b.alphaY, wo, wi) * F / (4 * cosThetaI * cosThetaO);
 }
 __device__ __forceinline__ float mf_pdf(const DevBsdf &b, vec3 wo, vec3 wi) {
@@ -605,7 +607,19 @@ __device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, D
     b->alpha = 0; b->hasD = false; b->hasS = false; b->Rd = rgb(0.f); b->Rs = rgb(0.f);
     b->hasR = false; b->Rr = rgb(0.f); b->oren = false; b->orenA = 1.f; b->orenB = 0.f;
     const DevMaterial m = sc.materials[sc.shapes[si.shape].material];
-    b->alphaY = 0; b->kind = 0; b->eta = 1.f;
+    b->alphaY = 0; b->kind = 0; b->eta = 1.f; b->frI = 1.5f; b->frT = 1.f; b->uber = nullptr;
+    if (m.type == 6) {      // UberMaterial, materials/uber.cpp:45-108: Lambertian + microfacet (FresnelDielectric(1, e)) as the plastic pair, and up to
+                            // three specular lobes (1 - opacity straight through, Kr, Kt) that only the next-segment sampling sees (bsdf_sample all = true)
+        const rgb op = clamp0(rgb(m.opacity[0], m.opacity[1], m.opacity[2]));
+        const rgb t = clamp0(-op + rgb(1.f));
+        b->kind = 5; b->uber = &sc.materials[sc.shapes[si.shape].material];
+        b->eta = is_black(t) ? m.eta : 1.f;
+        const rgb kd = op * clamp0(kdOverride ? *kdOverride : rgb(m.Kd[0], m.Kd[1], m.Kd[2]));
+        if (!is_black(kd)) { b->hasD = true; b->Rd = kd; }
+        const rgb ks = op * clamp0(ksOverride ? *ksOverride : rgb(m.Ks[0], m.Ks[1], m.Ks[2]));
+        if (!is_black(ks)) { b->hasS = true; b->Rs = ks; b->alpha = m.alpha; b->alphaY = m.alphaY; b->frI = 1.f; b->frT = m.eta; }
+        return;
+    }
     if (m.type == 5) {      // GlassMaterial, smooth (materials/glass.cpp:44-65 with allowMultipleLobes): one FresnelSpecular lobe
         b->eta = m.alpha;
         const rgb R = clamp0(ksOverride ? *ksOverride : rgb(m.Ks[0], m.Ks[1], m.Ks[2])), T = clamp0(kdOverride ? *kdOverride : rgb(m.Kd[0], m.Kd[1], m.Kd[2]));
@@ -666,7 +680,58 @@ __device__ __forceinline__ float bsdf_pdf(const DevBsdf &b, vec3 woW, vec3 wiW) 
 }
 // BSDF::Sample_f, core/reflection.cpp:703-762.  *pdf keeps its incoming value on the
 // "wo.z == 0" early return, as in the reference.
-__device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW, float u0, float u1, float *pdf, int *sampledType) {
+// all: Sample_f(BSDF_ALL) of the path's next segment (integrators/path.cpp:147-148); false: EstimateDirect's Sample_f(BSDF_ALL & ~BSDF_SPECULAR).
+// They differ only for UberMaterial, the one BSDF here that mixes specular and non-specular lobes.
+__device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW, float u0, float u1, float *pdf, int *sampledType, bool all = false) {
+    int nBefore = 0, nAfter = 0;      // uber's specular lobes in front of / behind the Lambertian + microfacet pair, in the order uber.cpp adds them
+    rgb uT0(0.f), uKr(0.f), uKt(0.f);
+    if (all && b.kind == 5) {
+        const DevMaterial &m = *b.uber;
+        const rgb op = clamp0(rgb(m.opacity[0], m.opacity[1], m.opacity[2]));
+        uT0 = clamp0(-op + rgb(1.f));
+        uKr = op * clamp0(rgb(m.Kr[0], m.Kr[1], m.Kr[2])); uKt = op * clamp0(rgb(m.Kt[0], m.Kt[1], m.Kt[2]));
+        nBefore = is_black(uT0) ? 0 : 1;
+        nAfter = (is_black(uKr) ? 0 : 1) + (is_black(uKt) ? 0 : 1);
+    }
+    if (nBefore + nAfter > 0) {
+        const int matchingAll = nBefore + bsdf_num(b) + nAfter;
+        const int compAll = sel_min((int)floorf(u0 * matchingAll), matchingAll - 1);
+        const bool pickT0 = nBefore == 1 && compAll == 0;
+        const int afterIdx = compAll - nBefore - bsdf_num(b);      // >= 0: a lobe behind the pair
+        if (pickT0 || afterIdx >= 0) {
+            const vec3 wo = to_local(b, woW);
+            if (wo.z == 0) return rgb(0.f);
+            *pdf = 0;
+            const bool pickR = !pickT0 && !is_black(uKr) && afterIdx == 0;
+            const float e = b.uber->eta;
+            if (pickR) {      // SpecularReflection(kr, FresnelDielectric(1, e)), core/reflection.cpp:136-143
+                const vec3 wi(-wo.x, -wo.y, wo.z);
+                *sampledType = BX_REFLECTION | BX_SPECULAR;
+                *pdf = 1.f / matchingAll;      // (pdf = 1, then "/= matchingComps", :748)
+                *wiW = to_world(b, wi);
+                return rgb(fr_dielectric(cos_theta(wi), 1.f, e)) * uKr / abs_cos_theta(wi);
+            }
+            // SpecularTransmission(T, etaA = 1, etaB), core/reflection.cpp:145-163 (TransportMode::Radiance): T0 = 1 - opacity with etaB = 1, or kt with etaB = e
+            const rgb T = pickT0 ? uT0 : uKt;
+            const float etaB = pickT0 ? 1.f : e;
+            const bool entering = cos_theta(wo) > 0;
+            const float etaI = entering ? 1.f : etaB, etaT = entering ? etaB : 1.f;
+            const vec3 n = face_forward(vec3(0.f, 0.f, 1.f), wo);
+            const float er = etaI / etaT;
+            const float cosThetaI = dot(n, wo);
+            const float sin2ThetaI = sel_max(0.f, 1 - cosThetaI * cosThetaI);
+            const float sin2ThetaT = er * er * sin2ThetaI;
+            if (sin2ThetaT >= 1) { *sampledType = 0; return rgb(0.f); }      // Refract() failed: BSDF::Sample_f sees pdf == 0
+            const float cosThetaT = sqrtf(1 - sin2ThetaT);
+            const vec3 wi = er * -wo + (er * cosThetaI - cosThetaT) * n;
+            rgb ft = T * (rgb(1.f) - rgb(fr_dielectric(cos_theta(wi), 1.f, etaB)));
+            ft = ft * ((etaI * etaI) / (etaT * etaT));
+            *sampledType = BX_SPECULAR | BX_TRANSMISSION;
+            *pdf = 1.f / matchingAll;
+            *wiW = to_world(b, wi);
+            return ft / abs_cos_theta(wi);
+        }
+    }
     if (b.hasR) {
         // the one lobe is SpecularReflection (core/reflection.cpp:136-143; FresnelNoOp::Evaluate == Spectrum(1.)): BSDF::Sample_f
         // returns its value as sampled, with its pdf of 1 (:744-760 skip specular lobes)
@@ -707,11 +772,13 @@ __device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW
         *wiW = to_world(b, wi);
         return rgb(1.f) * b.Rr / abs_cos_theta(wi);
     }
-    const int matching = bsdf_num(b);
+    const int nPair = bsdf_num(b);
+    const int matching = nBefore + nPair + nAfter;      // (nBefore = nAfter = 0 unless an uber BSDF is sampled over all its lobes)
     if (matching == 0) { *pdf = 0; *sampledType = 0; return rgb(0.f); }
-    const int comp = sel_min((int)floorf(u0 * matching), matching - 1);
-    const bool pickSpec = (matching == 2) ? (comp == 1) : b.hasS;
-    const float ur0 = sel_min(u0 * matching - comp, HPRT_ONE_MINUS_EPS);
+    const int compAll = sel_min((int)floorf(u0 * matching), matching - 1);
+    const int comp = compAll - nBefore;                 // within the Lambertian / microfacet pair (the specular picks returned above)
+    const bool pickSpec = (nPair == 2) ? (comp == 1) : b.hasS;
+    const float ur0 = sel_min(u0 * matching - compAll, HPRT_ONE_MINUS_EPS);
     vec3 wi, wo = to_local(b, woW);
     if (wo.z == 0) return rgb(0.f);
     *pdf = 0;
@@ -744,7 +811,7 @@ __device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW
     }
     if (*pdf == 0) { *sampledType = 0; return rgb(0.f); }
     *wiW = to_world(b, wi);
-    if (matching > 1) *pdf += pickSpec ? lambert_pdf(wo, wi) : mf_pdf(b, wo, wi);
+    if (nPair > 1) *pdf += pickSpec ? lambert_pdf(wo, wi) : mf_pdf(b, wo, wi);      // (the other matching lobes; specular ones have Pdf() == 0)
     if (matching > 1) *pdf /= matching;
     bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
     rgb f(0.f);

@@ -944,7 +944,7 @@ __global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, Path
             dim += 2;
             vec3 wo = -rayD, wi;
             float pdf = 0; int flags = 0;
-            rgb f = bsdf_sample(bsdf, wo, &wi, ub0, ub1, &pdf, &flags);
+            rgb f = bsdf_sample(bsdf, wo, &wi, ub0, ub1, &pdf, &flags, true);
             if (!(is_black(f) || pdf == 0.f)) {
                 beta = beta * (f * absdot(wi, si.ns) / pdf);
                 vec3 o = offset_ray_origin(si.p, si.pErr, si.n, wi);

@@ -450,6 +450,8 @@ struct rgb {
     HPRT_HD rgb(float r_, float g_, float b_) : r(r_), g(g_), b(b_) {}
 };
 HPRT_HD rgb operator+(rgb a, rgb b) { return rgb(a.r + b.r, a.g + b.g, a.b + b.b); }
+HPRT_HD rgb operator-(rgb a, rgb b) { return rgb(a.r - b.r, a.g - b.g, a.b - b.b); }
+HPRT_HD rgb operator-(rgb a) { return rgb(-a.r, -a.g, -a.b); }
 HPRT_HD rgb operator*(rgb a, rgb b) { return rgb(a.r * b.r, a.g * b.g, a.b * b.b); }
 HPRT_HD rgb operator*(rgb a, float s) { return rgb(a.r * s, a.g * s, a.b * s); }
 HPRT_HD rgb operator*(float s, rgb a) { return rgb(a.r * s, a.g * s, a.b * s); }

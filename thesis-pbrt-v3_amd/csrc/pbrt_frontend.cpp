@@ -325,6 +325,25 @@ struct Frontend {
             if (floatParam(geom, *mp, "uroughness", 0.f) != 0.f || floatParam(geom, *mp, "vroughness", 0.f) != 0.f)
                 warn("rough glass (MicrofacetTransmission) is outside the hot-path scope; rendered as smooth glass");
             (void)(mp->find("remaproughness", "bool") || geom.find("remaproughness", "bool"));      // (read by the reference; only rough glass uses it)
+        } else if (name == "uber") {        // CreateUberMaterial, materials/uber.cpp:110-140 (constant parameters; Kd / Ks may be image textures)
+            const float q[3] = {0.25f, 0.25f, 0.25f}, zero[3] = {0.f, 0.f, 0.f}, one[3] = {1.f, 1.f, 1.f};
+            m.type = kUber;
+            spectrumParam(geom, *mp, "Kd", q, m.Kd, &m.KdTex);
+            spectrumParam(geom, *mp, "Ks", q, m.Ks, &m.KsTex);
+            spectrumParam(geom, *mp, "Kr", zero, m.Kr);
+            spectrumParam(geom, *mp, "Kt", zero, m.Kt);
+            spectrumParam(geom, *mp, "opacity", one, m.opacity);
+            const float rough = floatParam(geom, *mp, "roughness", .1f);
+            const bool hasU = mp->find("uroughness", "float") || geom.find("uroughness", "float") || !mp->texture("uroughness").empty() || !geom.texture("uroughness").empty();
+            const bool hasV = mp->find("vroughness", "float") || geom.find("vroughness", "float") || !mp->texture("vroughness").empty() || !geom.texture("vroughness").empty();
+            m.roughness = hasU ? floatParam(geom, *mp, "uroughness", rough) : rough;      // roughu = uroughness or roughness; roughv = vroughness or roughu (:76-85)
+            m.sigma = hasV ? floatParam(geom, *mp, "vroughness", m.roughness) : m.roughness;
+            const bool hasEta = mp->find("eta", "float") || geom.find("eta", "float") || !mp->texture("eta").empty() || !geom.texture("eta").empty();
+            m.eta = hasEta ? floatParam(geom, *mp, "eta", 1.5f) : floatParam(geom, *mp, "index", 1.5f);
+            bool remap = true;
+            const Param *rp = geom.find("remaproughness", "bool"); if (!rp) rp = mp->find("remaproughness", "bool");
+            if (rp && rp->bools.size() == 1) remap = rp->bools[0];
+            m.remapRoughness = remap ? 1 : 0;
         } else if (name == "mirror") {      // CreateMirrorMaterial, materials/mirror.cpp:58-64
             const float dk[3] = {0.9f, 0.9f, 0.9f};
             m.type = kMirror;

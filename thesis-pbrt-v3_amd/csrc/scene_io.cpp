@@ -38,11 +38,14 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
     // section (objects, instances, top-level creation order) and is written only when needed.
     const bool instancing = sc.nObjects > 0 || !sc.instances.empty();
     // version 3 = version 2's layout (instancing section always present) followed by the image textures
-    const bool textured = !sc.textures.empty();
-    // version 4 = version 3's layout followed by the map index and the transforms of the infinite lights (in light order)
-    bool infinite = false;
+    bool infinite = false, uber = false;
     for (const LightDesc &l : sc.lights) if (l.type == kInfiniteLight) infinite = true;
-    o.raw("HPRTSCN1", 8); o.u32(infinite ? 4u : textured ? 3u : instancing ? 2u : 1u);
+    for (const MaterialDesc &m : sc.materials) if (m.type == kUber) uber = true;
+    // (versions 4 and 5 append to version 3's layout, so its sections are written even when they are empty)
+    const bool textured = !sc.textures.empty() || infinite || uber;
+    // version 4 = version 3's layout followed by the map index and the transforms of the infinite lights (in light order);
+    // version 5 = version 4's followed by Kr, Kt, opacity, eta of the uber materials (in material order)
+    o.raw("HPRTSCN1", 8); o.u32(uber ? 5u : infinite ? 4u : textured ? 3u : instancing ? 2u : 1u);
     o.i32(p.xres); o.i32(p.yres);
     o.raw(p.crop, 16);
     o.raw(p.filterRadius, 8); o.i32(p.filterType);
@@ -94,9 +97,12 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
             for (const MipLevel &l : t.levels) { o.i32(l.w); o.i32(l.h); o.raw(l.rgb.data(), 4 * l.rgb.size()); }
         }
     }
-    if (infinite)      // (an infinite light owns a map, so the texture section above is present)
+    if (infinite || uber)
         for (const LightDesc &l : sc.lights)
             if (l.type == kInfiniteLight) { o.i32(l.texture); o.raw(&l.lightToWorld, 64); o.raw(&l.worldToLight, 64); }
+    if (uber)
+        for (const MaterialDesc &m : sc.materials)
+            if (m.type == kUber) { o.raw(m.Kr, 12); o.raw(m.Kt, 12); o.raw(m.opacity, 12); o.f32(m.eta); }
     bool ok = o.ok;
     if (fclose(fp) != 0) ok = false;
     if (!ok) *err = "write error on " + path;
@@ -114,7 +120,7 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
     char magic[8]; in.raw(magic, 8);
     if (!in.ok || memcmp(magic, "HPRTSCN1", 8) != 0) return fail("not a baked hprt scene");
     const uint32_t version = in.u32();
-    if (version < 1 || version > 4) return fail("unsupported version");
+    if (version < 1 || version > 5) return fail("unsupported version");
     RenderOptions &p = sc->opt;
     p.xres = in.i32(); p.yres = in.i32();
     in.raw(p.crop, 16);
@@ -132,7 +138,10 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
     if (!fits(32ull * nMat + 20ull * nShapes + 36ull * nLights)) return fail("truncated or corrupt header (counts exceed the file)");
     sc->materials.resize(nMat);
     for (MaterialDesc &m : sc->materials) {
+        memset(&m, 0, sizeof(m));
         m.type = in.i32(); in.raw(m.Kd, 12); m.sigma = in.f32(); in.raw(m.Ks, 12); m.roughness = in.f32(); m.remapRoughness = in.i32();
+        m.opacity[0] = m.opacity[1] = m.opacity[2] = 1.f; m.eta = 1.5f;
+        if (m.type < 0 || m.type > kUber || (m.type == kUber && version < 5)) return fail("material type out of range");
     }
     sc->shapes.resize(nShapes);
     for (ShapeDesc &s : sc->shapes) {
@@ -212,6 +221,9 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
                 l.texture = in.i32(); in.raw(&l.lightToWorld, 64); in.raw(&l.worldToLight, 64);
                 if (!in.ok || l.texture < 0 || (size_t)l.texture >= sc->textures.size()) return fail("infinite light map out of range");
             }
+    if (version >= 5)
+        for (MaterialDesc &m : sc->materials)
+            if (m.type == kUber) { in.raw(m.Kr, 12); in.raw(m.Kt, 12); in.raw(m.opacity, 12); m.eta = in.f32(); }
     if (!in.ok) return fail("truncated file");
     fclose(fp);
     return true;

@@ -11,7 +11,7 @@
 
 namespace hprt {
 
-enum MaterialType { kMatte = 0, kPlastic = 1, kMirror = 2, kSubstrate = 3, kMetal = 4, kGlass = 5 };
+enum MaterialType { kMatte = 0, kPlastic = 1, kMirror = 2, kSubstrate = 3, kMetal = 4, kGlass = 5, kUber = 6 };
 // mirror: Kr travels in Ks.  substrate: roughness = uroughness, sigma = vroughness.  metal: Kd = eta, Ks = k, roughness / sigma likewise.  glass: Kd = Kt, Ks = Kr, roughness = eta (index).
 enum LightType { kPointLight = 0, kDistantLight = 1, kDiffuseAreaLight = 2, kInfiniteLight = 3 };
 enum ShapeKind { kTriangleMesh = 0, kSphere = 1 };
@@ -21,6 +21,8 @@ struct MaterialDesc {
     int32_t type;
     float Kd[3]; float sigma; float Ks[3]; float roughness; int32_t remapRoughness;
     int32_t KdTex, KsTex;     // index into SceneModel::textures when the parameter is an image texture, else -1
+    // uber (materials/uber.cpp; roughness = uroughness, sigma = vroughness): what the other materials do not have
+    float Kr[3], Kt[3], opacity[3], eta;
 };
 
 // ImageTexture<RGBSpectrum, Spectrum> (textures/imagemap.h) with its finished MIPMap (core/mipmap.h): the pyramid
