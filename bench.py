@@ -55,7 +55,7 @@ WORKLOADS = {
                "halton %d spp, path maxdepth 5, bvh", 1024, 64, "synthetic (procedural stand-in geometry, tools/scene_gen.py)"),
     "killeroo-simple": ("killeroo-simple (66,532 tris + sphere area light) 700x700, halton %d spp, path maxdepth 5, bvh", 256, 128,
                         "reference asset scenes/killeroo-simple, baked (tests/golden/killeroo_simple.hprt)"),
-    "living-room": ("living room (143,163 tris of the reference's scenes/living-room meshes with its matte / OrenNayar / substrate / metal / mirror / glass materials; uber as matte, textures as constants, point light for its missing sky map) "
+    "living-room": ("living room (143,163 tris of the reference's scenes/living-room meshes with its matte / OrenNayar / substrate / metal / mirror / glass / uber materials; textures as constants, point light for its missing sky map) "
                     "1280x720, halton %d spp, path maxdepth 5, bvh", 256, 32, "reference meshes, baked (tests/golden/living_room.hprt)"),
 }
 

@@ -31,9 +31,9 @@ gets the resulting files with the repository snapshot.
                          not in the repository) by a point light under the ceiling, sobol by halton, the triangle filter
                          by the box filter, maxdepth 65 by 5, image-mapped parameters by constants (two of the four
                          image files are not in the repository, the float pyramids of the others would add 37 MB).
-                         Its matte (incl. the OrenNayar plant pot), substrate, metal, mirror and glass materials are kept
-                         (round 2); uber (the plant's leaves, with an opacity map) becomes matte with its Kd (front-end
-                         substitution, recorded as warnings).
+                         Its matte (incl. the OrenNayar plant pot), substrate, metal, mirror, glass and uber materials are
+                         kept (round 2; the uber leaves without their opacity MAP: opacity 1): the front-end reports no
+                         substitution for this text.
                          No reference render exists for it (the
                          checked-in TungstenRender.png is another renderer's): it pins nothing, it is a workload.
 """
