@@ -308,6 +308,38 @@ void orc_sincosf_vs_libm(uint32_t first, uint32_t stride, uint64_t count, uint64
 }
 double orc_det_sin(double x) { return det::sin_d(x); }
 double orc_det_cos(double x) { return det::cos_d(x); }
+double orc_det_sin_glibc(double x) { return det::sin_glibc_d(x); }
+double orc_det_cos_glibc(double x) { return det::cos_glibc_d(x); }
+// Array form of the probes above for the GPU-side comparison (tests/test_gpu_math.py): same fn numbering and outputs as the
+// product's hprt_debug_device_math; libm != 0 evaluates this machine's libm instead of the restatements.
+void orc_math_eval(int fn, int libm, const float *x, const float *y, uint64_t n, double *o0, double *o1) {
+    for (uint64_t i = 0; i < n; ++i) {
+        double a = 0, b = 0;
+        volatile float xv = x[i], yv = y[i];
+        if (fn == 0) { a = libm ? (double)sinf(xv) : (double)det::sinf_glibc(x[i]); b = libm ? (double)cosf(xv) : (double)det::cosf_glibc(x[i]); }
+        else if (fn == 1) a = libm ? (double)acosf(xv) : (double)det::acosf_glibc(x[i]);
+        else if (fn == 2) a = libm ? (double)atan2f(yv, xv) : (double)det::atan2f_glibc(y[i], x[i]);
+        else if (fn == 3) a = libm ? (double)logf(xv) : (double)det::logf_glibc(x[i]);
+        else { volatile double xd = (double)x[i]; a = libm ? ::sin(xd) : det::sin_glibc_d((double)x[i]); b = libm ? ::cos(xd) : det::cos_glibc_d((double)x[i]); }
+        o0[i] = a; o1[i] = b;
+    }
+}
+// The restated double sin / cos against this process's libm on the float arguments with bit patterns first, first+stride, ...
+// (count of them) inside [0, 2 pi) — the domain of the one call site, core/microfacet.cpp:243-245; out[0] = sin, out[1] = cos mismatches
+void orc_sincos_d_vs_libm(uint32_t first, uint32_t stride, uint64_t count, uint64_t out[2]) {
+    uint64_t bs = 0, bc = 0;
+    uint32_t u = first;
+    for (uint64_t i = 0; i < count; ++i, u += stride) {
+        if (u > 0x40c90fdau) break;                     // (float)(6.28318530718 * 0x1.fffffep-1)
+        float y; memcpy(&y, &u, 4);
+        volatile double yy = (double)y;
+        double a = ::sin(yy), b = det::sin_glibc_d((double)y);
+        if (memcmp(&a, &b, 8)) ++bs;
+        a = ::cos(yy); b = det::cos_glibc_d((double)y);
+        if (memcmp(&a, &b, 8)) ++bc;
+    }
+    out[0] = bs; out[1] = bc;
+}
 float orc_det_atan2f(float y, float x) { return det::atan2f_glibc(y, x); }
 float orc_det_acosf(float x) { return det::acosf_glibc(x); }
 // logf mismatches against libm over positive finite float bit patterns first, first+stride, ...

@@ -683,6 +683,43 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
 __attribute__((visibility("default"))) int hprt_debug_poison_workspace(HprtScene *s, int byte) { if (!s) return HPRT_E_INVALID; s->poisonByte = byte < 0 ? -1 : (byte & 255); return HPRT_OK; }
 __attribute__((visibility("default"))) int hprt_debug_voxel_points(float out[640]) { if (!out) return HPRT_E_INVALID; VoxelSamplePoints(out); return HPRT_OK; }
 
+// Diagnostics hook (not part of include/hprt.h): the restated libm functions of hprt_math.h evaluated ON THE DEVICE over host
+// arrays, so that a test can hold them against the oracle's (which equal glibc's, tests/test_oracle_pins.py) directly rather
+// than through renders.  fn 0: sinf / cosf of x -> out0 / out1; 1: acosf(x) -> out0; 2: atan2f(y, x) -> out0; 3: logf(x) -> out0;
+// 4: double sin / cos of (double)x -> out0 / out1.  Outputs are doubles (a float result converts exactly).
+__global__ void k_debug_math(int fn, const float *x, const float *y, size_t n, double *o0, double *o1) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = 0, b = 0;
+    if (fn == 0) { float s, c; det_sincosf(x[i], &s, &c); a = (double)s; b = (double)c; }
+    else if (fn == 1) a = (double)det_acosf(x[i]);
+    else if (fn == 2) a = (double)det_atan2f(y[i], x[i]);
+    else if (fn == 3) a = (double)det_logf(x[i]);
+    else det_sincos_glibc_d((double)x[i], &a, &b);
+    o0[i] = a; o1[i] = b;
+}
+__attribute__((visibility("default"))) int hprt_debug_device_math(int device, int fn, const float *x, const float *y, size_t n, double *out0, double *out1) try {
+    if (fn < 0 || fn > 4 || !x || !y || !out0 || !out1 || n == 0 || n > ((size_t)1 << 28)) return SetError(HPRT_E_INVALID, "hprt_debug_device_math: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    float *dx = nullptr, *dy = nullptr; double *d0 = nullptr, *d1 = nullptr;
+    auto release = [&]() { (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(d0); (void)hipFree(d1); };
+    hipError_t e = hipMalloc((void **)&dx, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&dy, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d0, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d1, n * 8);
+    if (e == hipSuccess) e = hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_debug_math<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(fn, dx, dy, n, d0, d1);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out0, d0, n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out1, d1, n * 8, hipMemcpyDeviceToHost);
+    release();
+    if (e != hipSuccess) return SetError(HPRT_E_DEVICE, std::string("hprt_debug_device_math: ") + hipGetErrorString(e));
+    return HPRT_OK;
+} catch (...) { return hprt::HandleException(); }
+
 int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int device, HprtScene **out) try {
     if (!m || !b || !out) return SetError(HPRT_E_INVALID, "hprt_scene_create_from_model: null argument");
     const SceneModel &sm = m->sc;

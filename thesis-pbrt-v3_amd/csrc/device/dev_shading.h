@@ -373,7 +373,7 @@ __device__ __forceinline__ void tr_sample11(float cosTheta, float U1, float U2, 
     if ((double)cosTheta > .9999) {
         float r = sqrtf(U1 / (1 - U1));
         float phi = (float)(6.28318530718 * (double)U2);
-        double sn, cs; det_sincos((double)phi, &sn, &cs);
+        double sn, cs; det_sincos_glibc_d((double)phi, &sn, &cs);      // ::sin / ::cos of glibc, bit for bit
         *slope_x = (float)((double)r * cs);   // float * ::cos(double) -> double -> float
         *slope_y = (float)((double)r * sn);
         return;

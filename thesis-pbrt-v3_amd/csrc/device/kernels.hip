@@ -717,8 +717,20 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
 // registers than a larger workgroup can have).
 // TEX: scenes with image textures get their own instance of the generic variant (the lookups cost registers and a
 // call stack that every other scene would pay for in occupancy).
+// Waves per SIMD the register allocation of each variant is held to (second __launch_bounds__ argument): matte 111 and plastic
+// 120 registers -> four, generic 164 -> three, which is what the allocator picks on its own; the knobs exist for A/B builds
+// (tools/build_variant.sh).
+#ifndef HPRT_SHADE_WAVES_MATTE
+#define HPRT_SHADE_WAVES_MATTE 4
+#endif
+#ifndef HPRT_SHADE_WAVES_PLASTIC
+#define HPRT_SHADE_WAVES_PLASTIC 4
+#endif
+#ifndef HPRT_SHADE_WAVES_GENERIC
+#define HPRT_SHADE_WAVES_GENERIC 3
+#endif
 template <int MODE, int BS, bool TEX = false>
-__global__ __launch_bounds__(BS) void k_shade(DevScene sc, RenderParams rp, PathStream in, HitStream hit, uint32_t s0,
+__global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 ? HPRT_SHADE_WAVES_PLASTIC : HPRT_SHADE_WAVES_GENERIC) void k_shade(DevScene sc, RenderParams rp, PathStream in, HitStream hit, uint32_t s0,
                                                PathStream out, VertexStreams vs, QueueSet q, BinSet bins, float4 *Lfinal, uint32_t firstBounce) {
     __shared__ HaltonLds hl;
     __shared__ BlockAppendLds al;
