@@ -1,6 +1,6 @@
 """Randomised scene parity on the GPU: seeded compositions of everything the path supports — every light kind and light sample
 strategy, every material with random parameters, image textures, partial spheres, meshes with and without uv / normals,
-object instances under random (also mirroring) transforms, depth of field, odd resolutions, crop windows, spp 1-8,
+object instances under random (also mirroring) transforms, exactly coincident surfaces of different materials, depth of field, odd resolutions, crop windows, spp 1-8,
 maxdepth 0-12, the Russian-roulette threshold — in combinations the hand-written cases of test_gpu_scenes.py /
 test_gpu_textures.py do not reach.  Each scene is .pbrt text parsed by the product front-end (no warnings allowed), rendered
 by the HIP path through the C ABI and by the oracle: films and work counters must be identical; the film must also not
@@ -149,7 +149,11 @@ def random_scene(seed):
         body += "AttributeBegin\n" + _material(rng, textures) + _transform(rng)
         if rng.random() < .2:
             body += "ReverseOrientation\n"
-        body += _shape(rng) + "AttributeEnd\n"
+        shape = _shape(rng)
+        body += shape
+        if rng.random() < .2:      # the same surface once more with another material: ties in t, settled by the traversal order alone
+            body += _material(rng, textures) + shape
+        body += "AttributeEnd\n"
     nobj = int(rng.choice([0, 0, 1, 2]))
     for k in range(nobj):
         body += 'ObjectBegin "o%d"\n' % k

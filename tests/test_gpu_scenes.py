@@ -166,6 +166,17 @@ CASES = {
     "uber_leaf_and_furnace_material": _scene(SPHERE_LIGHT + MATTE + 'Shape "trianglemesh" ' + FLOOR + '\nMaterial "uber" "color Kd" [.2 .5 .1] "color Ks" [0 0 0] "color opacity" [.5 .5 .5]\n'
                                              'Shape "trianglemesh" ' + BUMPY + '\nAttributeBegin\nMaterial "uber" "color Kd" [.25 .25 .25] "color Ks" [0 0 0] "color Kr" [.5 .5 .5] "float index" [1]\n'
                                              'Translate -1 .5 .6\nShape "sphere" "float radius" [.5]\nAttributeEnd\n', spp=8),
+    # ---- exactly coincident surfaces: every closest-hit ray meets two or three primitives at the SAME t, and which one it reports is
+    #      decided by the reference's traversal order alone (`tScaled <= tMax`-style acceptance: the last one tested wins,
+    #      shapes/triangle.cpp:259-262 + core/primitive.cpp:128).  Different materials make a wrong winner visible in the film. ----
+    "coincident_meshes": _scene(SPHERE_LIGHT + 'Material "matte" "color Kd" [.8 .1 .1]\nShape "trianglemesh" ' + FLOOR + '\n' + PLASTIC + 'Shape "trianglemesh" ' + FLOOR + '\n' +
+                                'Material "matte" "color Kd" [.1 .7 .1]\nShape "trianglemesh" ' + BUMPY + '\nMaterial "mirror"\nShape "trianglemesh" ' + BUMPY + '\n' + MATTE +
+                                'Shape "trianglemesh" ' + BUMPY + "\n", spp=8),
+    "coincident_instance_and_mesh": _scene(SPHERE_LIGHT + 'LightSource "point" "point from" [-2 -2 3] "color I" [5 5 7]\n' + MATTE + 'Shape "trianglemesh" ' + FLOOR + '\n'
+                                           'ObjectBegin "b"\nMaterial "matte" "color Kd" [.1 .2 .8]\nShape "trianglemesh" ' + BUMPY + '\nObjectEnd\n' + PLASTIC +
+                                           'Shape "trianglemesh" ' + BUMPY + '\nObjectInstance "b"\nObjectInstance "b"\n'
+                                           'AttributeBegin\nTranslate 0 0 0\nMaterial "mirror"\nShape "sphere" "float radius" [.4]\nAttributeEnd\n'
+                                           'AttributeBegin\nMaterial "matte" "color Kd" [.9 .9 .1]\nShape "sphere" "float radius" [.4]\nAttributeEnd\n', spp=8),
     "no_lights": _scene(GEOM),
     "empty_scene": _scene(""),
     "light_only": _scene(SPHERE_LIGHT),
