@@ -6,7 +6,7 @@ test_gpu_textures.py do not reach.  Each scene is .pbrt text parsed by the produ
 by the HIP path through the C ABI and by the oracle: films and work counters must be identical; the film must also not
 depend on how the samples are cut into batches or sharded into tiles.
 
-HPRT_FUZZ_N (default 48) scenes starting at seed HPRT_FUZZ_SEED (default 0); `tools/fuzz_parity.sh` runs a long sweep."""
+HPRT_FUZZ_N (default 48) scenes starting at seed HPRT_FUZZ_SEED (default 0), HPRT_FUZZ_SCALE for large frames; `tools/fuzz_parity.sh` runs a long sweep."""
 import os
 
 import numpy as np
@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 
 N = int(os.environ.get("HPRT_FUZZ_N", "48"))
 SEED0 = int(os.environ.get("HPRT_FUZZ_SEED", "0"))
+SCALE = int(os.environ.get("HPRT_FUZZ_SCALE", "1"))      # > 1: frames that many times larger in each direction at twice the spp (millions of paths: many waves, many queue chunks)
 SMALL = _grid_mesh(5, 5, lambda x, y: 0.25 * np.sin(2.3 * x) * np.cos(1.7 * y))
 SMALL_UV = _grid_mesh(7, 6, lambda x, y: 0.2 * np.cos(1.1 * x * y), uv=True)
 BOX = ('"integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0] '
@@ -163,13 +164,13 @@ def random_scene(seed):
         for _ in range(int(rng.integers(1, 4))):
             body += "AttributeBegin\n" + (_material(rng, textures) if rng.random() < .3 else "") + _transform(rng) + 'ObjectInstance "o%d"\nAttributeEnd\n' % k
     # ---- camera / film / sampler / integrator ----
-    xres, yres = int(rng.integers(17, 141)), int(rng.integers(17, 101))
+    xres, yres = int(rng.integers(17, 141)) * SCALE, int(rng.integers(17, 101)) * SCALE
     cam = '"float lensradius" [%g] "float focaldistance" [%g]' % (_f(rng, .02, .2), _f(rng, 4, 8)) if rng.random() < .25 else ""
     film = ""
     if rng.random() < .3:
         a, b, c, d = _f(rng, 0, .4), _f(rng, .6, 1), _f(rng, 0, .4), _f(rng, .6, 1)
         film = '"float cropwindow" [%g %g %g %g]' % (a, b, c, d)
-    spp = int(rng.choice([1, 2, 3, 4, 4, 8]))
+    spp = int(rng.choice([1, 2, 3, 4, 4, 8])) * (2 if SCALE > 1 else 1)
     maxdepth = int(rng.choice([0, 1, 2, 3, 5, 5, 8, 12]))
     integ = ""
     if len(kinds) > 1 or "quad" in kinds or "emesh" in kinds:
