@@ -57,9 +57,11 @@ void orc_bvh_copy(void *h, void *nodes, uint32_t *primOrder) {
 
 // counters: [0]nodesFetched [1]nodesFetchedP [2]nodesEntered [3]nodesEnteredP [4]triTests [5]triTestsP
 //           [6]triHits [7]triHitsP [8]sphereTests [9]sphereTestsP [10]rays [11]shadowRays [12]cameraRays
+// ([4], [6] include Shape::Pdf's tests on triangle emitters as the reference's counters do; [8] counts what the aggregate's traversal tests —
+//  the reference has no sphere statistic, the fork's per-ray primitiveIntersections see the traversal's tests only)
 static void export_counters(const Counters &c, uint64_t *o) {
     o[0] = c.nodesFetched; o[1] = c.nodesFetchedP; o[2] = c.nodesEntered; o[3] = c.nodesEnteredP;
-    o[4] = c.triTests; o[5] = c.triTestsP; o[6] = c.triHits; o[7] = c.triHitsP;
+    o[4] = c.triTests + c.triTestsPdf; o[5] = c.triTestsP; o[6] = c.triHits + c.triHitsPdf; o[7] = c.triHitsP;      // the reference's nTests / nHits: every Triangle::Intersect call
     o[8] = c.sphereTests; o[9] = c.sphereTestsP; o[10] = c.rays; o[11] = c.shadowRays; o[12] = c.cameraRays;
 }
 

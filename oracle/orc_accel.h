@@ -18,6 +18,10 @@ struct Counters {
     uint64_t leavesEntered = 0, leavesEnteredP = 0;  // of those, leaves: ray.stats.leafNodeTraversals[P] (bvh.cpp:370,411)
     uint64_t triTests = 0, triTestsP = 0, triHits = 0, triHitsP = 0;
     uint64_t sphereTests = 0, sphereTestsP = 0;
+    // Shape::Pdf's own Intersect call on an emitter (core/shape.cpp:72-88) does not go through GeometricPrimitive: the fork's
+    // per-ray primitiveIntersections (core/primitive.cpp:119-125) do not see it, the reference's global nTests of
+    // Triangle::Intersect (shapes/triangle.cpp:191) does.  Kept apart so that both statistics can be formed.
+    uint64_t triTestsPdf = 0, triHitsPdf = 0, sphereTestsPdf = 0;
     uint64_t rays = 0, shadowRays = 0, cameraRays = 0;
     void add(const Counters &o) {
         nodesFetched += o.nodesFetched; nodesFetchedP += o.nodesFetchedP;
@@ -25,6 +29,7 @@ struct Counters {
         leavesEntered += o.leavesEntered; leavesEnteredP += o.leavesEnteredP;
         triTests += o.triTests; triTestsP += o.triTestsP; triHits += o.triHits; triHitsP += o.triHitsP;
         sphereTests += o.sphereTests; sphereTestsP += o.sphereTestsP;
+        triTestsPdf += o.triTestsPdf; triHitsPdf += o.triHitsPdf; sphereTestsPdf += o.sphereTestsPdf;
         rays += o.rays; shadowRays += o.shadowRays; cameraRays += o.cameraRays;
     }
 };

@@ -611,7 +611,10 @@ struct Renderer {
             Ray ray = SpawnRay(ref.p, ref.pError, ref.n, wi);
             Float tHit; SurfaceInteraction isectLight;
             TriRef tr{&m, &m.idx[3 * tri], (bool)((sh.reverseOrientation != 0) ^ (sh.swapsHandedness != 0))};
-            if (!TriangleIntersect(tr, ray, &tHit, &isectLight, ctr)) return 0;
+            Counters own;      // (this test is not the aggregate's: orc_accel.h Counters)
+            const bool found = TriangleIntersect(tr, ray, &tHit, &isectLight, own);
+            ctr.triTestsPdf += own.triTests; ctr.triHitsPdf += own.triHits;
+            if (!found) return 0;
             const int *v = &m.idx[3 * tri];
             Float pdf = DistanceSquared(ref.p, isectLight.p) / (AbsDot(isectLight.n, -wi) * TriangleArea(m.p[v[0]], m.p[v[1]], m.p[v[2]]));
             if (std::isinf(pdf)) pdf = 0.f;
@@ -625,7 +628,10 @@ struct Renderer {
             Ray ray = SpawnRay(ref.p, ref.pError, ref.n, wi);
             Float tHit; SurfaceInteraction isectLight;
             bool flip = (sh.reverseOrientation != 0) ^ (sh.swapsHandedness != 0);
-            if (!SphereIntersect(s, flip, ray, &tHit, &isectLight, ctr)) return 0;
+            Counters own;
+            const bool found = SphereIntersect(s, flip, ray, &tHit, &isectLight, own);
+            ctr.sphereTestsPdf += own.sphereTests;
+            if (!found) return 0;
             Float area = s.phiMax * s.radius * (s.zMax - s.zMin);
             Float pdf = DistanceSquared(ref.p, isectLight.p) / (AbsDot(isectLight.n, -wi) * area);
             if (std::isinf(pdf)) pdf = 0.f;

@@ -177,6 +177,11 @@ CASES = {
                                            'Shape "trianglemesh" ' + BUMPY + '\nObjectInstance "b"\nObjectInstance "b"\n'
                                            'AttributeBegin\nTranslate 0 0 0\nMaterial "mirror"\nShape "sphere" "float radius" [.4]\nAttributeEnd\n'
                                            'AttributeBegin\nMaterial "matte" "color Kd" [.9 .9 .1]\nShape "sphere" "float radius" [.4]\nAttributeEnd\n', spp=8),
+    # ---- an emitter sphere that the geometry runs through: shading points INSIDE their own emitter (Sphere::Sample / Pdf fall back to
+    #      Shape::Sample / Shape::Pdf, shapes/sphere.cpp:232-243, 288-296; the specialised shading variants hand such vertices to the
+    #      generic one) next to a quad emitter (Shape::Pdf's own Triangle::Intersect) ----
+    "geometry_inside_the_emitter": _scene('AttributeBegin\nMaterial "matte" "color Kd" [0 0 0]\nTranslate .6 -.4 .3\nAreaLightSource "area" "color L" [3 2.8 2.4]\n'
+                                          'Shape "sphere" "float radius" [1.1]\nAttributeEnd\n' + QUAD_LIGHT + GEOM, integ=UNIFORM, spp=8),
     "no_lights": _scene(GEOM),
     "empty_scene": _scene(""),
     "light_only": _scene(SPHERE_LIGHT),
@@ -221,6 +226,26 @@ def test_scene_film_parity(hprt, orc, tmp_path, name):
         assert st[k_dev] == c0[k_orc], (name, k_dev, st[k_dev], c0[k_orc])
     if name not in ("no_lights", "empty_scene"):
         assert film0[..., :3].max() > 0
+
+
+def test_pixel_statistics_do_not_count_the_tests_inside_shape_pdf(hprt, orc, tmp_path):
+    """The fork counts primitive tests per ray in GeometricPrimitive::Intersect / IntersectP (core/primitive.cpp:119-125): what the
+    aggregate's traversal tests.  Shape::Pdf's own Intersect call on an emitter (core/shape.cpp:72-88: triangle emitters always, a sphere
+    emitter for points inside it) is not one of them — a random scene at a large frame size found the oracle counting it."""
+    name = "geometry_inside_the_emitter"
+    p = tmp_path / (name + ".pbrt")
+    p.write_text(CASES[name])
+    model = hprt.Model.parse(str(p))
+    baked = str(tmp_path / (name + ".hprt")); model.save(baked)
+    oracle = orc.OracleScene(baked)
+    _, _, c0, _, _ = oracle.render(threads=8)
+    ref = oracle.pixel_stats()
+    scene = hprt.Scene(model, hprt.Bvh(model))
+    film, st = scene.render(pixel_stats=True)
+    got = scene.pixel_stats()
+    assert np.array_equal(got, ref)
+    assert int(got[..., 1].sum()) == st["tri_tests"] + st["sphere_tests"] and st["sphere_tests"] == c0["sphere_tests"]
+    assert st["tri_tests"] < c0["tri_tests"]      # the reference's global nTests (shapes/triangle.cpp:191) does count Shape::Pdf's tests
 
 
 def test_instanced_hits_identify_instance_and_primitive(hprt, orc, tmp_path):
