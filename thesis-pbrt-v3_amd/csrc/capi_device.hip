@@ -929,10 +929,10 @@ struct BatchTimers { double extendMs = 0, occludedMs = 0; uint64_t extendLaunche
 // bubbles) — and removed again: every kernel runs on the caller's stream, where HIP-event times are exclusive.
 int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspace &w, const QueueSet &qa, const QueueSet &qb,
              const BinSet &bins, uint32_t s0, uint32_t nSlots, bool count, EventTimer &ev, BatchTimers *bt, HprtRenderStats *stats,
-             uint32_t *pixelStats = nullptr) {
+             uint32_t *pixelStats = nullptr, const IrregularSink *irregular = nullptr) {
     uint4 *rayStats = pixelStats ? s->rayStats.as<uint4>() : nullptr;
     uint32_t *wcPath = s->workCounter.as<uint32_t>();
-    LaunchGenerate(st, s->dev, rp, w.path[0], s0, nSlots);
+    LaunchGenerate(st, s->dev, rp, w.path[0], s0, nSlots, irregular);
     const uint32_t *activeQ = nullptr; uint32_t active = nSlots;
     QueueSet q[2] = {qa, qb};
     DevCounters *ctr = s->counters.as<DevCounters>();
@@ -1117,22 +1117,35 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
 
     auto wall0 = std::chrono::high_resolution_clock::now();
     // ---- film footprint pre-pass ----
-    // (capacity: a first guess — a few samples per pixel have a zero Halton offset — and a second pass with the counted size if
-    // the guess was too small; HPRT_IRREGULAR_CAP: test hook for that second pass)
+    // Irregular film samples: k_generate lists them while it forms the camera samples (capacity: a first guess — a few samples per
+    // pixel have a zero Halton offset); if the guess was too small, k_find_irregular recounts with the counted size
+    // (HPRT_IRREGULAR_CAP: test hook for that fallback)
     static const uint32_t capHint = [] { const char *e = getenv("HPRT_IRREGULAR_CAP"); return e ? (uint32_t)std::max(1, atoi(e)) : (1u << 24); }();
     uint32_t irrCap = (uint32_t)std::min<uint64_t>((uint64_t)nPix * spp, capHint);
     HIP_TRY(s->irregularCount.alloc(16));
-    uint32_t nIrr = 0;
-    for (int pass = 0; pass < 2; ++pass) {
+    HIP_TRY(s->irregular.alloc((size_t)irrCap * sizeof(IrregularSample)));
+    HIP_TRY(hipMemsetAsync(s->irregularCount.p, 0, 16, st));
+    const IrregularSink sink = {f.fg, s->irregularCount.as<uint32_t>(), irrCap, s->irregular.as<IrregularSample>()};
+    // ---- batches ----
+    EventTimer ev; BatchTimers bt;
+    for (uint32_t s0 = 0; s0 < spp; s0 += chunk) {
+        const uint32_t c = std::min(chunk, spp - s0), nSlots = c * nPix;
+        rc = RunBatch(s, st, rp, ps, qa, qb, bins, s0, nSlots, count, ev, &bt, stats, pixelStats, &sink);
+        if (rc != HPRT_OK) return rc;
+        LaunchStoreRadiance(st, ps.Lfinal, LallR, LallG, LallB, nPix, s0, nSlots);
+    }
+    HIP_TRY(hipMemcpyAsync(s->hostCounts + 8, s->irregularCount.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    uint32_t nIrr = s->hostCounts[8];
+    if (nIrr > irrCap) {      // the list overflowed: once more, standalone, with room for all of them
+        if ((uint64_t)nIrr * sizeof(IrregularSample) > (8ull << 30)) return SetError(HPRT_E_UNSUPPORTED, "too many irregular film samples");
+        irrCap = nIrr;
         HIP_TRY(s->irregular.alloc((size_t)irrCap * sizeof(IrregularSample)));
         HIP_TRY(hipMemsetAsync(s->irregularCount.p, 0, 16, st));
         LaunchFindIrregular(st, s->dev, rp, f.fg, spp, s->irregularCount.as<uint32_t>(), irrCap, s->irregular.as<IrregularSample>());
         HIP_TRY(hipMemcpyAsync(s->hostCounts + 8, s->irregularCount.p, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        nIrr = s->hostCounts[8];
-        if (nIrr <= irrCap) break;
-        if (pass == 1 || (uint64_t)nIrr * sizeof(IrregularSample) > (8ull << 30)) return SetError(HPRT_E_UNSUPPORTED, "too many irregular film samples");
-        irrCap = nIrr;
+        if (s->hostCounts[8] != nIrr) return SetError(HPRT_E_DEVICE, "internal error: irregular film samples counted differently");
     }
     std::vector<IrregularSample> irr(nIrr);
     if (nIrr) HIP_TRY(hipMemcpy(irr.data(), s->irregular.p, (size_t)nIrr * sizeof(IrregularSample), hipMemcpyDeviceToHost));
@@ -1190,14 +1203,6 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
         ex.nForeignDest = (uint32_t)dest.size();
         ex.foreignDestFilmIndex = s->exFDest.as<uint32_t>(); ex.foreignDestBegin = s->exFDestBegin.as<uint32_t>(); ex.foreignGroupBegin = s->exFGroupBegin.as<uint32_t>();
         ex.foreignSrcPix = s->exFSrc.as<uint32_t>(); ex.foreignSample = s->exFSample.as<uint32_t>();
-    }
-    // ---- batches ----
-    EventTimer ev; BatchTimers bt;
-    for (uint32_t s0 = 0; s0 < spp; s0 += chunk) {
-        const uint32_t c = std::min(chunk, spp - s0), nSlots = c * nPix;
-        rc = RunBatch(s, st, rp, ps, qa, qb, bins, s0, nSlots, count, ev, &bt, stats, pixelStats);
-        if (rc != HPRT_OK) return rc;
-        LaunchStoreRadiance(st, ps.Lfinal, LallR, LallG, LallB, nPix, s0, nSlots);
     }
     LaunchFilmOwn(st, rp, f.fg, LallR, LallG, LallB, spp, ex, film);
     if (desc->flags & HPRT_RENDER_EXPORT_FOREIGN) {

@@ -56,6 +56,9 @@ struct FilmGeom {
     float maxSampleLuminance;
 };
 struct IrregularSample { uint32_t pix, sample; int16_t x0, x1, y0, y1; };
+// k_generate forms every camera sample's film position anyway: given this it also lists the irregular ones of its batch (count is
+// cumulative over the batches of a render; entries beyond capacity are counted, not stored — the host then falls back to k_find_irregular)
+struct IrregularSink { FilmGeom fg; uint32_t *count; uint32_t capacity; IrregularSample *out; };
 // Samples that also land in pixels other than their own, grouped per destination.
 struct FilmExtras {
     // same-tile: CSR over local pixels; entries sorted in the tile loop's order, pre first
@@ -77,7 +80,8 @@ void LaunchPixelStats(hipStream_t st, const uint4 *rayStats, const float4 *ids, 
                       uint32_t countImm, uint32_t gridItems, uint32_t nPix, bool anyHit, uint32_t *pix);
 void LaunchPixelStatsToFilm(hipStream_t st, const uint32_t *pix, const uint32_t *pixelXY, uint32_t nPix, uint32_t spp, int cx0, int cy0, int width,
                             unsigned long long *out7);
-void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathStream &out, uint32_t s0, uint32_t nSlots);
+void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathStream &out, uint32_t s0, uint32_t nSlots,
+                    const IrregularSink *irr = nullptr);
 void LaunchBin(hipStream_t st, const DevScene &sc, const PathStream &in, const HitStream &hit, const uint32_t *queue,
                const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, int32_t maxDepth, int32_t bounces, const BinSet &bins,
                float4 *Lfinal);

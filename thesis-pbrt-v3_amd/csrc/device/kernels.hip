@@ -600,9 +600,21 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
 // path id = sampleInChunk * nPix + pixelIndex, so consecutive lanes are consecutive pixels
 // of a 16x16 tile (coherent primary rays).  Bounce 0 uses the path id as stream index.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, PathStream out, uint32_t s0, uint32_t nSlots) {
+__device__ __forceinline__ void footprint(const FilmGeom &fg, int px, int py, float fx, float fy, int *x0, int *x1, int *y0, int *y1) {
+    // tile pixel bounds of the tile that samples (px,py): Film::GetFilmTile, core/film.cpp:96-107
+    const int tx0 = fg.sx0 + ((px - fg.sx0) / 16) * 16, ty0 = fg.sy0 + ((py - fg.sy0) / 16) * 16;
+    const int tx1 = sel_min(tx0 + 16, fg.sx1), ty1 = sel_min(ty0 + 16, fg.sy1);
+    const int bx0 = sel_max((int)ceilf((float)tx0 - 0.5f - fg.rx), fg.cx0), by0 = sel_max((int)ceilf((float)ty0 - 0.5f - fg.ry), fg.cy0);
+    const int bx1 = sel_min((int)floorf((float)tx1 - 0.5f + fg.rx) + 1, fg.cx1), by1 = sel_min((int)floorf((float)ty1 - 0.5f + fg.ry) + 1, fg.cy1);
+    const float dxf = fx - 0.5f, dyf = fy - 0.5f;
+    *x0 = sel_max((int)ceilf(dxf - fg.rx), bx0); *y0 = sel_max((int)ceilf(dyf - fg.ry), by0);
+    *x1 = sel_min((int)floorf(dxf + fg.rx) + 1, bx1); *y1 = sel_min((int)floorf(dyf + fg.ry) + 1, by1);
+}
+__global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, PathStream out, uint32_t s0, uint32_t nSlots, IrregularSink irr) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= nSlots) return;
+    bool irregular = false;
+    IrregularSample rec;
+    if (slot < nSlots) {
     const uint32_t pix = slot % rp.nPix, sIdx = slot / rp.nPix;
     const uint32_t pxy = rp.pixelXY[pix];
     const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
@@ -616,6 +628,17 @@ __global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, 
     out.ray.a[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tMax);
     out.ray.b[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(5u));   // sampler dimension 5 (after pFilm, time, pLens), bounce 0
     // beta = (1,1,1 | path id = slot) and L = (0,0,0 | continues) of a fresh path are not stored: k_bin and k_shade know them at bounce 0
+    if (irr.count) {      // the film's irregular samples (see k_find_irregular, which this replaces in a render)
+        int x0, x1, y0, y1;
+        footprint(irr.fg, px, py, fx, fy, &x0, &x1, &y0, &y1);
+        irregular = !(x0 == px && x1 == px + 1 && y0 == py && y1 == py + 1);
+        rec.pix = pix; rec.sample = s0 + sIdx; rec.x0 = (int16_t)x0; rec.x1 = (int16_t)x1; rec.y0 = (int16_t)y0; rec.y1 = (int16_t)y1;
+    }
+    }
+    if (irr.count) {      // (kernel-uniform)
+        const uint32_t pos = wave_append(irr.count, irregular);
+        if (irregular && pos < irr.capacity) irr.out[pos] = rec;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1088,16 +1111,6 @@ __global__ __launch_bounds__(256) void k_store_radiance(const float4 *Lfinal, fl
 // exactly their own pixel (pFilm fraction 0, or pixel + u rounding up to the next
 // integer: FilmTile::AddSample, core/film.h:136-143).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void footprint(const FilmGeom &fg, int px, int py, float fx, float fy, int *x0, int *x1, int *y0, int *y1) {
-    // tile pixel bounds of the tile that samples (px,py): Film::GetFilmTile, core/film.cpp:96-107
-    const int tx0 = fg.sx0 + ((px - fg.sx0) / 16) * 16, ty0 = fg.sy0 + ((py - fg.sy0) / 16) * 16;
-    const int tx1 = sel_min(tx0 + 16, fg.sx1), ty1 = sel_min(ty0 + 16, fg.sy1);
-    const int bx0 = sel_max((int)ceilf((float)tx0 - 0.5f - fg.rx), fg.cx0), by0 = sel_max((int)ceilf((float)ty0 - 0.5f - fg.ry), fg.cy0);
-    const int bx1 = sel_min((int)floorf((float)tx1 - 0.5f + fg.rx) + 1, fg.cx1), by1 = sel_min((int)floorf((float)ty1 - 0.5f + fg.ry) + 1, fg.cy1);
-    const float dxf = fx - 0.5f, dyf = fy - 0.5f;
-    *x0 = sel_max((int)ceilf(dxf - fg.rx), bx0); *y0 = sel_max((int)ceilf(dyf - fg.ry), by0);
-    *x1 = sel_min((int)floorf(dxf + fg.rx) + 1, bx1); *y1 = sel_min((int)floorf(dyf + fg.ry) + 1, by1);
-}
 __global__ __launch_bounds__(256) void k_find_irregular(DevScene sc, RenderParams rp, FilmGeom fg, uint32_t spp, uint32_t *count,
                                                         uint32_t capacity, IrregularSample *out) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1327,8 +1340,11 @@ extern "C" __attribute__((visibility("default"))) int hprt_debug_trace_profile(u
     if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_traceProf), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
-void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathStream &out, uint32_t s0, uint32_t nSlots) {
-    if (nSlots) hipLaunchKernelGGL(k_generate, dim3(blocks_for(nSlots, 256)), dim3(256), 0, st, sc, rp, out, s0, nSlots);
+void LaunchGenerate(hipStream_t st, const DevScene &sc, const RenderParams &rp, const PathStream &out, uint32_t s0, uint32_t nSlots,
+                    const IrregularSink *irr) {
+    IrregularSink sink; memset(&sink, 0, sizeof(sink));
+    if (irr) sink = *irr;
+    if (nSlots) hipLaunchKernelGGL(k_generate, dim3(blocks_for(nSlots, 256)), dim3(256), 0, st, sc, rp, out, s0, nSlots, sink);
 }
 void LaunchBin(hipStream_t st, const DevScene &sc, const PathStream &in, const HitStream &hit, const uint32_t *queue,
                const uint32_t *countPtr, uint32_t countImm, uint32_t gridItems, int32_t maxDepth, int32_t bounces, const BinSet &bins,
