@@ -4,7 +4,7 @@ object instances under random (also mirroring) transforms, exactly coincident su
 maxdepth 0-12, the Russian-roulette threshold — in combinations the hand-written cases of test_gpu_scenes.py /
 test_gpu_textures.py do not reach.  Each scene is .pbrt text parsed by the product front-end (no warnings allowed), rendered
 by the HIP path through the C ABI and by the oracle: films and work counters must be identical; the film must also not
-depend on how the samples are cut into batches or sharded into tiles.
+depend on how the samples are cut into batches or sharded into tiles; 20,000 random rays go through hprt_intersect / hprt_occluded.
 
 HPRT_FUZZ_N (default 48) scenes starting at seed HPRT_FUZZ_SEED (default 0), HPRT_FUZZ_SCALE for large frames; `tools/fuzz_parity.sh` runs a long sweep."""
 import os
@@ -218,6 +218,26 @@ def test_random_scene_parity(hprt, orc, tmp_path, seed):
     for k in COUNTERS:
         assert st[k] == c0[k], (seed, k, st[k], c0[k])
     assert st["tri_tests"] <= c0["tri_tests"]      # (the oracle also counts the tests inside Shape::Pdf of triangle emitters, as the reference's nTests does)
+    # the aggregate alone, through hprt_intersect / hprt_occluded: random rays (also axis-parallel ones, whose reciprocal directions hold
+    # infinities, and segments with a finite tMax) — t, primitive, instance, barycentrics, any-hit flags and the traversal counters
+    if model.counts()["primitives"] > 0:
+        rr = np.random.default_rng(seed)
+        nr = 20000
+        ro = (rr.uniform(-3.5, 3.5, (nr, 3)) + np.array([0, 0, 1.2])).astype(np.float32)
+        tgt = (rr.uniform(-2, 2, (nr, 3)) * np.array([1, 1, 0.5])).astype(np.float32)
+        rd = (tgt - ro).astype(np.float32)
+        axis = rr.random(nr) < .05
+        rd[axis] = np.eye(3, dtype=np.float32)[rr.integers(0, 3, int(axis.sum()))] * rr.choice([-1.0, 1.0], int(axis.sum()))[:, None].astype(np.float32)
+        rt = np.where(rr.random(nr) < 0.5, np.inf, rr.uniform(0.2, 1.5, nr)).astype(np.float32)
+        t0, p0, i0, b0, k0 = oracle.intersect_inst(ro, rd, rt)
+        t1, p1, i1, b1, k1 = scene.intersect_instanced(ro, rd, rt, count=True)
+        assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(p0, p1) and np.array_equal(i0, i1), seed
+        assert np.array_equal(b0.view(np.uint32), b1.view(np.uint32)), seed
+        assert [int(x) for x in k1] == [k0["nodes_fetched"], k0["nodes_entered"], k0["tri_tests"], k0["sphere_tests"]], seed
+        occ0, q0 = oracle.occluded(ro, rd, rt)
+        occ1, q1 = scene.occluded(ro, rd, rt, count=True)
+        assert np.array_equal(occ0, occ1), seed
+        assert [int(x) for x in q1] == [q0["nodes_fetched_p"], q0["nodes_entered_p"], q0["tri_tests_p"], q0["sphere_tests_p"]], seed
     # the plain render, a render cut into odd batches and a two-way tile sharding merged in source-tile order give the same film
     film_plain, st_plain = scene.render()
     assert np.array_equal(film_plain.view(np.uint32), film1.view(np.uint32)) and st_plain["rays"] <= st["rays"]
