@@ -615,25 +615,25 @@ __global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, 
     bool irregular = false;
     IrregularSample rec;
     if (slot < nSlots) {
-    const uint32_t pix = slot % rp.nPix, sIdx = slot / rp.nPix;
-    const uint32_t pxy = rp.pixelXY[pix];
-    const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
-    const uint64_t index = (uint64_t)rp.pixelOffset[pix] + (uint64_t)(s0 + sIdx) * (uint64_t)rp.hal.sampleStride;
-    const float u0 = halton_dim(sc, rp.hal, index, 0), u1 = halton_dim(sc, rp.hal, index, 1);
-    const float fx = (float)px + u0, fy = (float)py + u1;
-    float lu = 0.f, lv = 0.f;
-    if (rp.cam.lensRadius > 0) { lu = halton_dim(sc, rp.hal, index, 3); lv = halton_dim(sc, rp.hal, index, 4); }
-    DRay ray;
-    camera_ray(rp.cam, fx, fy, lu, lv, &ray);
-    out.ray.a[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tMax);
-    out.ray.b[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(5u));   // sampler dimension 5 (after pFilm, time, pLens), bounce 0
-    // beta = (1,1,1 | path id = slot) and L = (0,0,0 | continues) of a fresh path are not stored: k_bin and k_shade know them at bounce 0
-    if (irr.count) {      // the film's irregular samples (see k_find_irregular, which this replaces in a render)
-        int x0, x1, y0, y1;
-        footprint(irr.fg, px, py, fx, fy, &x0, &x1, &y0, &y1);
-        irregular = !(x0 == px && x1 == px + 1 && y0 == py && y1 == py + 1);
-        rec.pix = pix; rec.sample = s0 + sIdx; rec.x0 = (int16_t)x0; rec.x1 = (int16_t)x1; rec.y0 = (int16_t)y0; rec.y1 = (int16_t)y1;
-    }
+        const uint32_t pix = slot % rp.nPix, sIdx = slot / rp.nPix;
+        const uint32_t pxy = rp.pixelXY[pix];
+        const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
+        const uint64_t index = (uint64_t)rp.pixelOffset[pix] + (uint64_t)(s0 + sIdx) * (uint64_t)rp.hal.sampleStride;
+        const float u0 = halton_dim(sc, rp.hal, index, 0), u1 = halton_dim(sc, rp.hal, index, 1);
+        const float fx = (float)px + u0, fy = (float)py + u1;
+        float lu = 0.f, lv = 0.f;
+        if (rp.cam.lensRadius > 0) { lu = halton_dim(sc, rp.hal, index, 3); lv = halton_dim(sc, rp.hal, index, 4); }
+        DRay ray;
+        camera_ray(rp.cam, fx, fy, lu, lv, &ray);
+        out.ray.a[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tMax);
+        out.ray.b[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(5u));   // sampler dimension 5 (after pFilm, time, pLens), bounce 0
+        // beta = (1,1,1 | path id = slot) and L = (0,0,0 | continues) of a fresh path are not stored: k_bin and k_shade know them at bounce 0
+        if (irr.count) {      // the film's irregular samples (see k_find_irregular, which this replaces in a render)
+            int x0, x1, y0, y1;
+            footprint(irr.fg, px, py, fx, fy, &x0, &x1, &y0, &y1);
+            irregular = !(x0 == px && x1 == px + 1 && y0 == py && y1 == py + 1);
+            rec.pix = pix; rec.sample = s0 + sIdx; rec.x0 = (int16_t)x0; rec.x1 = (int16_t)x1; rec.y0 = (int16_t)y0; rec.y1 = (int16_t)y1;
+        }
     }
     if (irr.count) {      // (kernel-uniform)
         const uint32_t pos = wave_append(irr.count, irregular);
