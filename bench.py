@@ -47,7 +47,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
-COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")
+N_SIMDS = 1024          # 256 CUs x 4 SIMDs
+
+
+def counters_file():
+    """The newest committed counter summary, profiles/rNN_counters.json (tools/counters_passes.sh + collect_profiles.py)."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_counters.json")))
+    return fs[-1] if fs else None
+
+
+def code_object_hash(lib_path):
+    """sha256 of the gfx950 code objects inside a built libhprt.so (its .hip_fatbin section): what ties a counter summary to
+    the kernels that were measured.  Host-only changes of the library do not move it."""
+    import hashlib, struct
+    try:
+        with open(lib_path, "rb") as f:
+            data = f.read()
+        if data[:4] != b"\x7fELF" or data[4] != 2:
+            return None
+        shoff, = struct.unpack_from("<Q", data, 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+        def sh(i):
+            name, typ, flags, addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+            return name, off, size
+        _, stroff, strsize = sh(shstrndx)
+        for i in range(shnum):
+            name, off, size = sh(i)
+            end = data.index(b"\0", stroff + name)
+            if data[stroff + name:end] == b".hip_fatbin":
+                return hashlib.sha256(data[off:off + size]).hexdigest()
+    except Exception:
+        return None
+    return None
 
 WORKLOADS = {
     # name: (description, how to build the model, spp, cpu sample spp, data label)
@@ -83,21 +115,121 @@ def parse_args():
 
 
 # ---------------------------------------------------------------------------------------------
+# host CPUs: what the CPU baseline can really use
+# ---------------------------------------------------------------------------------------------
+def _cgroup_cpu_quota():
+    """CPUs' worth of quota the cgroup hierarchy of this process allows (None: unlimited), and where it was read."""
+    best, where = None, None
+    def consider(q, w):
+        nonlocal best, where
+        if q is not None and (best is None or q < best):
+            best, where = q, w
+    try:      # cgroup v2: cpu.max = "<quota|max> <period>" at every level from this process's group up to the root
+        rel = ""
+        for line in open("/proc/self/cgroup"):
+            parts = line.strip().split(":", 2)
+            if len(parts) == 3 and parts[0] == "0":
+                rel = parts[2]
+        d = os.path.normpath("/sys/fs/cgroup/" + rel.lstrip("/"))
+        while d.startswith("/sys/fs/cgroup"):
+            f = os.path.join(d, "cpu.max")
+            if os.path.exists(f):
+                q, per = open(f).read().split()[:2]
+                if q != "max":
+                    consider(float(q) / float(per), f)
+            if d == "/sys/fs/cgroup":
+                break
+            d = os.path.dirname(d)
+    except Exception:
+        pass
+    try:      # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            consider(q / per, "/sys/fs/cgroup/cpu/cpu.cfs_quota_us")
+    except Exception:
+        pass
+    return best, where
+
+
+def host_cpu_info():
+    """logical CPUs the OS shows, CPUs this process may run on (affinity), the cgroup's CPU quota, and the CPU model.
+    `usable` = what a thread pool can actually get: min(affinity, quota rounded up)."""
+    logical = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = logical
+    quota, where = _cgroup_cpu_quota()
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except Exception:
+        pass
+    usable = affinity if quota is None else max(1, min(affinity, int(-(-quota // 1))))
+    return {"logical_cpus": logical, "affinity_cpus": affinity, "cgroup_cpu_quota": None if quota is None else round(quota, 2),
+            "cgroup_quota_from": where, "usable_cpus": usable, "cpu_model": model}
+
+
+def sweep_threads(info):
+    return sorted({t for t in (1, 8, 32, info["usable_cpus"], info["affinity_cpus"]) if 1 <= t <= info["logical_cpus"]})
+
+
+# ---------------------------------------------------------------------------------------------
 # launcher: N fresh rank processes, started before this process makes any GPU call
 # ---------------------------------------------------------------------------------------------
 def launch_ranks(args):
+    """Starts args.gpus fresh rank processes and relays rank 0's stdout.  The parent watches ALL of them: the first child that
+    exits non-zero ends the run — the others are terminated (they would otherwise sit in init_process_group or in the first
+    collective until somebody's time limit) and the parent exits non-zero at once.  Rank r's stderr is relayed line by line,
+    tagged "[rank r]".  Children are only ever started fresh; a process that touched the GPU is never re-executed."""
+    import threading
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = []
+    procs, out_chunks, threads = [], [], []
+    def relay_err(r, pipe):
+        for line in iter(pipe.readline, b""):
+            sys.stderr.write("[rank %d] %s" % (r, line.decode("utf-8", "replace"))); sys.stderr.flush()
+    def collect_out(pipe):
+        for chunk in iter(lambda: pipe.read(65536), b""):
+            out_chunks.append(chunk)
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                             stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE)
+        procs.append(p)
+        t = threading.Thread(target=relay_err, args=(r, p.stderr), daemon=True); t.start(); threads.append(t)
+        if r == 0:
+            t = threading.Thread(target=collect_out, args=(p.stdout,), daemon=True); t.start(); threads.append(t)
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.1)
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with code %d; terminating the other ranks\n" % failed)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill(); p.wait()
+    for t in threads:
+        t.join(timeout=5.0)
+    sys.stdout.write(b"".join(out_chunks).decode())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    if failed is not None:
+        return abs(failed[1]) or 1
+    return 0
 
 
 # ---------------------------------------------------------------------------------------------
@@ -149,8 +281,21 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to label one as the other\n" % (args.gpus, world))
         sys.exit(2)
 
+    import datetime
     import numpy as np
     import torch
+
+    # ---- pre-flight, before any collective can be entered: a rank that cannot run must leave with a non-zero code NOW, so that
+    # the launcher (launch_ranks, or torch.distributed.run) ends the job instead of letting its peers wait for it ----
+    if os.environ.get("HPRT_TEST_FAIL_RANK") == str(rank):      # test hook: this rank dies during start-up
+        sys.stderr.write("bench.py: HPRT_TEST_FAIL_RANK=%d: failing on purpose before the process group\n" % rank)
+        sys.exit(7)
+    n_dev = torch.cuda.device_count()                           # (does not initialise the GPU)
+    need = 1 if (world == 1 or args.rehearse_on_one_gpu) else local_rank + 1
+    if n_dev < need:
+        sys.stderr.write("bench.py: rank %d needs cuda:%d but this node shows %d GPU(s)\n" % (rank, need - 1, n_dev))
+        sys.exit(3)
+    pg_timeout = datetime.timedelta(seconds=int(os.environ.get("HPRT_BENCH_PG_TIMEOUT", "180")))
 
     dist = None
     if world > 1:
@@ -159,10 +304,10 @@ def main():
         if args.rehearse_on_one_gpu:
             local_rank = 0
             torch.cuda.set_device(0)
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=pg_timeout)
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
     else:
         local_rank = 0
         torch.cuda.set_device(0)
@@ -181,7 +326,22 @@ def main():
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(hprt.Comm.unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, src=0)
-            comm = hprt.Comm(bytes(idt.cpu().numpy().tobytes()), rank, world, device=dev.index)
+            # ncclCommInitRank blocks until every rank has joined: bound it, a peer may have died since the broadcast above
+            import threading
+            box = {}
+            def make():
+                try:
+                    box["comm"] = hprt.Comm(bytes(idt.cpu().numpy().tobytes()), rank, world, device=dev.index)
+                except Exception as e:
+                    box["err"] = e
+            th = threading.Thread(target=make, daemon=True); th.start(); th.join(timeout=pg_timeout.total_seconds())
+            if th.is_alive():
+                sys.stderr.write("bench.py: rank %d: hprt_comm_create did not return within %d s; giving up\n" % (rank, pg_timeout.total_seconds()))
+                sys.stderr.flush()
+                os._exit(4)      # (the thread sits inside RCCL: nothing to clean up from here)
+            if "err" in box:
+                raise box["err"]
+            comm = box["comm"]
             rccl_ranks = comm.info()["n_ranks"]
         except Exception as e:      # e.g. the library's own communicator cannot be set up in this environment
             comm, rccl_ranks, err = None, None, "%s: %s" % (type(e).__name__, e)
@@ -241,18 +401,29 @@ def main():
         rays, samples = reduce_sum([sum(s["rays"] + s["shadow_rays"] for s in stats), sum(s["camera_rays"] for s in stats)])
         return elapsed, rays, samples, stats
 
-    def cpu_port(name, spp_sample, spp_full):
+    def cpu_port(name, spp_sample, spp_full, sweep=False):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc   # the oracle: CPU port of the same path (checker / baseline only)
         d = tempfile.mkdtemp(prefix="hprt_bench_")
         baked = os.path.join(d, name + ".hprt")
         build_model(hprt, name).save(baked)
         oracle = orc.OracleScene(baked)
-        threads = os.cpu_count() or 1
+        # threads = the CPUs this process can really get: os.cpu_count() shows the whole machine, the box's lease (CPU affinity
+        # and / or a cgroup quota) is usually a slice of it, and oversubscribing a quota only buys throttling
+        cpu = host_cpu_info()
+        threads = cpu["usable_cpus"]
         _, _, c, sec, nt = oracle.render(spp=spp_sample, threads=threads)
-        return {"value": round((c["rays"] + c["shadow_rays"]) / sec / 1e6, 3), "unit": "Mrays/s", "cores": int(nt), "kind": "port",
-                "sample": "%s at %d spp (of the %d spp workload), whole frame, tile loop only" % (name, spp_sample, spp_full),
-                "msamples_per_s": round(c["camera_rays"] / sec / 1e6, 3), "seconds": round(sec, 2)}
+        out = {"value": round((c["rays"] + c["shadow_rays"]) / sec / 1e6, 3), "unit": "Mrays/s", "cores": int(nt), "kind": "port",
+               "sample": "%s at %d spp (of the %d spp workload), whole frame, tile loop only" % (name, spp_sample, spp_full),
+               "msamples_per_s": round(c["camera_rays"] / sec / 1e6, 3), "seconds": round(sec, 2),
+               "mrays_per_s_per_thread": round((c["rays"] + c["shadow_rays"]) / sec / 1e6 / max(1, nt), 4), "host": cpu}
+        if sweep:      # how the port scales on this host: the same frame at 1 spp per thread count, a few seconds each
+            out["scaling"] = []
+            for t in sweep_threads(cpu):
+                _, _, c1, s1, n1 = oracle.render(spp=1, threads=t)
+                r1 = (c1["rays"] + c1["shadow_rays"]) / s1 / 1e6
+                out["scaling"].append({"threads": int(n1), "mrays_per_s": round(r1, 3), "per_thread": round(r1 / max(1, n1), 4), "seconds": round(s1, 2)})
+        return out
 
     # =========================================================================================
     # headline workload
@@ -288,41 +459,91 @@ def main():
         bytes_per_ray = 32.0 * v_per_ray + 48.0 * t_per_ray + 28.0 + 20.0
         achieved = ext_rays * bytes_per_ray / max(ext_sec, 1e-12) / 1e9
         avg_ms = 1e3 * ext_sec / max(1, ext_launches)
+        # The contract's model figure: algorithmic bytes / kernel time.  The BVH is served by L2 / MALL, so it is a
+        # request rate, not an HBM utilisation, and it is NOT what `frac` reports: `frac` is filled from the measured HBM traffic
+        # of the counter summary below (and stays null when there is none for this build).
         roof = {
-            "bound": "hbm", "kernel": "k_trace<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-            "what_frac_is": "algorithmic bytes (SURVEY §8(d) model) / kernel time / HBM peak; the BVH is served by L2/MALL, so this is not "
-                            "an HBM utilisation (see hbm_counter_frac) and the kernel is limited by instruction issue on divergent lanes "
-                            "(see lane_utilisation, wait_frac)",
-            "algorithmic_bytes_per_launch": round(ext_rays * bytes_per_ray / max(1, ext_launches)),
-            "bytes_per_ray": round(bytes_per_ray, 1), "nodes_fetched_per_ray": round(v_per_ray, 3),
-            "prim_tests_per_ray": round(t_per_ray, 3), "launches": int(ext_launches), "avg_launch_ms": round(avg_ms, 4),
+            "bound": None, "kernel": "k_trace<closest>", "achieved": None, "peak": HBM_PEAK_GBS, "peak_measured": None, "unit": "GB/s",
+            "frac": None, "traffic": None,
+            "algorithmic": {"bytes_per_ray": round(bytes_per_ray, 1), "nodes_fetched_per_ray": round(v_per_ray, 3), "prim_tests_per_ray": round(t_per_ray, 3),
+                            "bytes_per_launch": round(ext_rays * bytes_per_ray / max(1, ext_launches)), "rate_gbs": round(achieved, 2),
+                            "note": "32 B per node fetched + 48 B per primitive test + 28 B ray + 20 B hit (SURVEY §8(d)), V and T counted by the kernel; "
+                                    "served mostly by L1 / L2 / MALL: a request rate, not an HBM utilisation, and not a roofline fraction"},
+            "launches": int(ext_launches), "avg_launch_ms": round(avg_ms, 4),
             "kernel_mrays_per_s": round(ext_rays / max(ext_sec, 1e-12) / 1e6, 1),
             "occluded_kernel_mrays_per_s": round(sum(s["occluded_rays"] for s in stats) / max(sum(s["occluded_seconds"] for s in stats), 1e-12) / 1e6, 1),
         }
         return roof, ref_over_traced
 
+    # ---- on-box HBM stream bandwidth (a float4 copy of 4 GiB, far beyond the 256 MB MALL): the peak a stream kernel reaches HERE ----
+    stream_gbs = None
+    if rank == 0 and world == 1:
+        import ctypes as C
+        try:
+            fn = hprt.lib.hprt_debug_stream_copy
+            fn.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+            best, mean = C.c_double(), C.c_double()
+            if fn(dev.index, 4 << 30, 10, C.byref(best), C.byref(mean)) == 0:
+                stream_gbs = {"best": round(best.value, 1), "mean": round(mean.value, 1), "what": "float4 copy, 4 GiB -> 4 GiB, read + write bytes / HIP-event time, 10 launches"}
+        except Exception as e:
+            stream_gbs = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    lib_hash = code_object_hash(hprt.LIB_PATH)
+
+    def attach_counters(roof, workload, live):
+        """Measured figures of the SAME kernels from the committed rocprofv3 summary (rocprofv3 cannot run inside this process):
+        bound, HBM traffic and fraction, VALU issue fraction, lane utilisation.  The summary is stamped with the hash of the code
+        objects it was taken on; when the loaded library's differs the figures are flagged stale (and `frac` is not filled)."""
+        roof["peak_measured"] = stream_gbs
+        cf = counters_file()
+        if not cf:
+            roof["counters_from"] = None
+            return
+        roof["counters_from"] = os.path.relpath(cf, ROOT)
+        try:
+            cj_all = json.load(open(cf))
+            cj = cj_all.get(workload)
+            stamp = cj_all.get("_stamp", {})
+            roof["counters_commit"] = stamp.get("commit")
+            roof["counters_code_object_sha256"] = stamp.get("code_object_sha256")
+            roof["library_code_object_sha256"] = lib_hash
+            roof["counters_stale"] = not (lib_hash and stamp.get("code_object_sha256") == lib_hash)
+            if not cj:
+                return
+            k = cj["kernels"]
+            tc = k.get("k_trace<closest>") or k.get("k_trace<closest>[inst]")
+            if tc and tc.get("hbm_bytes_per_launch") is not None:
+                roof["traffic"] = round(tc["hbm_bytes_per_launch"])
+                # per launch of THIS run: the summary's bytes per launch over this run's HIP-event launch time (the two runs launch
+                # the same kernels on the same rays: avg_launch_ms of the summary rides along for comparison)
+                ms = roof["avg_launch_ms"] if live and not roof["counters_stale"] else tc["avg_launch_ms"]
+                roof["achieved"] = round(tc["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
+                roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
+                if stream_gbs and stream_gbs.get("best"):
+                    roof["frac_of_measured_peak"] = round(roof["achieved"] / stream_gbs["best"], 4)
+                roof["rocprof_avg_launch_ms"] = tc["avg_launch_ms"]
+            for f in ("valu_issue_frac", "lane_utilisation", "useful_lane_frac", "wait_frac", "effective_clock_mhz"):
+                if tc and f in tc:
+                    roof[f] = tc[f]
+            # what binds the kernel, from the counters: the VALU issue rate (fraction of the SIMDs' issue slots taken by VALU
+            # instructions) against the HBM fraction
+            if tc and "valu_issue_frac" in tc and roof.get("frac") is not None:
+                roof["bound"] = "valu_issue" if tc["valu_issue_frac"] >= roof["frac"] else "hbm"
+                roof["bound_frac"] = max(tc["valu_issue_frac"], roof["frac"])
+            elif roof.get("frac") is not None:
+                roof["bound"] = "hbm"
+            roof["per_kernel"] = {name: {f: v[f] for f in ("lane_utilisation", "valu_issue_frac", "useful_lane_frac", "wait_frac", "avg_launch_ms", "launches", "hbm_gbs", "hbm_frac") if f in v}
+                                  for name, v in k.items()}
+            roof["hbm_bytes_per_step"] = cj.get("hbm_bytes_per_step")
+            roof["step_hbm_frac"] = cj.get("step_hbm_frac")
+        except Exception as e:   # a malformed summary must not take the bench down
+            roof["counters_error"] = repr(e)
+
     roofline = cpu_baseline = trace_all_info = None
     ref_over_traced = 1.0
     if rank == 0 and world == 1:
         roofline, ref_over_traced = kernel_figures(head, stats)
-        # measured counters of the same step (rocprofv3 cannot run inside this process): profiles/r02_counters.json
-        if os.path.exists(COUNTERS) and not args.spp and not args.weak:
-            try:
-                cj = json.load(open(COUNTERS)).get(args.workload)
-                if cj:
-                    k = cj["kernels"]
-                    tc = k.get("k_trace<closest>")
-                    if tc and tc.get("hbm_bytes_per_launch") is not None:
-                        roofline["traffic"] = round(tc["hbm_bytes_per_launch"])
-                        roofline["traffic_from"] = "profiles/r02_counters.json"
-                        roofline["hbm_counter_frac"] = round(tc["hbm_bytes_per_launch"] / (tc["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                    roofline["per_kernel"] = {name: {f: v[f] for f in ("lane_utilisation", "wait_frac", "avg_launch_ms", "launches", "hbm_gbs", "hbm_frac") if f in v}
-                                              for name, v in k.items()}
-                    roofline["hbm_bytes_per_step"] = cj.get("hbm_bytes_per_step")
-                    roofline["step_hbm_frac"] = cj.get("step_hbm_frac")
-            except Exception as e:   # a malformed summary must not take the bench down
-                roofline["counters_error"] = repr(e)
+        attach_counters(roofline, args.workload, live=True)
         if not args.no_trace_all:
             torch.cuda.synchronize(dev); ta0 = time.perf_counter()
             ta = [head.render(args.spp_chunk, trace_all=True) for _ in range(args.steps)]
@@ -347,6 +568,7 @@ def main():
                         "mrays_per_s": round(r2 / e2 / 1e6, 2), "msamples_per_s": round(s2 / e2 / 1e6, 3), "rays_per_step": int(r2 / steps2)}
                 if world == 1:
                     roof2, rot2 = kernel_figures(del_w, st2)
+                    attach_counters(roof2, name, live=True)
                     item["reference_rays_per_step"] = int(r2 * rot2 / steps2)
                     item["roofline"] = roof2
                     if not args.no_cpu_baseline:
@@ -357,7 +579,7 @@ def main():
             torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = cpu_port(args.workload, cpu_spp, spp)
+        cpu_baseline = cpu_port(args.workload, cpu_spp, spp, sweep=True)
     if dist is not None:
         dist.barrier()
     if rank == 0:

@@ -13,6 +13,16 @@
  * Device entry points (hprt_scene_*, hprt_intersect, hprt_occluded, hprt_render,
  * hprt_film_*) require a gfx950 GPU and fail with HPRT_E_NO_DEVICE otherwise:
  * there is no CPU fallback behind this ABI.
+ *
+ * Concurrency.  An HprtScene allows ONE call in flight at a time: its work counter,
+ * ray / hit staging, traversal-stack area and render workspace belong to the scene,
+ * not to a call.  The library enforces it — calls from several host threads take the
+ * scene's mutex, and a call on one HIP stream first waits (on the device) for an
+ * earlier asynchronous *_device call on another — so concurrent use is SAFE but
+ * serialised: where pbrt calls BVHAccel::Intersect from every worker thread
+ * (core/parallel.cpp:247-299), a host gains nothing by doing the same here; it should
+ * batch.  HprtModel / HprtBvh objects are immutable after creation and may be read
+ * from any number of threads.  Different HprtScene objects are independent.
  */
 #ifndef HPRT_H
 #define HPRT_H
@@ -217,6 +227,12 @@ void hprt_scene_destroy(HprtScene *s);
 /* [0] BVH nodes fetched (traversal-loop iterations), [1] nodes entered (the   */
 /* reference's "BVH node traversals" counter), [2] triangle tests, [3] sphere  */
 /* tests — the figures SURVEY.md §8(d)'s byte model is built from.            */
+/* These calls are BATCH interfaces: n = 1 meets the single-ray contract of    */
+/* Aggregate::Intersect(const Ray&, SurfaceInteraction*) but costs a host-to-  */
+/* device copy, a kernel launch and a copy back (~tens of microseconds) per    */
+/* ray — a contract shim for tests, not a usable rendering path.  A host that  */
+/* wants images calls hprt_render; one that wants rays answered hands over     */
+/* thousands to millions at a time.                                            */
 /* ------------------------------------------------------------------------ */
 int hprt_intersect(HprtScene *s, size_t n, const float *o, const float *d, const float *tmax, float *t_out,
                    int32_t *prim_out, float *bary_out, uint64_t counters[4]);
@@ -287,6 +303,12 @@ typedef struct HprtRenderStats {
  * elsewhere — what Film::MergeFilmTile leaves in Film::pixels.  Summing such
  * buffers over GPUs (RCCL reduce) reproduces the single-GPU film exactly. */
 int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, void *stream, HprtRenderStats *stats);
+/* Optional: allocate everything the coming hprt_render(s, desc, ...) needs in HBM now (the wavefront workspace is
+ * ~393 B per path of a batch: 105 GB for the 256 M-path batches of a 700x700, 1,024 spp frame), so that a host that
+ * renders once (pbrt does: Integrator::Render, core/api.cpp:1851) pays the allocation at scene load — next to
+ * BVHAccel's own node allocation (accelerators/bvh.cpp:181) — not inside Render().  A later render with a
+ * description that needs more simply grows the buffers. */
+int hprt_scene_reserve(HprtScene *s, const HprtRenderDesc *desc);
 /* Pixel::stats (core/film.h:91; GeneralStats, core/geometry.h:1078-1173) of the last hprt_render that had
  * HPRT_RENDER_PIXEL_STATS set: per film pixel, row-major over the cropped pixel bounds, 7 values —
  * rays (= samples), primitiveIntersections, primitiveIntersectionsP, leafNodeTraversals,
@@ -329,12 +351,19 @@ int hprt_comm_create(const uint8_t id[HPRT_COMM_ID_BYTES], int rank, int n_ranks
 int hprt_comm_info(const HprtComm *c, int *rank, int *n_ranks, int *device);
 void hprt_comm_destroy(HprtComm *c);
 /* Collective over the communicator, after each rank's hprt_render(..., HPRT_RENDER_EXPORT_FOREIGN).  d_film_xyzw is the
- * DEVICE buffer that render wrote (NULL: the scene's own film); on return the root's buffer holds the merged frame
- * (what Film::pixels holds before WriteImage), other ranks' buffers are unspecified.  Blocks until `stream` is done. */
+ * DEVICE buffer that render wrote (NULL: whichever buffer it wrote — the caller's or the scene's own; a different
+ * pointer is refused); on return the root's buffer holds the merged frame (what Film::pixels holds before WriteImage),
+ * other ranks' buffers are unspecified.  Blocks until `stream` is done.
+ * Errors are collective-safe: a rank whose own arguments or state are unusable still takes part in the first (count)
+ * exchange and reports the failure through it, so EVERY rank returns an error and none waits for a peer that left;
+ * an error inside the grouped reduce / send / recv closes the group before it is returned. */
 int hprt_film_gather(HprtComm *c, HprtScene *s, float *d_film_xyzw, size_t n_pixels, int root, void *stream);
 /* The same for ONE process that drives n GPUs with one HprtScene each (how an adapter inside pbrt would: the proposal
  * of SURVEY.md §8(b)); communicators come from ncclCommInitAll on first use.  d_films may be NULL (every scene's own film). */
 int hprt_film_gather_local(HprtScene *const *per_gpu, float *const *d_films, int n, size_t n_pixels, int root);
+/* Destroys the communicators hprt_film_gather_local created (ncclCommDestroy) and frees its staging buffers.  Call it
+ * before the process ends while the HIP runtime is still alive; the library never does so from a static destructor. */
+void hprt_film_gather_local_shutdown(void);
 /* The transport-free halves, for hosts that move the data themselves (the gloo rehearsals in tests/ do): the records of
  * the last HPRT_RENDER_EXPORT_FOREIGN render (out == NULL: count only), and the ordered merge of any ranks' records into
  * a HOST copy of the summed films (sorts `records` by destination pixel and source tile, then adds; no GPU involved). */

@@ -137,3 +137,57 @@ def test_bench_refuses_a_mislabelled_world_size():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True)
     assert r.returncode == 2 and "refusing" in r.stderr
+
+
+def test_bench_launcher_fails_fast_when_a_rank_dies():
+    """bench.py --gpus N starts its ranks itself; when one of them exits non-zero during start-up (here: rank 1 on purpose,
+    rank 0 because this box has no GPU) the launcher terminates the rest and returns non-zero within seconds, with the
+    failing rank's stderr relayed under its tag.  (On the GPU box tests/test_gpu_parity.py repeats this with a rank 0 that
+    really is blocked in the rendezvous.)"""
+    import subprocess, time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--workload", "killeroo-simple",
+                        "--spp", "1", "--steps", "1", "--warmup", "0", "--no-secondary", "--no-cpu-baseline"],
+                       env=dict(env, HPRT_TEST_FAIL_RANK="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and time.time() - t0 < 60
+    assert "[rank 1]" in r.stderr and "failing on purpose" in r.stderr and "terminating the other ranks" in r.stderr
+
+
+def _bad_rank_worker(rank, world, port, out_dir, case):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    hprt = importlib.import_module("thesis-pbrt-v3_amd")
+    tiles = importlib.import_module("thesis-pbrt-v3_amd.tiles")
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    film = torch.zeros((4, 4, 4), dtype=torch.float32)
+    rec = np.zeros(1, hprt.FILM_RECORD)
+    if rank == 1:
+        if case == "shape": film = torch.zeros((4, 5, 4), dtype=torch.float32)      # a film of another size
+        if case == "records": rec = np.zeros(3, np.float32)                            # not records at all
+        if case == "missing": rec = None                                               # this rank merged its records itself
+    try:
+        tiles.gather_film(film, dist, dst=0, records=rec)
+        verdict = "merged"
+    except RuntimeError as e:
+        verdict = "refused: " + str(e)
+    with open(os.path.join(out_dir, "%s_%d.txt" % (case, rank)), "w") as f:
+        f.write(verdict)
+    dist.barrier()      # the group is still usable: nobody is stuck in a half-entered collective
+    dist.destroy_process_group()
+
+
+def test_one_bad_rank_makes_every_rank_refuse_the_merge(tmp_path):
+    """The error path of the film merge is collective-safe (the gloo twin of hprt_film_gather's protocol, csrc/capi_gather.hip):
+    when ONE rank's arguments are unusable, every rank raises before the reduce — nobody hangs in it — and the process group
+    stays usable (the barrier after it completes)."""
+    import time
+    for case in ("shape", "records", "missing"):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        t0 = time.time()
+        mp.spawn(_bad_rank_worker, args=(3, port, str(tmp_path), case), nprocs=3, join=True)
+        assert time.time() - t0 < 60
+        verdicts = [open(str(tmp_path / ("%s_%d.txt" % (case, r)))).read() for r in range(3)]
+        assert all(v.startswith("refused: gather_film:") for v in verdicts), verdicts

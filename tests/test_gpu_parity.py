@@ -246,7 +246,27 @@ def test_rccl_film_gather_through_the_c_abi(hprt, killeroo_model, killeroo_scene
     killeroo_scene.render(opt, film_ptr=film.data_ptr())
     with pytest.raises(hprt.HprtError):
         comm.film_gather(killeroo_scene, film.data_ptr(), n_pix)
+    # ... and it was refused THROUGH the collective (the failing rank still takes part in the count exchange, so that no peer is
+    # left waiting): the communicator is as usable as before — another failure of the same kind, then a valid gather
+    killeroo_scene.render(opt, film_ptr=film.data_ptr(), export_foreign=True)
+    other = torch.zeros_like(film)
+    with pytest.raises(hprt.HprtError, match="not the buffer"):      # a film buffer the last render did not write
+        comm.film_gather(killeroo_scene, other.data_ptr(), n_pix)
+    with pytest.raises(hprt.HprtError):                                # a film of another size
+        comm.film_gather(killeroo_scene, film.data_ptr(), n_pix - 1)
+    comm.film_gather(killeroo_scene, None, n_pix, root=0, stream=torch.cuda.current_stream().cuda_stream)   # NULL: the buffer the last render wrote
+    assert np.array_equal(film.cpu().numpy().view(np.uint32), plain.view(np.uint32))
+    # the library-owned film is stale after a render into a caller's buffer: reading it is refused, not answered with old pixels
+    with pytest.raises(hprt.HprtError):
+        hprt._check(hprt.lib.hprt_film_read(killeroo_scene._h, hprt._ptr(own), n_pix))
     del comm
+    hprt.lib.hprt_film_gather_local_shutdown()
+    # ... after which the single-process gather simply builds its communicators again
+    killeroo_scene.render(opt, export_foreign=True)
+    hprt.film_gather_local([killeroo_scene], None, n_pix, root=0)
+    hprt._check(hprt.lib.hprt_film_read(killeroo_scene._h, hprt._ptr(own), n_pix))
+    assert np.array_equal(own.view(np.uint32), plain.view(np.uint32))
+    hprt.lib.hprt_film_gather_local_shutdown()
 
 
 def _rccl_rank_worker(rank, world, port, out_path, spp):
@@ -347,6 +367,14 @@ def test_bench_launches_its_own_ranks(tmp_path, killeroo_oracle):
     # a rank count that does not match the flag is refused, not mislabelled
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True)
     assert r.returncode == 2 and "refusing" in r.stderr
+    # a rank that dies in start-up ends the run at once: rank 0 is then waiting in the rendezvous for a peer that will never
+    # come — the launcher must terminate it and return non-zero within seconds, not sit there until somebody's time limit
+    import time
+    t0 = time.time()
+    r = subprocess.run(cmd, env=dict(env, HPRT_TEST_FAIL_RANK="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and time.time() - t0 < 60, (r.returncode, time.time() - t0)
+    assert "[rank 1]" in r.stderr and "terminating the other ranks" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]      # no result line from a broken run
 
 
 def test_per_pixel_statistics_match(hprt, orc, killeroo_scene, killeroo_oracle, tmp_path):

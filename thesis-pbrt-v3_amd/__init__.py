@@ -171,6 +171,8 @@ def _load():
         "hprt_comm_destroy": (None, [vp]),
         "hprt_film_gather": (C.c_int, [vp, vp, vp, sz, C.c_int, vp]),
         "hprt_film_gather_local": (C.c_int, [P(vp), P(vp), C.c_int, sz, C.c_int]),
+        "hprt_film_gather_local_shutdown": (None, []),
+        "hprt_scene_reserve": (C.c_int, [vp, P(RenderDesc)]),
         "hprt_film_records_read": (C.c_int, [vp, vp, sz, P(sz)]),
         "hprt_film_records_merge": (C.c_int, [vp, sz, vp, sz]),
     }
@@ -380,6 +382,13 @@ class Scene:
             film = np.zeros((y1 - y0, x1 - x0, 4), np.float32)
             _check(lib.hprt_film_read(self._h, _ptr(film), film.shape[0] * film.shape[1]))
         return film, st.as_dict()
+
+    def reserve(self, opt=None, tile_begin=0, tile_end=0, tile_stride=1, spp_chunk=0):
+        """hprt_scene_reserve: allocate the workspace of the coming render now (a host that renders once pays it at load)."""
+        desc = RenderDesc()
+        desc.opt = opt or self._model.options
+        desc.tile_begin, desc.tile_end, desc.tile_stride, desc.spp_chunk, desc.flags = tile_begin, tile_end, tile_stride, spp_chunk, 0
+        _check(lib.hprt_scene_reserve(self._h, C.byref(desc)))
 
     def debug_poison(self, byte):
         """Test hook (not part of include/hprt.h): fill every scratch stream, queue and stack with `byte` before each render

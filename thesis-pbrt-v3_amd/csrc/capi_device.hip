@@ -681,6 +681,44 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
 
 // Diagnostics hook (not part of include/hprt.h): the 128 sample points of a voxel, RadicalInverse(0..4, i) as [5][128]
 __attribute__((visibility("default"))) int hprt_debug_poison_workspace(HprtScene *s, int byte) { if (!s) return HPRT_E_INVALID; s->poisonByte = byte < 0 ? -1 : (byte & 255); return HPRT_OK; }
+// Diagnostics hook (not part of include/hprt.h): the first batch of the next hprt_render copies the rays that bounce `bounce` queues
+// (kind 0: the path segments entering bounce + 1, 1: its shadow rays, 2: its BSDF-sampled light rays) into d_out7 ([7][cap] planes:
+// ox oy oz dx dy dz tmax); hprt_debug_captured returns how many.  d_out7 == NULL switches it off.
+__attribute__((visibility("default"))) int hprt_debug_capture_rays(HprtScene *s, int bounce, int kind, float *d_out7, size_t cap) {
+    if (!s || kind < 0 || kind > 2 || cap > 0x7fffffffull) return HPRT_E_INVALID;
+    s->capture.bounce = bounce; s->capture.kind = kind; s->capture.out7 = d_out7; s->capture.cap = cap; s->capture.n = 0;
+    return HPRT_OK;
+}
+__attribute__((visibility("default"))) long long hprt_debug_captured(HprtScene *s) { return s ? (long long)s->capture.n : -1; }
+// Measurement hook (not part of include/hprt.h): HBM stream bandwidth of this box, a float4 copy of `bytes` bytes (src and dst far
+// larger than the 256 MB Infinity Cache), timed with HIP events over `iters` launches after one warm-up; GB/s count read + write.
+__attribute__((visibility("default"))) int hprt_debug_stream_copy(int device, size_t bytes, int iters, double *best_gbs, double *mean_gbs) try {
+    if (!best_gbs || !mean_gbs || iters < 1 || iters > 1000 || bytes < (1u << 20) || bytes > (64ull << 30)) return SetError(HPRT_E_INVALID, "hprt_debug_stream_copy: bad argument");
+    int dev = 0;
+    if (int rc = CheckDevice(device, &dev)) return rc;
+    HIP_TRY(hipSetDevice(dev));
+    DevBuf a, b;
+    HIP_TRY(a.alloc(bytes)); HIP_TRY(b.alloc(bytes));
+    HIP_TRY(hipMemset(a.p, 1, bytes)); HIP_TRY(hipMemset(b.p, 2, bytes));
+    const size_t n = bytes / 16;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    LaunchStreamCopy(nullptr, a.as<float4>(), b.as<float4>(), n);
+    HIP_TRY(hipDeviceSynchronize());
+    double best = 0, sum = 0;
+    for (int i = 0; i < iters; ++i) {
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        LaunchStreamCopy(nullptr, a.as<float4>(), b.as<float4>(), n);
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        const double g = 2.0 * (double)(n * 16) / ((double)ms * 1e-3) / 1e9;
+        best = std::max(best, g); sum += g;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *best_gbs = best; *mean_gbs = sum / iters;
+    return HPRT_OK;
+} catch (...) { return hprt::HandleException(); }
 __attribute__((visibility("default"))) int hprt_debug_voxel_points(float out[640]) { if (!out) return HPRT_E_INVALID; VoxelSamplePoints(out); return HPRT_OK; }
 
 // Diagnostics hook (not part of include/hprt.h): the restated libm functions of hprt_math.h evaluated ON THE DEVICE over host
@@ -831,13 +869,15 @@ int hprt_intersect_device(HprtScene *s, size_t n, const float *d_rays7, float *d
     if (n > 0x7ffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
     if (n == 0) return HPRT_OK;
     HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    SceneCall call(s, st);
     RayStream rays; HitStream hits;
     int rc = ApiStreams(s, n, &rays, &hits);
     if (rc != HPRT_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
     LaunchPackRays(st, d_rays7, (uint32_t)n, rays);
     LaunchTrace(st, s->dev, false, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, rays, hits, nullptr, nullptr, s->workCounter.as<uint32_t>());
     LaunchUnpackHits(st, hits, (uint32_t)n, d_t, d_prim, d_bary3);
+    call.leave_async();
     HIP_TRY(hipGetLastError());
     return HPRT_OK;
 } catch (...) { return hprt::HandleException(); }
@@ -846,13 +886,15 @@ int hprt_occluded_device(HprtScene *s, size_t n, const float *d_rays7, uint8_t *
     if (n > 0x7ffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
     if (n == 0) return HPRT_OK;
     HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    SceneCall call(s, st);
     RayStream rays; HitStream hits;
     int rc = ApiStreams(s, n, &rays, &hits);
     if (rc != HPRT_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
     LaunchPackRays(st, d_rays7, (uint32_t)n, rays);
     HitStream none; none.a = nullptr; none.b = nullptr;
     LaunchTrace(st, s->dev, true, false, nullptr, nullptr, (uint32_t)n, (uint32_t)n, rays, none, d_occ, nullptr, s->workCounter.as<uint32_t>());
+    call.leave_async();
     HIP_TRY(hipGetLastError());
     return HPRT_OK;
 } catch (...) { return hprt::HandleException(); }
@@ -863,6 +905,7 @@ static int TraceHost(HprtScene *s, bool anyHit, size_t n, const float *o, const 
     if (n > 0x7ffffff0ull) return SetError(HPRT_E_INVALID, "too many rays in one call");
     if (n == 0) { if (counters) memset(counters, 0, 32); return HPRT_OK; }
     HIP_TRY(hipSetDevice(s->device));
+    SceneCall call(s, nullptr);      // (blocking call on the null stream: ends in hipDeviceSynchronize)
     std::vector<float4> ra(n), rb(n);
     for (size_t i = 0; i < n; ++i) {
         ra[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], tmax[i]);
@@ -962,6 +1005,13 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         HIP_TRY(hipMemcpyAsync(s->hostCounts + 4096, cur.nextCount, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const uint32_t nNext = s->hostCounts[4096], nShadow = s->hostCounts[4096 + 64], nMis = s->hostCounts[4096 + 128], nResolve = s->hostCounts[4096 + 192];
+        if (s->capture.out7 && s->capture.bounce == bounce && s0 == 0) {      // diagnostics (hprt_debug_capture_rays)
+            const uint32_t *cq = s->capture.kind == 0 ? cur.next : s->capture.kind == 1 ? cur.shadow : cur.mis;
+            const uint32_t cn = s->capture.kind == 0 ? nNext : s->capture.kind == 1 ? nShadow : nMis;
+            const RayStream &cs = s->capture.kind == 0 ? out.ray : s->capture.kind == 1 ? w.vs.shadow : w.vs.mis;
+            LaunchCaptureRays(st, cq, cn, cs, s->capture.out7, (uint32_t)s->capture.cap);
+            s->capture.n = std::min<size_t>(cn, s->capture.cap);
+        }
         if (nShadow) {
             hipEvent_t a = ev.get(), b = ev.get();
             HIP_TRY(hipEventRecord(a, st));
@@ -1024,6 +1074,29 @@ int PoisonWorkspace(HprtScene *s) {
     return HPRT_OK;
 }
 
+// Samples per pixel of one wavefront batch (see the comment at its use in hprt_render)
+int ChooseBatch(HprtScene *s, int32_t sppChunk, uint32_t nPix, uint32_t spp, uint32_t *out) {
+    uint32_t chunk;
+    if (sppChunk > 0) chunk = (uint32_t)sppChunk;
+    else {
+        size_t freeB = 0, totalB = 0;
+        HIP_TRY(hipMemGetInfo(&freeB, &totalB));
+        freeB += s->planes.bytes + s->queues.bytes;                 // this scene's previous workspace is reused or released
+        const size_t perPath = kPlaneBytesPerSlot + 12 * sizeof(uint32_t);
+        static const size_t capM = [] { const char *e = getenv("HPRT_BATCH_MPATHS"); return e ? (size_t)atoi(e) : (size_t)256; }();
+        const size_t budget = std::min<size_t>(capM << 20, std::max<size_t>(freeB / 2 / perPath, 1ull << 20));
+        chunk = std::max<uint32_t>(1u, (uint32_t)(budget / std::max<uint32_t>(nPix, 1u)));
+        if ((uint64_t)chunk * nPix > 0x7fffffffull) chunk = (uint32_t)(0x7fffffffull / nPix);
+        chunk = std::max(1u, std::min(chunk, spp));
+        const uint32_t nBatches = (spp + chunk - 1) / chunk;
+        chunk = (spp + nBatches - 1) / nBatches;                    // equal batches
+    }
+    chunk = std::min(chunk, spp);
+    if ((uint64_t)chunk * nPix > 0x7fffffffull) chunk = (uint32_t)(0x7fffffffull / nPix);
+    *out = chunk;
+    return HPRT_OK;
+}
+
 // Host-side grouping of the irregular samples into per-destination lists, in the exact
 // order the reference's tile loop would have added them (core/integrator.cpp:267-333).
 struct ExtraEntry { uint32_t dest; uint32_t srcTile; uint32_t srcPos; uint32_t sample; uint32_t srcPix; uint8_t pre; };
@@ -1034,6 +1107,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     if (!s || !desc) return SetError(HPRT_E_INVALID, "hprt_render: null argument");
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
+    SceneCall call(s, st);      // (blocking: every path out of a started render has synchronised `st`, or failed)
     const HprtRenderOptions &o = desc->opt;
     int rc0;
     if (o.spp <= 0 || o.max_depth < 0) return SetError(HPRT_E_INVALID, "spp must be positive and max_depth non-negative");
@@ -1057,6 +1131,7 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     s->nForeignRecords = 0; s->foreignExported = (desc->flags & HPRT_RENDER_EXPORT_FOREIGN) != 0;
     float *film = d_film_xyzw;
     if (!film) { HIP_TRY(s->film.alloc(16 * s->filmPixels)); film = s->film.as<float>(); }
+    s->lastFilm = film;
     HIP_TRY(hipMemsetAsync(film, 0, 16 * s->filmPixels, st));
     if (nPix == 0) { HIP_TRY(hipStreamSynchronize(st)); return HPRT_OK; }
     // ---- sizes ----
@@ -1067,23 +1142,8 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     // of the 288 GB), less if the device has less free (half of what is free now), and of EQUAL size (1,024 spp of the atrium:
     // two batches of 512 instead of 522 + 502 or, at the old 128 M cap, four of 256: -1 % per frame).  killeroo-simple
     // at 256 spp is one batch of 125 M paths: 6.5 % faster than two batches of 64 M.  (HPRT_BATCH_MPATHS changes the cap.)
-    uint32_t chunk;
-    if (desc->spp_chunk > 0) chunk = (uint32_t)desc->spp_chunk;
-    else {
-        size_t freeB = 0, totalB = 0;
-        HIP_TRY(hipMemGetInfo(&freeB, &totalB));
-        freeB += s->planes.bytes + s->queues.bytes;                 // this scene's previous workspace is reused or released
-        const size_t perPath = kPlaneBytesPerSlot + 12 * sizeof(uint32_t);
-        static const size_t capM = [] { const char *e = getenv("HPRT_BATCH_MPATHS"); return e ? (size_t)atoi(e) : (size_t)256; }();
-        const size_t budget = std::min<size_t>(capM << 20, std::max<size_t>(freeB / 2 / perPath, 1ull << 20));
-        chunk = std::max<uint32_t>(1u, (uint32_t)(budget / std::max<uint32_t>(nPix, 1u)));
-        if ((uint64_t)chunk * nPix > 0x7fffffffull) chunk = (uint32_t)(0x7fffffffull / nPix);
-        chunk = std::max(1u, std::min(chunk, spp));
-        const uint32_t nBatches = (spp + chunk - 1) / chunk;
-        chunk = (spp + nBatches - 1) / nBatches;                    // equal batches
-    }
-    chunk = std::min(chunk, spp);
-    if ((uint64_t)chunk * nPix > 0x7fffffffull) chunk = (uint32_t)(0x7fffffffull / nPix);
+    uint32_t chunk = 0;
+    if ((rc = ChooseBatch(s, desc->spp_chunk, nPix, spp, &chunk)) != HPRT_OK) return rc;
     const size_t maxSlots = (size_t)chunk * nPix;
     Workspace ps; QueueSet qa, qb; BinSet bins;
     rc = EnsureWorkspace(s, maxSlots, &ps, &qa, &qb, &bins);
@@ -1235,9 +1295,45 @@ int hprt_render(HprtScene *s, const HprtRenderDesc *desc, float *d_film_xyzw, vo
     return HPRT_OK;
 } catch (...) { return hprt::HandleException(); }
 
+// Pays for the coming hprt_render(s, desc, ...) at load time: the wavefront workspace (path streams and queues: ~393 B per path of
+// a batch, 105 GB for a 256 M-path batch) and the per-sample radiance store are allocated now, so that the render itself starts
+// with its first kernel.  (A fresh process gets 100 GB in under a millisecond, but right after another process released as much the
+// driver may spend seconds reclaiming it inside hipMalloc — DESIGN.md §7; a pbrt host renders once and would pay that inside Render().)
+int hprt_scene_reserve(HprtScene *s, const HprtRenderDesc *desc) try {
+    if (!s || !desc) return SetError(HPRT_E_INVALID, "hprt_scene_reserve: null argument");
+    const HprtRenderOptions &o = desc->opt;
+    if (o.spp <= 0 || o.max_depth < 0) return SetError(HPRT_E_INVALID, "spp must be positive and max_depth non-negative");
+    HIP_TRY(hipSetDevice(s->device));
+    SceneCall call(s, nullptr);
+    FrameSetup f;
+    int rc = SetupFrame(o, &f);
+    if (rc != HPRT_OK) return rc;
+    const int nTiles = f.ntx * f.nty;
+    const int tb = std::max(0, desc->tile_begin), te = desc->tile_end <= 0 ? nTiles : std::min(desc->tile_end, nTiles), ts = std::max(1, desc->tile_stride);
+    uint64_t nPix64 = 0;
+    for (int t = tb; t < te; t += ts) {
+        const int tx = t % f.ntx, ty = t / f.ntx;
+        const int x0 = f.fg.sx0 + tx * 16, x1 = std::min(x0 + 16, f.fg.sx1), y0 = f.fg.sy0 + ty * 16, y1 = std::min(y0 + 16, f.fg.sy1);
+        nPix64 += (uint64_t)(x1 - x0) * (uint64_t)(y1 - y0);
+    }
+    if (nPix64 == 0) return HPRT_OK;
+    const uint32_t nPix = (uint32_t)nPix64, spp = (uint32_t)o.spp;
+    const size_t lallBytes = 3ull * spp * nPix * sizeof(float);
+    if (lallBytes > (96ull << 30)) return SetError(HPRT_E_UNSUPPORTED, "per-sample radiance store would exceed 96 GiB; render in several tile ranges");
+    uint32_t chunk = 0;
+    if ((rc = ChooseBatch(s, desc->spp_chunk, nPix, spp, &chunk)) != HPRT_OK) return rc;
+    Workspace ps; QueueSet qa, qb; BinSet bins;
+    if ((rc = EnsureWorkspace(s, (size_t)chunk * nPix, &ps, &qa, &qb, &bins)) != HPRT_OK) return rc;
+    HIP_TRY(s->Lall.alloc(lallBytes));
+    HIP_TRY(s->pixelXY.alloc((size_t)nPix * sizeof(uint32_t))); HIP_TRY(s->pixelOffset.alloc((size_t)nPix * sizeof(uint64_t)));
+    HIP_TRY(hipDeviceSynchronize());
+    return HPRT_OK;
+} catch (...) { return hprt::HandleException(); }
+
 // Pixel::stats of the last hprt_render with HPRT_RENDER_PIXEL_STATS (core/film.h:91): 7 values per film pixel
 int hprt_pixel_stats_read(HprtScene *s, uint64_t *out7, size_t n_pixels) try {
     if (!s || !out7) return SetError(HPRT_E_INVALID, "hprt_pixel_stats_read: null argument");
+    SceneCall call(s, nullptr);
     if (!s->pixelStatsValid) return SetError(HPRT_E_INVALID, "no per-pixel statistics: render with HPRT_RENDER_PIXEL_STATS first");
     if (n_pixels != s->filmPixels) return SetError(HPRT_E_INVALID, "hprt_pixel_stats_read: pixel count differs from the last render's film");
     HIP_TRY(hipSetDevice(s->device));
@@ -1246,7 +1342,9 @@ int hprt_pixel_stats_read(HprtScene *s, uint64_t *out7, size_t n_pixels) try {
 } catch (...) { return hprt::HandleException(); }
 int hprt_film_read(HprtScene *s, float *xyzw_out, size_t n_pixels) try {
     if (!s || !xyzw_out) return SetError(HPRT_E_INVALID, "hprt_film_read: null argument");
-    if (!s->film.p || n_pixels != s->filmPixels) return SetError(HPRT_E_INVALID, "hprt_film_read: no library-owned film of that size (render with d_film_xyzw == NULL first)");
+    SceneCall call(s, nullptr);
+    if (!s->film.p || s->lastFilm != s->film.as<float>() || n_pixels != s->filmPixels)
+        return SetError(HPRT_E_INVALID, "hprt_film_read: the last render did not write a library-owned film of that size (render with d_film_xyzw == NULL first)");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemcpy(xyzw_out, s->film.p, 16 * n_pixels, hipMemcpyDeviceToHost));
     return HPRT_OK;
@@ -1260,6 +1358,7 @@ int hprt_sample_radiance(HprtScene *s, const HprtRenderOptions *opt, size_t n, c
     if (opt->max_depth < 0) return SetError(HPRT_E_INVALID, "max_depth must be non-negative");
     if (int rcd = CheckDepth(opt->max_depth)) return rcd;
     HIP_TRY(hipSetDevice(s->device));
+    SceneCall call(s, nullptr);
     FrameSetup f;
     int rc = SetupFrame(*opt, &f);
     if (rc != HPRT_OK) return rc;

@@ -127,40 +127,66 @@ void hprt_comm_destroy(HprtComm *c) {
     delete c;
 }
 
+// A rank whose own arguments or state are unusable must not return before the collectives: its peers would wait in them for
+// ever.  Every rank therefore reaches the count all-gather, a failing one sends COUNT_FAILED instead of its record count, and
+// all ranks return an error together; the one failure that can only happen later (the root's staging allocation) is agreed
+// on by a one-word all-reduce before the grouped reduce / send / recv.  Inside the group the first error is kept and
+// ncclGroupEnd is ALWAYS called: a group left open makes the communicator unusable.
+static const uint32_t COUNT_FAILED = 0xffffffffu;
+
 int hprt_film_gather(HprtComm *c, HprtScene *s, float *d_film_xyzw, size_t n_pixels, int root, void *stream) try {
-    if (!c || !s) return SetError(HPRT_E_INVALID, "hprt_film_gather: null argument");
-    if (root < 0 || root >= c->nRanks) return SetError(HPRT_E_INVALID, "hprt_film_gather: root outside the communicator");
-    if (s->device != c->device) return SetError(HPRT_E_INVALID, "hprt_film_gather: scene and communicator live on different devices");
-    int rc = CheckGatherable(s, n_pixels);
-    if (rc != HPRT_OK) return rc;
-    float *film = d_film_xyzw ? d_film_xyzw : s->film.as<float>();
-    if (!film) return SetError(HPRT_E_INVALID, "hprt_film_gather: no film (render first)");
+    if (!c || !s) return SetError(HPRT_E_INVALID, "hprt_film_gather: null argument");      // (nothing to take part with)
+    int localRc = HPRT_OK; std::string localMsg;
+    auto fail = [&](int code, const std::string &m) { if (localRc == HPRT_OK) { localRc = code; localMsg = m; } };
+    if (root < 0 || root >= c->nRanks) fail(HPRT_E_INVALID, "hprt_film_gather: root outside the communicator");
+    if (s->device != c->device) fail(HPRT_E_INVALID, "hprt_film_gather: scene and communicator live on different devices");
+    if (!s->foreignExported) fail(HPRT_E_INVALID, "film gather: the scene's last render did not set HPRT_RENDER_EXPORT_FOREIGN");
+    else if (n_pixels != s->filmPixels) fail(HPRT_E_INVALID, "film gather: pixel count differs from the last render's film");
+    // the film of the LAST render: the caller's buffer if that render was given one, else the scene's own
+    float *film = d_film_xyzw ? d_film_xyzw : s->lastFilm;
+    if (!film) fail(HPRT_E_INVALID, "hprt_film_gather: no film (render first)");
+    else if (s->lastFilm && film != s->lastFilm) fail(HPRT_E_INVALID, "hprt_film_gather: d_film_xyzw is not the buffer the scene's last render wrote");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
+    SceneCall call(s, st);
     const int n = c->nRanks;
-    // ---- record counts of every rank ----
+    // ---- record counts of every rank (COUNT_FAILED: that rank cannot go on) ----
     uint32_t *dCounts = c->counts.as<uint32_t>();
-    c->hostCounts[n] = s->nForeignRecords;
+    c->hostCounts[n] = localRc == HPRT_OK ? s->nForeignRecords : COUNT_FAILED;
     HIP_TRY(hipMemcpyAsync(dCounts + n, c->hostCounts + n, sizeof(uint32_t), hipMemcpyHostToDevice, st));
     NCCL_TRY(ncclAllGather(dCounts + n, dCounts, 1, ncclUint32, c->comm, st));
     HIP_TRY(hipMemcpyAsync(c->hostCounts, dCounts, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (localRc != HPRT_OK) return SetError(localRc, localMsg);
+    for (int r = 0; r < n; ++r)
+        if (c->hostCounts[r] == COUNT_FAILED) return SetError(HPRT_E_INVALID, "hprt_film_gather: rank " + std::to_string(r) + " reported a failure; nothing was merged");
     size_t total = 0;
     std::vector<size_t> offset((size_t)n + 1, 0);
     for (int r = 0; r < n; ++r) { offset[r] = total; total += c->hostCounts[r]; }
     offset[n] = total;
-    if (c->rank == root) HIP_TRY(c->staging.alloc(std::max<size_t>(1, total) * sizeof(FilmRecord)));
+    // ---- the root's staging area; every rank learns whether it exists ----
+    uint32_t bad = 0u;
+    if (c->rank == root && c->staging.alloc(std::max<size_t>(1, total) * sizeof(FilmRecord)) != hipSuccess) bad = 1u;
+    c->hostCounts[n] = bad;
+    HIP_TRY(hipMemcpyAsync(dCounts + n, c->hostCounts + n, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    NCCL_TRY(ncclAllReduce(dCounts + n, dCounts + n, 1, ncclUint32, ncclMax, c->comm, st));
+    HIP_TRY(hipMemcpyAsync(c->hostCounts + n, dCounts + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (c->hostCounts[n] != 0u) return SetError(HPRT_E_DEVICE, "hprt_film_gather: the root could not allocate the record staging area; nothing was merged");
     // ---- films: one reduce; records: peer -> root ----
     constexpr size_t kWords = sizeof(FilmRecord) / sizeof(uint32_t);
+    ncclResult_t firstErr = ncclSuccess; const char *firstWhat = "";
+    auto note = [&](ncclResult_t r, const char *what) { if (r != ncclSuccess && firstErr == ncclSuccess) { firstErr = r; firstWhat = what; } };
     NCCL_TRY(ncclGroupStart());
-    NCCL_TRY(ncclReduce(film, film, 4 * n_pixels, ncclFloat, ncclSum, root, c->comm, st));
+    note(ncclReduce(film, film, 4 * n_pixels, ncclFloat, ncclSum, root, c->comm, st), "ncclReduce");
     if (c->rank == root) {
         for (int r = 0; r < n; ++r)
             if (r != root && c->hostCounts[r])
-                NCCL_TRY(ncclRecv(c->staging.as<FilmRecord>() + offset[r], c->hostCounts[r] * kWords, ncclUint32, r, c->comm, st));
+                note(ncclRecv(c->staging.as<FilmRecord>() + offset[r], c->hostCounts[r] * kWords, ncclUint32, r, c->comm, st), "ncclRecv");
     } else if (s->nForeignRecords)
-        NCCL_TRY(ncclSend(s->foreignRecords.p, s->nForeignRecords * kWords, ncclUint32, root, c->comm, st));
-    NCCL_TRY(ncclGroupEnd());
+        note(ncclSend(s->foreignRecords.p, s->nForeignRecords * kWords, ncclUint32, root, c->comm, st), "ncclSend");
+    note(ncclGroupEnd(), "ncclGroupEnd");
+    if (firstErr != ncclSuccess) return SetError(HPRT_E_DEVICE, std::string("hprt_film_gather: ") + firstWhat + ": " + ncclGetErrorString(firstErr));
     if (c->rank != root) { HIP_TRY(hipStreamSynchronize(st)); return HPRT_OK; }
     if (s->nForeignRecords)
         HIP_TRY(hipMemcpyAsync(c->staging.as<FilmRecord>() + offset[root], s->foreignRecords.p, s->nForeignRecords * sizeof(FilmRecord), hipMemcpyDeviceToDevice, st));
@@ -170,37 +196,57 @@ int hprt_film_gather(HprtComm *c, HprtScene *s, float *d_film_xyzw, size_t n_pix
     return ApplyRecords(rec, film, n_pixels, c->staging, c->destBegin, st);
 } catch (...) { return hprt::HandleException(); }
 
+namespace {
+// hprt_film_gather_local's communicators: one clique per device list, created on first use.  The map is never destroyed by
+// the C++ runtime (static destruction may run after the HIP runtime is gone, and a DevBuf's hipFree or ncclCommDestroy would
+// then touch a dead runtime): hprt_film_gather_local_shutdown releases it explicitly.
+struct Clique {
+    std::vector<ncclComm_t> comms; std::vector<int> devs; DevBuf recBuf, beginBuf; int rootDev = 0;
+    ~Clique() {
+        (void)hipSetDevice(rootDev);
+        (void)recBuf.alloc(0); (void)beginBuf.alloc(0);
+        for (ncclComm_t cm : comms) if (cm) (void)ncclCommDestroy(cm);
+    }
+};
+std::mutex &CliqueMutex() { static std::mutex *m = new std::mutex(); return *m; }
+std::map<std::vector<int>, std::unique_ptr<Clique>> &Cliques() { static auto *m = new std::map<std::vector<int>, std::unique_ptr<Clique>>(); return *m; }
+}  // namespace
+
 int hprt_film_gather_local(HprtScene *const *per_gpu, float *const *d_films, int n, size_t n_pixels, int root) try {
     if (!per_gpu || n < 1 || root < 0 || root >= n) return SetError(HPRT_E_INVALID, "hprt_film_gather_local: bad argument");
     std::vector<int> devs(n);
     std::vector<float *> films(n);
+    // (one process: every check runs before the first collective call, so an early return strands nobody)
     for (int i = 0; i < n; ++i) {
         if (!per_gpu[i]) return SetError(HPRT_E_INVALID, "hprt_film_gather_local: null scene");
         int rc = CheckGatherable(per_gpu[i], n_pixels);
         if (rc != HPRT_OK) return rc;
         devs[i] = per_gpu[i]->device;
-        films[i] = (d_films && d_films[i]) ? d_films[i] : per_gpu[i]->film.as<float>();
+        films[i] = (d_films && d_films[i]) ? d_films[i] : per_gpu[i]->lastFilm;
         if (!films[i]) return SetError(HPRT_E_INVALID, "hprt_film_gather_local: a scene has no film (render first)");
+        if (per_gpu[i]->lastFilm && films[i] != per_gpu[i]->lastFilm) return SetError(HPRT_E_INVALID, "hprt_film_gather_local: a film pointer is not the buffer that scene's last render wrote");
         for (int k = 0; k < i; ++k) if (devs[k] == devs[i]) return SetError(HPRT_E_INVALID, "hprt_film_gather_local: two scenes on one device (RCCL refuses duplicate GPUs)");
     }
-    // one clique of communicators per device list, created on first use and kept for the life of the process
-    struct Clique { std::vector<ncclComm_t> comms; DevBuf recBuf, beginBuf; };
-    static std::mutex mu;
-    static std::map<std::vector<int>, std::unique_ptr<Clique>> cliques;
-    std::lock_guard<std::mutex> lock(mu);
-    std::unique_ptr<Clique> &cl = cliques[devs];
+    std::lock_guard<std::mutex> lock(CliqueMutex());
+    std::unique_ptr<Clique> &cl = Cliques()[devs];
     if (!cl) {
         std::unique_ptr<Clique> fresh(new Clique());
-        fresh->comms.resize(n);
+        fresh->comms.assign(n, nullptr); fresh->devs = devs;
         NCCL_TRY(ncclCommInitAll(fresh->comms.data(), n, devs.data()));
         cl = std::move(fresh);
     }
+    cl->rootDev = devs[root];
+    ncclResult_t firstErr = ncclSuccess; hipError_t firstHip = hipSuccess;
     NCCL_TRY(ncclGroupStart());
-    for (int i = 0; i < n; ++i) {
-        HIP_TRY(hipSetDevice(devs[i]));
-        NCCL_TRY(ncclReduce(films[i], films[i], 4 * n_pixels, ncclFloat, ncclSum, root, cl->comms[i], nullptr));
+    for (int i = 0; i < n; ++i) {      // (keep going on an error: the group must be closed whatever happened inside it)
+        const hipError_t he = hipSetDevice(devs[i]);
+        if (he != hipSuccess) { if (firstHip == hipSuccess) firstHip = he; continue; }
+        const ncclResult_t r = ncclReduce(films[i], films[i], 4 * n_pixels, ncclFloat, ncclSum, root, cl->comms[i], nullptr);
+        if (r != ncclSuccess && firstErr == ncclSuccess) firstErr = r;
     }
-    NCCL_TRY(ncclGroupEnd());
+    const ncclResult_t ge = ncclGroupEnd();
+    if (firstHip != hipSuccess) return SetError(HPRT_E_DEVICE, std::string("hprt_film_gather_local: hipSetDevice: ") + hipGetErrorString(firstHip));
+    if (firstErr != ncclSuccess || ge != ncclSuccess) return SetError(HPRT_E_DEVICE, std::string("hprt_film_gather_local: ncclReduce group: ") + ncclGetErrorString(firstErr != ncclSuccess ? firstErr : ge));
     // one process sees every device's memory: the records need no collective
     std::vector<FilmRecord> rec;
     for (int i = 0; i < n; ++i) {
@@ -214,6 +260,11 @@ int hprt_film_gather_local(HprtScene *const *per_gpu, float *const *d_films, int
     HIP_TRY(hipSetDevice(devs[root]));
     return ApplyRecords(rec, films[root], n_pixels, cl->recBuf, cl->beginBuf, nullptr);
 } catch (...) { return hprt::HandleException(); }
+
+void hprt_film_gather_local_shutdown(void) {
+    std::lock_guard<std::mutex> lock(CliqueMutex());
+    Cliques().clear();
+}
 
 int hprt_film_records_read(HprtScene *s, HprtFilmRecord *out, size_t capacity, size_t *n_records) try {
     if (!s || !n_records) return SetError(HPRT_E_INVALID, "hprt_film_records_read: null argument");

@@ -106,6 +106,9 @@ void LaunchFilmForeignExport(hipStream_t st, const RenderParams &rp, const FilmG
                              FilmRecord *out);
 // SpatialLightDistribution for every voxel: ri = RadicalInverse(0..4, i), i < 128, as [5][128] floats on the device
 void LaunchVoxelDistributions(hipStream_t st, const DevScene &sc, const float *ri, uint32_t nVox, float *func, float *cdf, float *funcInt);
+void LaunchStreamCopy(hipStream_t st, const float4 *src, float4 *dst, size_t n);
+// diagnostics: the rays a queue lists, as [7][cap] planes (the layout of the *_device entry points)
+void LaunchCaptureRays(hipStream_t st, const uint32_t *queue, uint32_t n, const RayStream &rays, float *out7, uint32_t cap);
 void LaunchFilmApplyRecords(hipStream_t st, const FilmRecord *rec, const uint32_t *destBegin, uint32_t nDest, float *film);
 
 }  // namespace hprt

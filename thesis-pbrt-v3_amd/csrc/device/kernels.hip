@@ -1430,6 +1430,31 @@ void LaunchPixelStatsToFilm(hipStream_t st, const uint32_t *pix, const uint32_t 
                             unsigned long long *out7) {
     if (nPix) hipLaunchKernelGGL(k_pixel_stats_to_film, dim3(blocks_for(nPix, 256)), dim3(256), 0, st, pix, pixelXY, nPix, spp, cx0, cy0, width, out7);
 }
+__global__ __launch_bounds__(256) void k_capture_rays(const uint32_t *queue, uint32_t n, RayStream rays, float *out7, uint32_t cap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = queue ? queue[i] : i;
+    const float4 a = rays.a[s], b = rays.b[s];
+    const size_t N = cap;
+    out7[i] = a.x; out7[N + i] = a.y; out7[2 * N + i] = a.z; out7[3 * N + i] = b.x; out7[4 * N + i] = b.y; out7[5 * N + i] = b.z; out7[6 * N + i] = a.w;
+}
+void LaunchCaptureRays(hipStream_t st, const uint32_t *queue, uint32_t n, const RayStream &rays, float *out7, uint32_t cap) {
+    n = std::min(n, cap);
+    if (n) hipLaunchKernelGGL(k_capture_rays, dim3(blocks_for(n, 256)), dim3(256), 0, st, queue, n, rays, out7, cap);
+}
+// On-box HBM stream bandwidth (bench.py's roofline.peak_measured): a float4 copy, four 16-byte loads in
+// flight per lane, 256 consecutive bytes per wave and request.
+__global__ __launch_bounds__(256) void k_stream_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
+    const size_t base = (size_t)blockIdx.x * 1024u + threadIdx.x;
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k * 256u < n) v[k] = src[base + k * 256u];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k * 256u < n) dst[base + k * 256u] = v[k];
+}
+void LaunchStreamCopy(hipStream_t st, const float4 *src, float4 *dst, size_t n) {
+    if (n) hipLaunchKernelGGL(k_stream_copy, dim3((uint32_t)((n + 1023) / 1024)), dim3(256), 0, st, src, dst, n);
+}
 void LaunchPackRays(hipStream_t st, const float *rays7, uint32_t n, const RayStream &out) {
     if (n) hipLaunchKernelGGL(k_pack_rays, dim3(blocks_for(n, 256)), dim3(256), 0, st, rays7, n, out);
 }

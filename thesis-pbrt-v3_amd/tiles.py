@@ -35,6 +35,26 @@ def gather_film(film, dist, dst=0, records=None):
     (then the plain sum is the merged film, exact as long as no pixel receives contributions from more than two ranks).
     With the RCCL backend ("nccl") a device tensor is reduced directly over xGMI; with gloo it takes a round trip
     through host memory."""
+    # Agreement before the first data collective, as hprt_film_gather has it (csrc/capi_gather.hip): a rank whose own
+    # arguments are unusable must not leave its peers waiting in the reduce, so every rank publishes what it is about to
+    # merge and all of them raise together when the descriptions differ or one rank reports a failure.
+    hprt = importlib.import_module(__package__)
+    problem = None
+    try:
+        if not hasattr(film, "shape") or not hasattr(film, "is_cuda"):
+            problem = "film is not a tensor"
+        elif records is not None and np.asarray(records).dtype != hprt.FILM_RECORD:
+            problem = "records are not FILM_RECORD entries"
+    except Exception as e:      # (anything odd about the arguments is a local failure, reported like the others)
+        problem = repr(e)
+    mine = (problem, tuple(getattr(film, "shape", ())), str(getattr(film, "dtype", "")), records is not None)
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    failed = [(r, m[0]) for r, m in enumerate(everyone) if m[0] is not None]
+    if failed:
+        raise RuntimeError("gather_film: rank %d reported: %s; nothing was merged" % failed[0])
+    if any(m[1:] != everyone[0][1:] for m in everyone):
+        raise RuntimeError("gather_film: the ranks disagree about the film (shape, dtype, records): %r; nothing was merged" % ([m[1:] for m in everyone],))
     via_host = film.is_cuda and dist.get_backend() == "gloo"
     host = film.cpu() if via_host else film
     dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
@@ -43,7 +63,6 @@ def gather_film(film, dist, dst=0, records=None):
         parts = [None] * world if dist.get_rank() == dst else None
         dist.gather_object(np.ascontiguousarray(records), parts, dst=dst)
         if dist.get_rank() == dst:
-            hprt = importlib.import_module(__package__)
             allrec = np.concatenate([np.asarray(p, hprt.FILM_RECORD) for p in parts]) if parts else np.zeros(0, hprt.FILM_RECORD)
             merged = host.cpu().numpy() if host.is_cuda else host.numpy()
             hprt.film_records_merge(merged, allrec)

@@ -5,10 +5,13 @@ and for the step: kernel time, HBM bytes, HBM bytes / kernel time / peak.
 Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM): FETCH_SIZE and WRITE_SIZE count KiB; FETCH_SIZE
 reports half of the bytes of 16-B-per-lane reads on gfx950 and is doubled; WRITE_SIZE is taken as is.
 usage: counters_summary.py <dir with stats/ sq/ fetch/ write/> <workload name>   -> JSON on stdout"""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench      # code_object_hash: the stamp that ties this summary to the kernels it was taken on
 
 root, workload = sys.argv[1], sys.argv[2]
 PEAK = 8000.0e9
+N_SIMDS = 1024.0      # 256 CUs x 4 SIMDs
 
 
 def short(name):
@@ -33,7 +36,7 @@ K = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in rows("stats", "*_kernel_stats.csv"):
     k = short(r["Name"])
     K[k]["launches"] += int(r["Calls"]); K[k]["total_ns"] += float(r["TotalDurationNs"])
-for sub in ("sq", "fetch", "write"):
+for sub in ("sq", "fetch", "write", "l1", "l2"):
     for r in rows(sub, "*_counter_collection.csv"):
         K[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
 out = {}
@@ -49,6 +52,19 @@ for k, v in K.items():
         step_hbm += hbm
     if v.get("SQ_ACTIVE_INST_VALU"):
         e["lane_utilisation"] = round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4)
+        if v.get("GRBM_GUI_ACTIVE"):
+            # kernel cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs; MI355X_MICROARCH.md "DVFS give-back"); a wave64 VALU
+            # instruction holds its SIMD's issue slot for 4 cycles: fraction of all SIMD issue slots that issued VALU work
+            cycles = v["GRBM_GUI_ACTIVE"] / 8.0
+            e["valu_issue_frac"] = round(v["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * cycles), 4)
+            e["useful_lane_frac"] = round(e["valu_issue_frac"] * e["lane_utilisation"], 4)
+            e["effective_clock_mhz"] = round(cycles / (v["total_ns"] * 1e-9) / 1e6, 1)
+    if v.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        e["l1_accesses"] = round(v["TCP_TOTAL_CACHE_ACCESSES_sum"]); e["l1_miss_rate"] = round(v.get("TCP_TCC_READ_REQ_sum", 0.0) / v["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
+        if v.get("GRBM_GUI_ACTIVE"):
+            e["l1_tagconflict_stall_frac"] = round(v.get("TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", 0.0) / 256.0 / (v["GRBM_GUI_ACTIVE"] / 8.0), 4)      # summed over 256 TCPs
+    if v.get("TCC_HIT_sum") or v.get("TCC_MISS_sum"):
+        e["l2_hit_rate"] = round(v.get("TCC_HIT_sum", 0.0) / max(1.0, v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0)), 4)
     if v.get("SQ_WAVE_CYCLES"):
         e["wait_frac"] = round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4)
         e["valu_per_wave"] = round(v["SQ_INSTS_VALU"] / max(1.0, v["SQ_WAVES"]), 1); e["salu_per_wave"] = round(v["SQ_INSTS_SALU"] / max(1.0, v["SQ_WAVES"]), 1)
@@ -59,4 +75,6 @@ res = {"command": "python3 bench.py --profile-step --workload " + workload,
        "kernel_ms_per_step": round(step_ns / 1e6, 2), "hbm_bytes_per_step": round(step_hbm),
        "step_hbm_frac": round(step_hbm / max(step_ns * 1e-9, 1e-12) / PEAK, 4) if step_ns else None,
        "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["total_ms"]))}
+lib = os.environ.get("HPRT_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "thesis-pbrt-v3_amd", "lib", "libhprt.so")
+res["code_object_sha256"] = bench.code_object_hash(lib)
 print(json.dumps({workload: res}, indent=1))
