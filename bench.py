@@ -88,8 +88,13 @@ WORKLOADS = {
     "killeroo-simple": ("killeroo-simple (66,532 tris + sphere area light) 700x700, halton %d spp, path maxdepth 5, bvh", 256, 128,
                         "reference asset scenes/killeroo-simple, baked (tests/golden/killeroo_simple.hprt)"),
     "living-room": ("living room (143,163 tris of the reference's scenes/living-room meshes with its matte / OrenNayar / substrate / metal / mirror / glass / uber materials; textures as constants, point light for its missing sky map) "
-                    "1280x720, halton %d spp, path maxdepth 5, bvh", 256, 32, "reference meshes, baked (tests/golden/living_room.hprt)"),
+                    "1280x720, halton %d spp, path maxdepth 5, bvh", 2048, 32, "reference meshes, baked (tests/golden/living_room.hprt); BASELINE configs[3]'s class (the conference-room blob is stripped from the reference) at its 2,048 spp"),
+    # BASELINE configs[4] as SURVEY.md §8(d)-5 defines it: TransformedPrimitive instancing (core/primitive.cpp:77-102, core/api.cpp:1778-1820)
+    "instanced-10m": ("10.01 M-triangle instanced scene: the reference's killeroo mesh (33,264 tris, one object definition) x 301 ObjectInstances on a jittered 7x7x7 "
+                      "lattice (PCG32 sequence 5), ground quad, distant light; two-level BVH; 700x700, halton %d spp, path maxdepth 5, bvh", 4096, 8,
+                      "reference mesh (baked, tests/golden/killeroo.hprt) instanced by tools/scene_gen.py:instanced_killeroo"),
 }
+SECONDARY = ("killeroo-simple", "living-room", "instanced-10m")
 
 
 def parse_args():
@@ -234,12 +239,12 @@ def launch_ranks(args):
 
 # ---------------------------------------------------------------------------------------------
 def build_model(hprt, name):
-    if name == "atrium":
+    if name in ("atrium", "instanced-10m"):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import scene_gen
-        text, _ = scene_gen.atrium(1.0)
+        text, _ = scene_gen.atrium(1.0) if name == "atrium" else scene_gen.instanced_killeroo(os.path.join(GOLDEN, "killeroo.hprt"))
         d = tempfile.mkdtemp(prefix="hprt_bench_")
-        path = os.path.join(d, "atrium.pbrt")
+        path = os.path.join(d, name + ".pbrt")
         with open(path, "w") as f:
             f.write(text)
         return hprt.Model.parse(path)
@@ -556,11 +561,11 @@ def main():
     # =========================================================================================
     secondary = []
     if not args.no_secondary:
-        for name in [n for n in ("killeroo-simple", "living-room") if n != args.workload] + (["atrium"] if args.workload != "atrium" else []):
+        for name in [n for n in SECONDARY if n != args.workload] + (["atrium"] if args.workload != "atrium" else []):
             d2, spp2, cpu2, label2 = WORKLOADS[name]
             spp2 = spp2 * (world if args.weak else 1)
             del_w = Workload(hprt, tiles, torch, name, spp2, dev, rank, world)
-            steps2 = max(1, min(args.steps, 3))
+            steps2 = max(1, min(args.steps, 3 if name == "killeroo-simple" else 2))      # (the 2,048 / 4,096 spp frames take seconds each)
             e2, r2, s2, st2 = timed(del_w, steps2, 1)
             item = None
             if rank == 0:

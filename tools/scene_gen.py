@@ -107,3 +107,48 @@ def instanced(xres=700, yres=700, spp=64, maxdepth=5, n_side=32, grid=72):
             'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]\nSampler "halton" "integer pixelsamples" [%d]\n'
             'Integrator "path" "integer maxdepth" [%d]\nWorldBegin\n%sWorldEnd\n' % (xres, yres, spp, maxdepth, "".join(body)))
     return text, n_side * n_side * 2 * (grid - 1) ** 2 + 2
+
+
+class _PCG32:
+    """pbrt's RNG (core/rng.h:64-144) — the generator SURVEY.md §8(d)-5 names for the lattice jitter."""
+    MULT = 0x5851f42d4c957f2d
+    def __init__(self, seq):
+        self.state, self.inc = 0, ((seq << 1) | 1) & 0xffffffffffffffff
+        self.u32(); self.state = (self.state + 0x853c49e6748fea9b) & 0xffffffffffffffff; self.u32()
+    def u32(self):
+        old = self.state
+        self.state = (old * self.MULT + self.inc) & 0xffffffffffffffff
+        x = (((old >> 18) ^ old) >> 27) & 0xffffffff
+        rot = old >> 59
+        return ((x >> rot) | (x << ((-rot) & 31))) & 0xffffffff
+    def f(self):
+        return min(float(np.float32(self.u32()) * np.float32(2.0 ** -32)), float(np.nextafter(np.float32(1), np.float32(0))))
+
+
+def instanced_killeroo(killeroo_baked, xres=700, yres=700, spp=64, maxdepth=5, n_instances=301):
+    """BASELINE.json configs[4] as SURVEY.md §8(d)-5 writes it: the killeroo mesh (33,264 triangles after one Loop level: the baked
+    mesh of the reference's scenes/killeroo, tests/golden/killeroo.hprt) as ONE object definition, instanced 301 times
+    (= 10.01 M triangles) through ObjectBegin / ObjectInstance on a jittered 7 x 7 x 7 lattice (PCG32 sequence 5, the first 301
+    cells, x fastest), each instance also turned about the vertical axis; a ground quad; one distant light."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import baked_reader
+    mesh = [s for s in baked_reader.read_shapes(killeroo_baked)["shapes"] if s["kind"] == 0][0]
+    lo, hi = mesh["P"].min(0), mesh["P"].max(0)
+    P = (mesh["P"] - 0.5 * (lo + hi)).astype(np.float32)      # object space: centred on its bounding box
+    obj = ('ObjectBegin "killeroo"\nShape "trianglemesh" "integer indices" [' + " ".join(map(str, mesh["indices"].ravel())) + '] "point P" [' +
+           " ".join("%.9g" % v for v in P.ravel()) + '] "normal N" [' + " ".join("%.9g" % v for v in mesh["N"].ravel()) + "]\nObjectEnd\n")
+    sx, sy, sz = 460.0, 460.0, 260.0      # lattice spacing: the mesh is 72 x 397 x 182 and turns about z
+    rng = _PCG32(5)
+    body = ['LightSource "distant" "point from" [0.4 -0.5 1] "point to" [0 0 0] "color L" [3.2 3.1 2.9]\n',
+            'Material "matte" "color Kd" [.55 .5 .42]\n' + _mesh([[-6000, -6000, -260], [6000, -6000, -260], [6000, 6000, -260], [-6000, 6000, -260]], [0, 1, 2, 0, 2, 3]),
+            'Material "plastic" "color Kd" [.4 .5 .4] "color Ks" [.3 .3 .3] "float roughness" [.15]\n', obj]
+    for c in range(n_instances):
+        i, j, k = c % 7, (c // 7) % 7, c // 49
+        jx, jy, jz, ang = rng.f(), rng.f(), rng.f(), rng.f()
+        body.append('AttributeBegin\nTranslate %.9g %.9g %.9g\nRotate %.9g 0 0 1\nObjectInstance "killeroo"\nAttributeEnd\n' % (
+            (i - 3 + 0.5 * (jx - 0.5)) * sx, (j - 3 + 0.5 * (jy - 0.5)) * sy, (k + 0.5 * (jz - 0.5)) * sz, 360.0 * ang))
+    text = ('LookAt -3300 -3900 2600  0 0 700  0 0 1\nCamera "perspective" "float fov" [40]\n'
+            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]\nSampler "halton" "integer pixelsamples" [%d]\n'
+            'Integrator "path" "integer maxdepth" [%d]\nAccelerator "bvh"\nWorldBegin\n%sWorldEnd\n' % (xres, yres, spp, maxdepth, "".join(body)))
+    return text, n_instances * len(mesh["indices"]) + 2
