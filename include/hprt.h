@@ -80,6 +80,11 @@ int hprt_model_texture_level(const HprtModel *m, uint32_t texture, uint32_t leve
 /* Baked scene container (post-parse, world-space; DESIGN.md "Baked scene"). */
 int hprt_model_load(const char *baked_path, HprtModel **out);
 int hprt_model_save(const HprtModel *m, const char *baked_path);
+/* The same with every image texture stored as the image it was read from (8-bit texels as the file held them + the
+ * conversion parameters of ImageTexture::GetTexture, textures/imagemap.cpp:52-97) instead of its finished float pyramid:
+ * 3 bytes per source texel instead of 16 per power-of-two texel.  hprt_model_load rebuilds the pyramid with the MIPMap
+ * constructor that built it at parse time (core/mipmap.h:113-201), so both forms load to the same floats. */
+int hprt_model_save_compact(const HprtModel *m, const char *baked_path);
 void hprt_model_destroy(HprtModel *m);
 int hprt_model_get_options(const HprtModel *m, HprtRenderOptions *out);
 int hprt_model_set_options(HprtModel *m, const HprtRenderOptions *in);
@@ -147,6 +152,7 @@ typedef struct HprtMaterialDesc {    /* materials/matte.cpp:64-72, materials/pla
     /* type 6, UberMaterial (materials/uber.cpp): Kd, Ks as named, roughness = uroughness, sigma = vroughness, and the lobes only it
      * has: Kr (specular reflection), Kt (specular transmission), opacity (1 - opacity passes straight through), eta */
     float Kr[3], Kt[3], opacity[3], eta;
+    int32_t opacity_texture;         /* uber: "opacity" as an image texture (materials/uber.cpp:53, scenes/livingroom:30), else -1 */
 } HprtMaterialDesc;
 
 /* ImageTexture<RGBSpectrum, Spectrum> (textures/imagemap.h:71-122) with its built MIPMap (core/mipmap.h):

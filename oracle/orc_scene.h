@@ -23,6 +23,7 @@ struct Material {
     int KdTex = -1, KsTex = -1;       // Scene::textures index when the parameter is an ImageTexture
     // uber (materials/uber.cpp; roughness = uroughness, sigma = vroughness): the lobes the other materials do not have
     Float Kr[3] = {0, 0, 0}, Kt[3] = {0, 0, 0}, opacity[3] = {1, 1, 1}; Float eta = 1.5f;
+    int opTex = -1;                   // uber: "opacity" as an ImageTexture (materials/uber.cpp:53)
 };
 // ImageTexture<RGBSpectrum, Spectrum> with its built MIPMap (textures/imagemap.h, core/mipmap.h).  The pyramid is
 // built once by the product's host code (csrc/texture_io.cpp) and travels in the baked scene; lookups are restated here.
@@ -109,7 +110,7 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
     char magic[8]; r.raw(magic, 8);
     if (!r.ok || memcmp(magic, "HPRTSCN1", 8) != 0) { *err = "bad magic"; return false; }
     uint32_t version = r.u32();
-    if (version < 1 || version > 5) { *err = "bad version"; return false; }
+    if (version < 1 || version > 6) { *err = "bad version"; return false; }
     SceneParams &p = sc->prm;
     p.xres = r.i32(); p.yres = r.i32();
     for (int i = 0; i < 4; ++i) p.crop[i] = r.f32();
@@ -203,6 +204,9 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
         if (!r.ok || nTex > (1u << 20)) { *err = "bad texture count"; return false; }
         sc->textures.resize(nTex);
         for (auto &t : sc->textures) {
+            // version 6: a texture record is led by its form; the oracle reads finished pyramids only (form 0) — a compact file (the
+            // source image, rebuilt by the product's MIPMap constructor at load) is expanded by the product first (Model.save)
+            if (version >= 6 && r.i32() != 0) { *err = "compact texture record: save the model in expanded form for the oracle"; return false; }
             t.trilinear = r.i32(); t.maxAniso = r.f32(); t.wrap = r.i32(); t.su = r.f32(); t.sv = r.f32(); t.du = r.f32(); t.dv = r.f32();
             r.raw(t.weightLut, sizeof(t.weightLut));
             uint32_t nl = r.u32();
@@ -230,6 +234,12 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
             if (m.type == MAT_UBER) { r.raw(m.Kr, 12); r.raw(m.Kt, 12); r.raw(m.opacity, 12); m.eta = r.f32(); }
     } else
         for (auto &m : sc->materials) if (m.type == MAT_UBER) { *err = "uber material in a container older than version 5"; return false; }
+    if (version >= 6)        // uber materials: the opacity texture
+        for (auto &m : sc->materials)
+            if (m.type == MAT_UBER) {
+                m.opTex = r.i32();
+                if (!r.ok || m.opTex < -1 || m.opTex >= (int)sc->textures.size()) { *err = "bad opacity texture index"; return false; }
+            }
     if (!r.ok) { *err = "truncated file"; return false; }
     return true;
 }

@@ -491,7 +491,7 @@ inline void ComputeScatteringFunctions(const Scene &scene, const Material &m, co
     const Spec Ks = m.KsTex >= 0 ? EvalImageTexture(scene.textures[m.KsTex], si) : Spec(m.Ks[0], m.Ks[1], m.Ks[2]);
     if (m.type == MAT_UBER) {        // materials/uber.cpp:45-108 (constant e, opacity, Kr, Kt; roughness = uroughness, sigma = vroughness; no bump map)
         const Float e = m.eta;
-        Spec op = Spec(m.opacity[0], m.opacity[1], m.opacity[2]).Clamp();
+        Spec op = (m.opTex >= 0 ? EvalImageTexture(scene.textures[m.opTex], si) : Spec(m.opacity[0], m.opacity[1], m.opacity[2])).Clamp();      // opacity->Evaluate(*si).Clamp(), :53
         Spec t = (-op + Spec(1.f)).Clamp();
         if (!t.IsBlack()) {
             bsdf->eta = 1.f;

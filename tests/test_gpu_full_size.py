@@ -130,7 +130,8 @@ def test_configs_3_and_4_at_their_own_spp(hprt, orc, tmp_path, bench_module, nam
     assert (st_b["rays"], st_b["shadow_rays"]) == (st_a["rays"], st_a["shadow_rays"])
     assert np.array_equal(film_a.view(np.uint32), film_b.view(np.uint32))
     w = film_a[..., 3]
-    assert np.isfinite(film_a).all() and (np.abs(w - spp) <= 6).all() and (w == spp).mean() > 0.8, (float(w.min()), float(w.max()), float((w == spp).mean()))
+    # (a sample whose Halton offset is exactly 0 also lands in the neighbouring pixel: ~1 in 16,000 samples, so at 4,096 spp a quarter of the pixels carry one)
+    assert np.isfinite(film_a).all() and (w >= spp).all() and (w - spp <= 8).all() and (w == spp).mean() > 0.6, (float(w.min()), float(w.max()), float((w == spp).mean()))
     merged = np.zeros_like(film_a)
     records = []
     for r in range(2):

@@ -31,6 +31,16 @@ def _write_images(d):
     _write_tga(str(d / "stripes.tga"), np.repeat(_checker(48, 6, 5)[:, :1], 20, axis=1), rle=True)   # 20 x 48: non power of two
     rng = np.random.default_rng(11)
     _write_pfm(str(d / "hdr.pfm"), (rng.random((33, 57, 3)) * 1.5).astype(np.float32))                # resampled to 64 x 64
+    # a "leaf": the colour image doubles as the opacity map (scenes/livingroom:12-13,30 binds leaf.tga to Kd AND opacity): black
+    # (opacity 0) outside a blob, grey levels on its fringe, and some texels with channels that differ (a coloured opacity)
+    yy, xx = np.mgrid[0:45, 0:37]
+    r = np.hypot((xx - 18) / 15.0, (yy - 22) / 19.0)
+    leaf = np.zeros((45, 37, 3), np.int32)
+    leaf[r < 1.0] = [40, 170, 60]
+    fringe = (r >= 0.8) & (r < 1.0)
+    leaf[fringe] = (leaf[fringe] * ((1.0 - r[fringe]) / 0.2)[:, None]).astype(np.int32)
+    leaf[20:24, 10:14] = [255, 128, 0]
+    _write_tga(str(d / "leaf.tga"), np.clip(leaf + np.random.default_rng(4).integers(0, 12, leaf.shape) * (leaf.sum(-1, keepdims=True) > 0), 0, 255).astype(np.uint8), rle=False)
     sky = np.zeros((8, 16, 3), np.float32)                                                              # a power-of-two map with a bright patch
     sky[...] = [0.1, 0.15, 0.3]; sky[1:3, 10:13] = [30.0, 28.0, 20.0]
     _write_pfm(str(d / "sky.pfm"), sky)
@@ -75,6 +85,16 @@ CASES = {
     "infinite_sun_patch": _scene('AttributeBegin\nRotate -90 1 0 0\nLightSource "infinite" "string mapname" "%(dir)s/sky.pfm"\nAttributeEnd\n' +
                                  _tex("chk", "chk.png", '"float uscale" [3] "float vscale" [3]') % {"dir": "%(dir)s"} +
                                  'Material "matte" "texture Kd" "chk"\nShape "trianglemesh" ' + FLOOR + "\n" + MATTE + 'Shape "trianglemesh" ' + BUMPY + "\n", spp=8),
+    # UberMaterial with an image texture on Kd AND on opacity (materials/uber.cpp:53-61: what is not opaque passes straight through
+    # a SpecularTransmission(1 - opacity, 1, 1) lobe): the living room's leaves (scenes/livingroom:30).  A canopy of textured quads
+    # over the floor, two lights, depth 6 so that paths thread several leaves
+    "uber_textured_opacity": _scene(SPHERE_LIGHT + 'LightSource "point" "point from" [-2 -1 3.5] "color I" [9 9 8]\n' +
+                                    _tex("leafc", "leaf.tga", '"bool trilinear" ["true"]') + _tex("leafo", "leaf.tga", '"bool trilinear" ["true"]') +
+                                    _tex("leafe", "leaf.tga", '"float uscale" [2] "float vscale" [2] "string wrap" ["black"]') +
+                                    MATTE + 'Shape "trianglemesh" ' + FLOOR + "\n" +
+                                    'Material "uber" "rgb Ks" [0 0 0] "texture Kd" "leafc" "texture opacity" "leafo"\nShape "trianglemesh" ' + BUMPY_UV + "\n"
+                                    'AttributeBegin\nTranslate 0.3 0.2 0.9\nRotate 25 1 0 0\nMaterial "uber" "rgb Kd" [.3 .5 .2] "rgb Ks" [.2 .2 .2] "rgb Kr" [.1 .1 .1] "rgb Kt" [.2 .2 .2] '
+                                    '"float roughness" [.2] "float index" [1.3] "texture opacity" "leafe"\nShape "trianglemesh" ' + BUMPY_UV + "\nAttributeEnd\n", spp=4, maxdepth=6),
     # one sample per pixel (differential scale 1), and far minification (grazing floor up to the horizon)
     "spp1_grazing": """LookAt 0 -3.9 -0.25  0 4 -0.45  0 0 1
 Camera "perspective" "float fov" [55]

@@ -600,3 +600,43 @@ def test_corrupt_and_truncated_inputs_are_refused_not_fatal(hprt, tmp_path):
                 head % (b"3", b"77777") + good[-49:]):
         with pytest.raises(hprt.HprtError):
             hprt.Model.parse(scene_with(bad))
+
+
+def test_compact_container_carries_the_image_not_the_pyramid(hprt, orc, tmp_path):
+    """Baked container version 6 (csrc/scene_io.cpp): an image texture travels as the image it was read from (8-bit texels + the
+    conversion parameters of ImageTexture::GetTexture) and the product's own MIPMap constructor rebuilds the pyramid at load —
+    the same floats as the expanded form, at a fraction of the size; an uber material's textured opacity
+    (materials/uber.cpp:53, scenes/livingroom:30) is part of the model in both forms.  The oracle reads finished pyramids only."""
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (45, 37, 3)).astype(np.uint8)          # not a power of two: resampled to 64 x 64
+    _write_tga(str(tmp_path / "leaf.tga"), img, rle=False)
+    text = ('LookAt 0 -4 2  0 0 0  0 0 1\nCamera "perspective" "float fov" [40]\nFilm "image" "integer xresolution" [32] "integer yresolution" [24]\n'
+            'Sampler "halton" "integer pixelsamples" [2]\nIntegrator "path" "integer maxdepth" [3]\nWorldBegin\n'
+            'LightSource "point" "point from" [0 0 4] "color I" [20 20 20]\n'
+            'Texture "c" "spectrum" "imagemap" "string filename" "%s/leaf.tga" "bool trilinear" ["true"]\n'
+            'Texture "o" "spectrum" "imagemap" "string filename" "%s/leaf.tga" "float scale" [1.5]\n'
+            'Material "uber" "rgb Ks" [0 0 0] "texture Kd" "c" "texture opacity" "o"\n'
+            'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-2 -2 0 2 -2 0 2 2 0 -2 2 0] "float uv" [0 0 1 0 1 1 0 1]\nWorldEnd\n' % (tmp_path, tmp_path))
+    p = tmp_path / "leaf.pbrt"; p.write_text(text)
+    m = hprt.Model.parse(str(p))
+    assert m.warnings() == [] and m.counts()["textures"] == 2
+    full, small = str(tmp_path / "full.hprt"), str(tmp_path / "small.hprt")
+    m.save(full); m.save(small, compact=True)
+    assert os.path.getsize(small) < os.path.getsize(full) / 4
+    a, b = hprt.Model.load(full), hprt.Model.load(small)
+    for t in range(2):
+        ia, la = a.texture(t); ib, lb = b.texture(t); i0, l0 = m.texture(t)
+        assert ia == ib == i0 and len(la) == len(lb) == 7
+        for x, y, z in zip(la, lb, l0):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)) and np.array_equal(x.view(np.uint32), z.view(np.uint32))
+    # a compact file loads and saves again in either form: expanded from compact == expanded from the parse
+    again = str(tmp_path / "again.hprt"); b.save(again)
+    assert open(again, "rb").read() == open(full, "rb").read()
+    b.save(again, compact=True)
+    assert open(again, "rb").read() == open(small, "rb").read()
+    # the oracle renders the expanded form (textured opacity included: the quad is partly see-through) and refuses the compact one
+    o = orc.OracleScene(full)
+    rgb, film, c, _, _ = o.render(threads=2)
+    assert film[..., 3].min() >= 2 and rgb.max() > 0
+    with pytest.raises(RuntimeError, match="compact"):
+        orc.OracleScene(small)

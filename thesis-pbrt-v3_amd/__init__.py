@@ -95,7 +95,7 @@ class ShapeDesc(C.Structure):
 class MaterialDesc(C.Structure):
     _fields_ = [("type", C.c_int32), ("Kd", C.c_float * 3), ("sigma", C.c_float), ("Ks", C.c_float * 3), ("roughness", C.c_float),
                 ("remap_roughness", C.c_int32), ("kd_texture", C.c_int32), ("ks_texture", C.c_int32),
-                ("Kr", C.c_float * 3), ("Kt", C.c_float * 3), ("opacity", C.c_float * 3), ("eta", C.c_float)]
+                ("Kr", C.c_float * 3), ("Kt", C.c_float * 3), ("opacity", C.c_float * 3), ("eta", C.c_float), ("opacity_texture", C.c_int32)]
 
 
 class TextureLevel(C.Structure):
@@ -135,6 +135,7 @@ def _load():
         "hprt_model_parse": (C.c_int, [cp, P(cp), C.c_int, P(vp)]),
         "hprt_model_load": (C.c_int, [cp, P(vp)]),
         "hprt_model_save": (C.c_int, [vp, cp]),
+        "hprt_model_save_compact": (C.c_int, [vp, cp]),
         "hprt_model_destroy": (None, [vp]),
         "hprt_model_get_options": (C.c_int, [vp, P(RenderOptions)]),
         "hprt_model_set_options": (C.c_int, [vp, P(RenderOptions)]),
@@ -221,8 +222,9 @@ class Model:
         _check(lib.hprt_model_load(path.encode(), C.byref(h)))
         return Model(h)
 
-    def save(self, path):
-        _check(lib.hprt_model_save(self._h, path.encode()))
+    def save(self, path, compact=False):
+        """Baked container; compact=True stores image textures as their source images (rebuilt at load) instead of float pyramids."""
+        _check((lib.hprt_model_save_compact if compact else lib.hprt_model_save)(self._h, path.encode()))
 
     @property
     def options(self):

@@ -425,9 +425,11 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     for (uint32_t m = 0; m < d->n_materials; ++m) {
         const HprtMaterialDesc &in = d->materials[m];
         if (in.type < 0 || in.type > 6) return SetError(HPRT_E_UNSUPPORTED, "material type outside the hot-path scope (matte, plastic, mirror, substrate, metal, glass, uber)");
-        if (in.kd_texture >= (int32_t)d->n_textures || in.ks_texture >= (int32_t)d->n_textures) return SetError(HPRT_E_INVALID, "material texture index out of range");
+        if (in.kd_texture >= (int32_t)d->n_textures || in.ks_texture >= (int32_t)d->n_textures || (in.type == 6 && in.opacity_texture >= (int32_t)d->n_textures))
+            return SetError(HPRT_E_INVALID, "material texture index out of range");
         DevMaterial &o = mats[m];
         o.KdTex = in.kd_texture >= 0 ? in.kd_texture : -1; o.KsTex = in.ks_texture >= 0 ? in.ks_texture : -1;
+        o.opTex = in.type == 6 && in.opacity_texture >= 0 ? in.opacity_texture : -1;
         o.type = in.type; memcpy(o.Kd, in.Kd, 12); memcpy(o.Ks, in.Ks, 12);
         o.alpha = in.remap_roughness ? RoughnessToAlpha(in.roughness) : in.roughness;
         o.alphaY = o.alpha;
@@ -689,6 +691,32 @@ __attribute__((visibility("default"))) int hprt_debug_capture_rays(HprtScene *s,
     s->capture.bounce = bounce; s->capture.kind = kind; s->capture.out7 = d_out7; s->capture.cap = cap; s->capture.n = 0;
     return HPRT_OK;
 }
+static int ApiStreams(HprtScene *s, size_t n, RayStream *rays, HitStream *hits);
+// Diagnostics (tools/sort_experiment.py): what consuming rays through a PERMUTED index queue costs.  The n rays of d_rays7 stay where
+// they are; d_queue lists them in the order to be traced.  ms[0]: a streaming pass that gathers the rays through the queue into
+// [7][n] planes at d_scratch7 (the physical permutation a sort would have to do), ms[1]: k_trace reading the rays through the queue.
+__attribute__((visibility("default"))) int hprt_debug_trace_queued(HprtScene *s, size_t n, const float *d_rays7, const uint32_t *d_queue, int anyHit,
+                                                                    float *d_scratch7, float ms[2]) try {
+    if (!s || !d_rays7 || !d_queue || !d_scratch7 || !ms || n == 0 || n > 0x7ffffff0ull) return SetError(HPRT_E_INVALID, "hprt_debug_trace_queued: bad argument");
+    HIP_TRY(hipSetDevice(s->device));
+    SceneCall call(s, nullptr);
+    RayStream rays; HitStream hits;
+    if (int rc = ApiStreams(s, n, &rays, &hits)) return rc;
+    DevBuf occ; HIP_TRY(occ.alloc(n));
+    hipEvent_t e[3];
+    for (auto &x : e) HIP_TRY(hipEventCreate(&x));
+    LaunchPackRays(nullptr, d_rays7, (uint32_t)n, rays);
+    HIP_TRY(hipEventRecord(e[0], nullptr));
+    LaunchCaptureRays(nullptr, d_queue, (uint32_t)n, rays, d_scratch7, (uint32_t)n);
+    HIP_TRY(hipEventRecord(e[1], nullptr));
+    HitStream none; none.a = nullptr; none.b = nullptr;
+    LaunchTrace(nullptr, s->dev, anyHit != 0, false, d_queue, nullptr, (uint32_t)n, (uint32_t)n, rays, anyHit ? none : hits, anyHit ? occ.as<uint8_t>() : nullptr, nullptr, s->workCounter.as<uint32_t>());
+    HIP_TRY(hipEventRecord(e[2], nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipEventElapsedTime(&ms[0], e[0], e[1])); HIP_TRY(hipEventElapsedTime(&ms[1], e[1], e[2]));
+    for (auto &x : e) (void)hipEventDestroy(x);
+    return HPRT_OK;
+} catch (...) { return hprt::HandleException(); }
 __attribute__((visibility("default"))) long long hprt_debug_captured(HprtScene *s) { return s ? (long long)s->capture.n : -1; }
 // Measurement hook (not part of include/hprt.h): HBM stream bandwidth of this box, a float4 copy of `bytes` bytes (src and dst far
 // larger than the 256 MB Infinity Cache), timed with HIP events over `iters` launches after one warm-up; GB/s count read + write.
@@ -785,7 +813,7 @@ int hprt_scene_create_from_model(const HprtModel *m, const HprtBvh *b, int devic
         const MaterialDesc &s = sm.materials[i];
         mats[i].type = s.type; memcpy(mats[i].Kd, s.Kd, 12); mats[i].sigma = s.sigma; memcpy(mats[i].Ks, s.Ks, 12);
         mats[i].roughness = s.roughness; mats[i].remap_roughness = s.remapRoughness;
-        mats[i].kd_texture = s.KdTex; mats[i].ks_texture = s.KsTex;
+        mats[i].kd_texture = s.KdTex; mats[i].ks_texture = s.KsTex; mats[i].opacity_texture = s.opacityTex;
         memcpy(mats[i].Kr, s.Kr, 12); memcpy(mats[i].Kt, s.Kt, 12); memcpy(mats[i].opacity, s.opacity, 12); mats[i].eta = s.eta;
     }
     std::vector<std::vector<HprtTextureLevel>> texLevels(sm.textures.size());

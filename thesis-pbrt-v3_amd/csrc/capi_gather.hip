@@ -196,6 +196,7 @@ int hprt_film_gather(HprtComm *c, HprtScene *s, float *d_film_xyzw, size_t n_pix
     return ApplyRecords(rec, film, n_pixels, c->staging, c->destBegin, st);
 } catch (...) { return hprt::HandleException(); }
 
+extern "C++" {
 namespace {
 // hprt_film_gather_local's communicators: one clique per device list, created on first use.  The map is never destroyed by
 // the C++ runtime (static destruction may run after the HIP runtime is gone, and a DevBuf's hipFree or ncclCommDestroy would
@@ -211,6 +212,7 @@ struct Clique {
 std::mutex &CliqueMutex() { static std::mutex *m = new std::mutex(); return *m; }
 std::map<std::vector<int>, std::unique_ptr<Clique>> &Cliques() { static auto *m = new std::map<std::vector<int>, std::unique_ptr<Clique>>(); return *m; }
 }  // namespace
+}  // extern "C++"
 
 int hprt_film_gather_local(HprtScene *const *per_gpu, float *const *d_films, int n, size_t n_pixels, int root) try {
     if (!per_gpu || n < 1 || root < 0 || root >= n) return SetError(HPRT_E_INVALID, "hprt_film_gather_local: bad argument");

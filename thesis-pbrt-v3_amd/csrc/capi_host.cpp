@@ -66,6 +66,12 @@ int hprt_model_save(const HprtModel *m, const char *baked_path) try {
     if (!SaveBakedScene(m->sc, baked_path, &err)) return SetError(HPRT_E_IO, err);
     return HPRT_OK;
 } catch (...) { return hprt::HandleException(); }
+int hprt_model_save_compact(const HprtModel *m, const char *baked_path) try {
+    if (!m || !baked_path) return SetError(HPRT_E_INVALID, "hprt_model_save_compact: null argument");
+    std::string err;
+    if (!SaveBakedScene(m->sc, baked_path, &err, true)) return SetError(HPRT_E_IO, err);
+    return HPRT_OK;
+} catch (...) { return hprt::HandleException(); }
 void hprt_model_destroy(HprtModel *m) { delete m; }
 
 int hprt_model_get_options(const HprtModel *m, HprtRenderOptions *o) try {

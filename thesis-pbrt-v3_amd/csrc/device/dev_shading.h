@@ -321,6 +321,7 @@ struct DevBsdf {
     float alphaY;          // Trowbridge-Reitz alpha along v (== alpha for plastic)
     float eta;             // BSDF::eta (1 unless glass)
     float frI, frT;        // FresnelDielectric(frI, frT) of the microfacet lobe: (1.5, 1) for plastic, (1, e) for uber
+    rgb op;                    // kind 5: the clamped opacity at this vertex (a constant or its image texture, materials/uber.cpp:53)
     const DevMaterial *uber;   // kind 5 (UberMaterial): the material, for the specular lobes only Sample_f(BSDF_ALL) can pick (kr, kt, 1 - opacity)
     int kind;              // 0: the lobes above; 4 (with hasR): ONE FresnelSpecular lobe (glass: Rr = R, Rd = T, eta); 2: ONE FresnelBlend lobe (substrate: Rd, Rs, alpha, alphaY); 3: ONE conductor
                            // microfacet lobe (metal: Rd = eta, Rs = k, R = 1).  Kinds 2 and 3 are flagged hasS (a glossy reflection lobe)
@@ -599,8 +600,9 @@ __device__ __noinline__ rgb eval_image_texture(const DevScene &sc, int texId, co
 }
 
 // kdOverride / ksOverride: evaluated image textures of the material's Kd / Ks (null: the constants)
+// opOverride: the evaluated image texture of an uber material's opacity
 __device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, DevBsdf *b, const rgb *kdOverride = nullptr,
-                                          const rgb *ksOverride = nullptr) {
+                                          const rgb *ksOverride = nullptr, const rgb *opOverride = nullptr) {
     b->ns = si.ns; b->ng = si.n;
     b->ss = normalize(si.sdpdu);
     b->ts = cross(b->ns, b->ss);
@@ -610,9 +612,9 @@ __device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, D
     b->alphaY = 0; b->kind = 0; b->eta = 1.f; b->frI = 1.5f; b->frT = 1.f; b->uber = nullptr;
     if (m.type == 6) {      // UberMaterial, materials/uber.cpp:45-108: Lambertian + microfacet (FresnelDielectric(1, e)) as the plastic pair, and up to
                             // three specular lobes (1 - opacity straight through, Kr, Kt) that only the next-segment sampling sees (bsdf_sample all = true)
-        const rgb op = clamp0(rgb(m.opacity[0], m.opacity[1], m.opacity[2]));
+        const rgb op = clamp0(opOverride ? *opOverride : rgb(m.opacity[0], m.opacity[1], m.opacity[2]));
         const rgb t = clamp0(-op + rgb(1.f));
-        b->kind = 5; b->uber = &sc.materials[sc.shapes[si.shape].material];
+        b->kind = 5; b->uber = &sc.materials[sc.shapes[si.shape].material]; b->op = op;
         b->eta = is_black(t) ? m.eta : 1.f;
         const rgb kd = op * clamp0(kdOverride ? *kdOverride : rgb(m.Kd[0], m.Kd[1], m.Kd[2]));
         if (!is_black(kd)) { b->hasD = true; b->Rd = kd; }
@@ -687,7 +689,7 @@ __device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW
     rgb uT0(0.f), uKr(0.f), uKt(0.f);
     if (all && b.kind == 5) {
         const DevMaterial &m = *b.uber;
-        const rgb op = clamp0(rgb(m.opacity[0], m.opacity[1], m.opacity[2]));
+        const rgb op = b.op;
         uT0 = clamp0(-op + rgb(1.f));
         uKr = op * clamp0(rgb(m.Kr[0], m.Kr[1], m.Kr[2])); uKt = op * clamp0(rgb(m.Kt[0], m.Kt[1], m.Kt[2]));
         nBefore = is_black(uT0) ? 0 : 1;

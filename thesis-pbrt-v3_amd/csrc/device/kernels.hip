@@ -852,11 +852,12 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
             spFull = true;
 #endif
             DevBsdf bsdf;
-            bool useKd = false, useKs = false;
-            rgb kdTex, ksTex;
+            bool useKd = false, useKs = false, useOp = false;
+            rgb kdTex, ksTex, opTex;
             if (texScene) {
                 const DevMaterial m = sc.materials[sc.shapes[si.shape].material];
-                if (m.KdTex >= 0 || m.KsTex >= 0) {
+                const int opTexId = m.type == 6 ? m.opTex : -1;
+                if (m.KdTex >= 0 || m.KsTex >= 0 || opTexId >= 0) {
                     // SurfaceInteraction::ComputeDifferentials (core/interaction.cpp:103-149): only the camera ray carries
                     // differentials (RayDifferential(const Ray &) clears them for every spawned ray, core/geometry.h:1213-1216)
                     DevUvDiff uvd; uvd.dudx = uvd.dvdx = uvd.dudy = uvd.dvdy = 0.f;
@@ -875,9 +876,10 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
                     }
                     if (m.KdTex >= 0) { kdTex = eval_image_texture(sc, m.KdTex, tg, uvd); useKd = true; }
                     if (m.KsTex >= 0) { ksTex = eval_image_texture(sc, m.KsTex, tg, uvd); useKs = true; }
+                    if (opTexId >= 0) { opTex = eval_image_texture(sc, opTexId, tg, uvd); useOp = true; }
                 }
             }
-            bsdf_init(sc, si, &bsdf, useKd ? &kdTex : nullptr, useKs ? &ksTex : nullptr);
+            bsdf_init(sc, si, &bsdf, useKd ? &kdTex : nullptr, useKs ? &ksTex : nullptr, useOp ? &opTex : nullptr);
             if (MODE == 0) { bsdf.hasS = false; bsdf.Rs = rgb(0.f); bsdf.alpha = 0.f; }   // matte: no microfacet lobe (matte.cpp:45-62)
             if (MODE != 2) { bsdf.hasR = false; bsdf.oren = false; bsdf.kind = 0; }      // mirror, substrate, metal and OrenNayar surfaces are shaded by the generic variant
             SP_MARK(1);      // textures + bsdf_init

@@ -276,7 +276,7 @@ struct Frontend {
         }
         MaterialDesc m;
         memset(&m, 0, sizeof(m));
-        m.KdTex = m.KsTex = -1;
+        m.KdTex = m.KsTex = m.opacityTex = -1;
         if (name == "plastic") {
             const float dk[3] = {0.25f, 0.25f, 0.25f};
             m.type = kPlastic;
@@ -332,7 +332,7 @@ struct Frontend {
             spectrumParam(geom, *mp, "Ks", q, m.Ks, &m.KsTex);
             spectrumParam(geom, *mp, "Kr", zero, m.Kr);
             spectrumParam(geom, *mp, "Kt", zero, m.Kt);
-            spectrumParam(geom, *mp, "opacity", one, m.opacity);
+            spectrumParam(geom, *mp, "opacity", one, m.opacity, &m.opacityTex);      // (an image texture: the leaves of scenes/livingroom, :30)
             const float rough = floatParam(geom, *mp, "roughness", .1f);
             const bool hasU = mp->find("uroughness", "float") || geom.find("uroughness", "float") || !mp->texture("uroughness").empty() || !geom.texture("uroughness").empty();
             const bool hasV = mp->find("vroughness", "float") || geom.find("vroughness", "float") || !mp->texture("vroughness").empty() || !geom.texture("vroughness").empty();
@@ -711,6 +711,7 @@ struct Frontend {
                             w = h = 1; rgb.assign(3, 0.5f);
                         }
                         BuildMipMap(w, h, rgb, scale, gamma, &td);
+                        KeepTextureSource(w, h, rgb, scale, gamma, true, &td);
                         id = (int)sc->textures.size();
                         sc->textures.push_back(std::move(td));
                         imageCache[key] = id;

@@ -29,7 +29,7 @@ struct In {
 
 }  // namespace
 
-bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *err) {
+bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *err, bool compactTextures) {
     FILE *fp = fopen(path.c_str(), "wb");
     if (!fp) { *err = "cannot create " + path; return false; }
     Out o{fp};
@@ -45,7 +45,14 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
     const bool textured = !sc.textures.empty() || infinite || uber;
     // version 4 = version 3's layout followed by the map index and the transforms of the infinite lights (in light order);
     // version 5 = version 4's followed by Kr, Kt, opacity, eta of the uber materials (in material order)
-    o.raw("HPRTSCN1", 8); o.u32(uber ? 5u : infinite ? 4u : textured ? 3u : instancing ? 2u : 1u);
+    // version 6 = version 5's layout with (a) every texture record led by its FORM — 0: the finished levels as before; 1 / 2: the
+    // image the levels are built from (8-bit or float texels as ReadImage returned them + ImageTexture::GetTexture's conversion
+    // parameters), rebuilt by the product's own MIPMap constructor at load (texture_io.cpp) — and (b) the opacity texture of every
+    // uber material after the uber block.  Written when a compact file is asked for or an uber material has a textured opacity.
+    bool opacityTextured = false;
+    for (const MaterialDesc &m : sc.materials) if (m.type == kUber && m.opacityTex >= 0) opacityTextured = true;
+    const bool v6 = opacityTextured || (compactTextures && !sc.textures.empty());
+    o.raw("HPRTSCN1", 8); o.u32(v6 ? 6u : uber ? 5u : infinite ? 4u : textured ? 3u : instancing ? 2u : 1u);
     o.i32(p.xres); o.i32(p.yres);
     o.raw(p.crop, 16);
     o.raw(p.filterRadius, 8); o.i32(p.filterType);
@@ -79,7 +86,7 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
         }
     }
     for (const LightDesc &l : sc.lights) { o.i32(l.type); o.raw(l.pos, 12); o.raw(l.I, 12); o.i32(l.shape); o.i32(l.twoSided); }
-    if (instancing || textured) {
+    if (instancing || textured || v6) {
         o.u32(sc.nObjects);
         for (const ShapeDesc &s : sc.shapes) o.i32(s.object);
         o.u32((uint32_t)sc.instances.size());
@@ -87,22 +94,32 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
         o.u32((uint32_t)sc.top.size());
         for (const TopItem &t : sc.top) { o.i32(t.kind); o.u32(t.index); }
     }
-    if (textured) {
+    if (textured || v6) {
         for (const MaterialDesc &m : sc.materials) { o.i32(m.KdTex); o.i32(m.KsTex); }
         o.u32((uint32_t)sc.textures.size());
         for (const TextureDesc &t : sc.textures) {
+            const bool asSource = v6 && compactTextures && (!t.src8.empty() || !t.srcF.empty());
+            if (v6) o.i32(asSource ? (t.src8.empty() ? 2 : 1) : 0);
             o.i32(t.trilinear); o.f32(t.maxAniso); o.i32(t.wrap); o.f32(t.su); o.f32(t.sv); o.f32(t.du); o.f32(t.dv);
+            if (asSource) {
+                o.i32(t.srcW); o.i32(t.srcH); o.f32(t.srcScale); o.i32(t.srcGamma); o.i32(t.srcFlipY);
+                if (!t.src8.empty()) o.raw(t.src8.data(), t.src8.size()); else o.raw(t.srcF.data(), 4 * t.srcF.size());
+                continue;
+            }
             o.raw(t.weightLut, sizeof(t.weightLut));
             o.u32((uint32_t)t.levels.size());
             for (const MipLevel &l : t.levels) { o.i32(l.w); o.i32(l.h); o.raw(l.rgb.data(), 4 * l.rgb.size()); }
         }
     }
-    if (infinite || uber)
+    if (infinite || uber || v6)
         for (const LightDesc &l : sc.lights)
             if (l.type == kInfiniteLight) { o.i32(l.texture); o.raw(&l.lightToWorld, 64); o.raw(&l.worldToLight, 64); }
-    if (uber)
+    if (uber || v6)
         for (const MaterialDesc &m : sc.materials)
             if (m.type == kUber) { o.raw(m.Kr, 12); o.raw(m.Kt, 12); o.raw(m.opacity, 12); o.f32(m.eta); }
+    if (v6)
+        for (const MaterialDesc &m : sc.materials)
+            if (m.type == kUber) o.i32(m.opacityTex);
     bool ok = o.ok;
     if (fclose(fp) != 0) ok = false;
     if (!ok) *err = "write error on " + path;
@@ -120,7 +137,7 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
     char magic[8]; in.raw(magic, 8);
     if (!in.ok || memcmp(magic, "HPRTSCN1", 8) != 0) return fail("not a baked hprt scene");
     const uint32_t version = in.u32();
-    if (version < 1 || version > 5) return fail("unsupported version");
+    if (version < 1 || version > 6) return fail("unsupported version");
     RenderOptions &p = sc->opt;
     p.xres = in.i32(); p.yres = in.i32();
     in.raw(p.crop, 16);
@@ -140,7 +157,7 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
     for (MaterialDesc &m : sc->materials) {
         memset(&m, 0, sizeof(m));
         m.type = in.i32(); in.raw(m.Kd, 12); m.sigma = in.f32(); in.raw(m.Ks, 12); m.roughness = in.f32(); m.remapRoughness = in.i32();
-        m.opacity[0] = m.opacity[1] = m.opacity[2] = 1.f; m.eta = 1.5f;
+        m.opacity[0] = m.opacity[1] = m.opacity[2] = 1.f; m.eta = 1.5f; m.opacityTex = -1;
         if (m.type < 0 || m.type > kUber || (m.type == kUber && version < 5)) return fail("material type out of range");
     }
     sc->shapes.resize(nShapes);
@@ -201,7 +218,19 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
         if (!in.ok || nTex > (1u << 20)) return fail("corrupt texture count");
         sc->textures.resize(nTex);
         for (TextureDesc &t : sc->textures) {
+            const int32_t form = version >= 6 ? in.i32() : 0;
             t.trilinear = in.i32(); t.maxAniso = in.f32(); t.wrap = in.i32(); t.su = in.f32(); t.sv = in.f32(); t.du = in.f32(); t.dv = in.f32();
+            if (!in.ok || form < 0 || form > 2 || t.wrap < 0 || t.wrap > 2) return fail("corrupt texture header");
+            if (form != 0) {      // the source image: the levels are rebuilt here, by the constructor that built them at parse time
+                t.srcW = in.i32(); t.srcH = in.i32(); t.srcScale = in.f32(); t.srcGamma = in.i32(); t.srcFlipY = in.i32();
+                if (!in.ok || t.srcW <= 0 || t.srcH <= 0 || t.srcW > 65536 || t.srcH > 65536) return fail("corrupt texture source");
+                const uint64_t nv = 3ull * (uint64_t)t.srcW * (uint64_t)t.srcH;
+                if (!fits(form == 1 ? nv : 4 * nv)) return fail("truncated texture source");
+                if (form == 1) { t.src8.resize(nv); in.raw(t.src8.data(), nv); } else { t.srcF.resize(nv); in.raw(t.srcF.data(), 4 * nv); }
+                if (!in.ok) return fail("truncated texture source");
+                RebuildFromSource(&t);
+                continue;
+            }
             in.raw(t.weightLut, sizeof(t.weightLut));
             const uint32_t nl = in.u32();
             if (!in.ok || nl == 0 || nl > 32 || t.wrap < 0 || t.wrap > 2) return fail("corrupt texture header");
@@ -224,6 +253,12 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
     if (version >= 5)
         for (MaterialDesc &m : sc->materials)
             if (m.type == kUber) { in.raw(m.Kr, 12); in.raw(m.Kt, 12); in.raw(m.opacity, 12); m.eta = in.f32(); }
+    if (version >= 6)
+        for (MaterialDesc &m : sc->materials)
+            if (m.type == kUber) {
+                m.opacityTex = in.i32();
+                if (!in.ok || m.opacityTex < -1 || m.opacityTex >= (int32_t)sc->textures.size()) return fail("opacity texture index out of range");
+            }
     if (!in.ok) return fail("truncated file");
     fclose(fp);
     return true;

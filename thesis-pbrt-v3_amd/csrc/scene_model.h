@@ -23,6 +23,7 @@ struct MaterialDesc {
     int32_t KdTex, KsTex;     // index into SceneModel::textures when the parameter is an image texture, else -1
     // uber (materials/uber.cpp; roughness = uroughness, sigma = vroughness): what the other materials do not have
     float Kr[3], Kt[3], opacity[3], eta;
+    int32_t opacityTex;       // uber: image texture of "opacity" (materials/uber.cpp:53), else -1
 };
 
 // ImageTexture<RGBSpectrum, Spectrum> (textures/imagemap.h) with its finished MIPMap (core/mipmap.h): the pyramid
@@ -34,6 +35,11 @@ struct TextureDesc {
     int32_t trilinear = 0; float maxAniso = 8.f; int32_t wrap = kWrapRepeat;
     float su = 1.f, sv = 1.f, du = 0.f, dv = 0.f;       // UVMapping2D (core/texture.cpp:93-99)
     float weightLut[128];                                // MIPMap::weightLut
+    // What the pyramid was built from (ReadImage's texels, top row first, as 8-bit values when the file held 8-bit channels, and
+    // ImageTexture::GetTexture's conversion parameters): lets the baked container carry the image instead of its float
+    // pyramid (version 6: 3 bytes per source texel instead of 16 per power-of-two texel) and rebuild the levels at load.
+    int32_t srcW = 0, srcH = 0; float srcScale = 1.f; int32_t srcGamma = 0, srcFlipY = 1;
+    std::vector<uint8_t> src8; std::vector<float> srcF;   // one of them: 3 * srcW * srcH values; both empty: no source kept
 };
 
 struct MeshData {             // world space, as TriangleMesh holds it (shapes/triangle.cpp:54-92)
@@ -100,8 +106,12 @@ struct SceneModel {
 // ImageTexture::GetTexture + MIPMap::MIPMap (textures/imagemap.cpp:52-97, core/mipmap.h:113-201)
 bool ReadImageFile(const std::string &path, int *w, int *h, std::vector<float> *rgb, std::string *err);
 void BuildMipMap(int w, int h, const std::vector<float> &rgb, float scale, bool gamma, TextureDesc *tex, bool flipY = true);
+// keeps ReadImage's texels with the texture (as bytes when every value is k / 255.f) so that SaveBakedScene can store them compactly
+void KeepTextureSource(int w, int h, const std::vector<float> &rgb, float scale, bool gamma, bool flipY, TextureDesc *tex);
+// rebuilds the levels of a texture loaded in source form
+void RebuildFromSource(TextureDesc *tex);
 
-bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *err);
+bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *err, bool compactTextures = false);
 bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err);
 // pbrt front-end (pbrt_frontend.cpp): parses the directive subset of SURVEY.md §8(f)-2
 bool ParsePbrtFile(const std::string &path, const std::map<std::string, std::string> &subst, SceneModel *sc,

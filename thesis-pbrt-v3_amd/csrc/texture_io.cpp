@@ -287,4 +287,24 @@ void BuildMipMap(int w, int h, const std::vector<float> &rgbIn, float scale, boo
     }
 }
 
+void KeepTextureSource(int w, int h, const std::vector<float> &rgb, float scale, bool gamma, bool flipY, TextureDesc *tex) {
+    tex->srcW = w; tex->srcH = h; tex->srcScale = scale; tex->srcGamma = gamma ? 1 : 0; tex->srcFlipY = flipY ? 1 : 0;
+    tex->src8.clear(); tex->srcF.clear();
+    bool bytes = true;
+    std::vector<uint8_t> b(rgb.size());
+    for (size_t i = 0; i < rgb.size() && bytes; ++i) {
+        const float k = std::nearbyint(rgb[i] * 255.f);
+        if (!(k >= 0.f && k <= 255.f) || (float)(int)k / 255.f != rgb[i]) bytes = false;      // (the TGA / PNG readers form byte / 255.f)
+        else b[i] = (uint8_t)(int)k;
+    }
+    if (bytes) tex->src8 = std::move(b); else tex->srcF = rgb;
+}
+void RebuildFromSource(TextureDesc *tex) {
+    std::vector<float> rgb;
+    if (!tex->src8.empty()) { rgb.resize(tex->src8.size()); for (size_t i = 0; i < rgb.size(); ++i) rgb[i] = (float)tex->src8[i] / 255.f; }
+    else rgb = tex->srcF;
+    tex->levels.clear();
+    BuildMipMap(tex->srcW, tex->srcH, rgb, tex->srcScale, tex->srcGamma != 0, tex, tex->srcFlipY != 0);
+}
+
 }  // namespace hprt

@@ -88,6 +88,21 @@ def cubecell(d, k):
     return ((ax.astype(np.int64) * 2 + sgn) * k * k + iu * k + iv).astype(np.uint64)
 
 
+lib.hprt_debug_trace_queued.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+
+
+def run_queued(label, r7, order, anyhit, iters=4):
+    """the same rays left in render order, consumed through the sorted index queue: what a device-side INDEX sort would give"""
+    n = r7.shape[1]
+    rays = torch.from_numpy(np.ascontiguousarray(r7)).to(dev); q = torch.from_numpy(order.astype(np.uint32).view(np.int32)).to(dev)
+    scratch = torch.empty(7 * n, dtype=torch.float32, device=dev)
+    ms = (C.c_float * 2)(); best = [1e9, 1e9]
+    for _ in range(iters + 1):
+        hprt._check(lib.hprt_debug_trace_queued(scene._h, n, rays.data_ptr(), q.data_ptr(), 1 if anyhit else 0, scratch.data_ptr(), ms))
+        best = [min(best[0], ms[0]), min(best[1], ms[1])]
+    print("  %-34s n=%9d %8.2f ms %8.1f Mrays/s   (+ permutation pass alone: %.2f ms)" % (label + " [queue]", n, best[1], n / best[1] / 1e3, best[0]), flush=True)
+
+
 rng = np.random.default_rng(1)
 for b in bounces:
     for kind, anyhit, what in ((0, False, "path rays entering bounce %d" % (b + 1)), (1, True, "shadow rays of bounce %d" % b)):
@@ -111,6 +126,9 @@ for b in bounces:
         for kname, key in keys.items():
             order = np.argsort(key, kind="stable")
             v = run(kname, r[:, order], anyhit)
+            if kname in ("morton4", "morton8", "morton6|cube8"):
+                run_queued(kname, r, order, anyhit)
+        run_queued("render order", r, np.arange(n), anyhit)
         # segment-local sort: what a per-chunk (not global) sort would give
         for seg in (1 << 16, 1 << 20):
             key = keys["morton6|oct"]
