@@ -87,8 +87,8 @@ WORKLOADS = {
                "halton %d spp, path maxdepth 5, bvh", 1024, 64, "synthetic (procedural stand-in geometry, tools/scene_gen.py)"),
     "killeroo-simple": ("killeroo-simple (66,532 tris + sphere area light) 700x700, halton %d spp, path maxdepth 5, bvh", 256, 128,
                         "reference asset scenes/killeroo-simple, baked (tests/golden/killeroo_simple.hprt)"),
-    "living-room": ("living room (143,163 tris of the reference's scenes/living-room meshes with its matte / OrenNayar / substrate / metal / mirror / glass / uber materials; textures as constants, point light for its missing sky map) "
-                    "1280x720, halton %d spp, path maxdepth 5, bvh", 2048, 32, "reference meshes, baked (tests/golden/living_room.hprt); BASELINE configs[3]'s class (the conference-room blob is stripped from the reference) at its 2,048 spp"),
+    "living-room": ("living room (143,163 tris of the reference's scenes/living-room meshes with its matte / OrenNayar / substrate / metal / mirror / glass / uber materials and the two image textures it ships — picture8.tga on the painting, leaf.tga on the leaves' Kd and opacity; the two stripped wood maps as constants, point light for its missing sky map) "
+                    "1280x720, halton %d spp, path maxdepth 5, bvh", 2048, 32, "reference meshes, baked (tests/golden/living_room.hprt); BASELINE configs[3]'s class (the conference-room blob is stripped from the reference) at its 2,048 spp; image textures picture8.tga + leaf.tga (Kd and uber opacity) as the scene binds them"),
     # BASELINE configs[4] as SURVEY.md §8(d)-5 defines it: TransformedPrimitive instancing (core/primitive.cpp:77-102, core/api.cpp:1778-1820)
     "instanced-10m": ("10.01 M-triangle instanced scene: the reference's killeroo mesh (33,264 tris, one object definition) x 301 ObjectInstances on a jittered 7x7x7 "
                       "lattice (PCG32 sequence 5), ground quad, distant light; two-level BVH; 700x700, halton %d spp, path maxdepth 5, bvh", 4096, 8,

@@ -337,17 +337,22 @@ def test_sponza_class_interior(hprt, orc, tmp_path):
         assert st[k] == c0[k], k
 
 
-def test_living_room_real_interior(hprt, orc):
+def test_living_room_real_interior(hprt, orc, tmp_path):
     """The reference's only asset-backed interior (scenes/livingroom: 65 PLY meshes, 143,163 triangles with normals and
     uv, BVH depth 26, ~57 nodes per ray), baked by tests/golden/make_fixtures.py with a point light in place of the
     environment light whose map the reference does not ship: BASELINE.json's conference-room class of scene with real
-    geometry.  Film and counters must equal the oracle's; the BVH must equal the oracle's node for node."""
+    geometry — with the two image textures the reference does ship (picture8.tga on the painting, leaf.tga on the leaves' Kd and
+    uber OPACITY, scenes/livingroom:12-13,24,30; the fixture carries the images, the product rebuilds the MIPMaps at load).  Film
+    and counters must equal the oracle's (which reads the pyramids from the expanded form the product saves); the BVH must equal
+    the oracle's node for node."""
     import os
     from conftest import ROOT
     path = os.path.join(ROOT, "tests", "golden", "living_room.hprt")
     model = hprt.Model.load(path)
-    assert model.counts()["triangles"] == 143163
+    assert model.counts()["triangles"] == 143163 and model.counts()["textures"] == 2
     bvh = hprt.Bvh(model)
+    path = str(tmp_path / "living_room_expanded.hprt")
+    model.save(path)
     oracle = orc.OracleScene(path)
     n1, o1 = oracle.bvh_arrays(); n2, o2 = bvh.arrays()
     assert np.array_equal(n1, n2) and np.array_equal(o1, o2) and bvh.info()["max_depth"] == 26
@@ -363,3 +368,6 @@ def test_living_room_real_interior(hprt, orc):
     for k in ("camera_rays", "rays", "shadow_rays", "nodes_fetched", "nodes_fetched_p", "tri_tests", "tri_tests_p"):
         assert st[k] == c0[k], (k, st[k], c0[k])
     assert (film0[..., :3].sum(axis=2) > 0).mean() > 0.9      # a lit room, not a black frame
+    # the textured parts are in view and textured: the painting's pixels are not one flat colour (a crop of the right wall)
+    paint = film0[20:50, 160:180, :3] / film0[20:50, 160:180, 3:4]
+    assert np.unique(np.round(paint, 3).reshape(-1, 3), axis=0).shape[0] > 100

@@ -550,14 +550,20 @@ def test_image_readers_against_an_independent_encoder(hprt, tmp_path):
         assert np.array_equal(back, cases[name]), name
 
 
-def test_living_room_fixture_builds_the_same_bvh_on_both_sides(hprt, orc):
+def test_living_room_fixture_builds_the_same_bvh_on_both_sides(hprt, orc, tmp_path):
     """tests/golden/living_room.hprt (the reference's scenes/livingroom geometry, see ATTRIBUTION.md): the product's
     builder and the oracle's must produce the same 233,709 nodes from its 143,163 triangles."""
     path = os.path.join(GOLDEN, "living_room.hprt")
     model = hprt.Model.load(path)
     c = model.counts()
-    assert (c["triangles"], c["shapes"], c["lights"], c["textures"]) == (143163, 65, 1, 0)
+    assert (c["triangles"], c["shapes"], c["lights"], c["textures"]) == (143163, 65, 1, 2)      # picture8.tga, leaf.tga
     bvh = hprt.Bvh(model)
+    # the fixture is compact (container version 6: the images, not their pyramids); the oracle reads the expanded form
+    assert os.path.getsize(path) < 12 * 2 ** 20
+    path = str(tmp_path / "expanded.hprt"); model.save(path)
+    assert os.path.getsize(path) > 40 * 2 ** 20
+    info0, levels0 = model.texture(0)
+    assert (info0["levels"], levels0[0].shape) == (12, (1024, 2048, 3))      # 1280 x 853 resampled to powers of two (core/mipmap.h:113-150)
     o = orc.OracleScene(path)
     n1, o1 = o.bvh_arrays(); n2, o2 = bvh.arrays()
     assert np.array_equal(n1, n2) and np.array_equal(o1, o2)
