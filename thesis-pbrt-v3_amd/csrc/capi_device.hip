@@ -408,14 +408,18 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
                     // a triangle of an emissive mesh: aux = 1 + its light, and TAG_GENERIC — the generic shading variant is the one that looks for Le
                     const int32_t triLight = sh.area_light >= 0 ? sh.area_light + (int32_t)e.local : -1;
                     if (triLight >= 0) lightPrim[triLight] = (int32_t)i;
-                    uint32_t tag = (bogus ? TAG_BOGUS : 0u) | (md.type == 1 ? TAG_PLASTIC : 0u) | (md.kd_texture >= 0 || md.ks_texture >= 0 || triLight >= 0 || md.type >= 2 || (md.type == 0 && clampf(md.sigma, 0.f, 90.f) != 0.f) ? TAG_GENERIC : 0u);      // (mirror, substrate, metal, OrenNayar: generic variant)
+                    const bool textured = md.kd_texture >= 0 || md.ks_texture >= 0 || (md.type == 6 && md.opacity_texture >= 0);
+                    uint32_t tag = (bogus ? TAG_BOGUS : 0u) | (md.type == 1 ? TAG_PLASTIC : 0u) | (textured || triLight >= 0 || md.type >= 2 || (md.type == 0 && clampf(md.sigma, 0.f, 90.f) != 0.f) ? TAG_GENERIC : 0u) |      // (mirror, substrate, metal, OrenNayar: generic variant)
+                                   (textured ? TAG_TEXTURED : 0u);
                     r0 = make_float4(a[0], a[1], a[2], u2f(tag)); r1 = make_float4(b[0], b[1], b[2], u2f(s)); r2 = make_float4(c[0], c[1], c[2], u2f((uint32_t)(triLight + 1)));
                     for (int k = 0; k < 3; ++k) {
                         primVtx[3 * i + k] = (uint32_t)(vtxBase[s] + (uint32_t)v[k]);
                         if (sh.N) { const float *nn = &sh.N[3 * (size_t)v[k]]; primN[3 * i + k] = make_float4(nn[0], nn[1], nn[2], 0.f); }
                     }
                 } else {
-                    r0 = make_float4(0, 0, 0, u2f(TAG_SPHERE)); r1 = make_float4(0, 0, 0, u2f(s)); r2 = make_float4(0, 0, 0, u2f((uint32_t)sphereOfShape[s]));
+                    const HprtMaterialDesc &md = d->materials[sh.material];
+                    const bool textured = md.kd_texture >= 0 || md.ks_texture >= 0 || (md.type == 6 && md.opacity_texture >= 0);
+                    r0 = make_float4(0, 0, 0, u2f(TAG_SPHERE | (textured ? TAG_TEXTURED : 0u))); r1 = make_float4(0, 0, 0, u2f(s)); r2 = make_float4(0, 0, 0, u2f((uint32_t)sphereOfShape[s]));
                 }
             }
             tris[3 * i] = r0; tris[3 * i + 1] = r1; tris[3 * i + 2] = r2;
@@ -651,6 +655,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     dv.primeMagic = sc->primeMagic.as<uint64_t>();
     dv.worldRadius = worldRadius;
     dv.spatial = 0; dv.voxN[0] = dv.voxN[1] = dv.voxN[2] = 1; dv.voxFunc = dv.voxCdf = dv.voxFuncInt = nullptr;
+    dv.voxSlot = nullptr; dv.voxRequest = nullptr; dv.voxRequestCount = nullptr;
     for (int a = 0; a < 3; ++a) { dv.wbMin[a] = wbLo.get(a); dv.wbMax[a] = wbHi.get(a); }
     if (lightStrategy == 2) {
         // SpatialLightDistribution (core/lightdistrib.cpp:95-120, maxVoxels = 64): the voxel grid over the world bound.  The reference
@@ -661,18 +666,38 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
         const float bmax = diag.get(me);
         uint64_t nVox = 1;
         for (int a = 0; a < 3; ++a) { dv.voxN[a] = std::max(1, int(std::round(diag.get(a) / bmax * 64))); nVox *= (uint64_t)dv.voxN[a]; }
-        const uint64_t tableFloats = nVox * (2ull * d->n_lights + 2ull);
-        if (tableFloats > (1ull << 28))
-            return SetError(HPRT_E_UNSUPPORTED, "spatial light distribution: voxels x lights exceeds the 1 GiB table of this build (use \"uniform\" or \"power\")");
-        HIP_TRY(sc->voxFunc.alloc(nVox * d->n_lights * sizeof(float)));
-        HIP_TRY(sc->voxCdf.alloc(nVox * (d->n_lights + 1ull) * sizeof(float)));
-        HIP_TRY(sc->voxFuncInt.alloc(nVox * sizeof(float)));
+        // The table of every voxel (2 * nLights + 2 floats each) is computed now when it is small: a lookup is then a plain read.  With
+        // many lights (every triangle of an emissive mesh is one, core/api.cpp:1609-1636) it is not — 64^3 voxels x 500 lights is
+        // already 1 GiB — and the reference never builds it either: it fills a voxel when a vertex first falls into it
+        // (core/lightdistrib.cpp:149-229).  Same here then, per batch: a bounded pool of rows, a voxel -> row map, and the
+        // bounce loop computes the rows its vertices asked for (RunBatch).  HPRT_VOXEL_DENSE_MAX_MB moves the switch (tests: 0).
+        const uint64_t denseMaxFloats = [] { const char *e = getenv("HPRT_VOXEL_DENSE_MAX_MB"); return e ? (uint64_t)atoll(e) * (1ull << 18) : (1ull << 28); }();      // (read per scene: tests switch it)
+        const uint64_t rowFloats = 2ull * d->n_lights + 2ull;
+        const bool dense = nVox * rowFloats <= denseMaxFloats;
+        uint64_t rows = nVox;
+        if (!dense) {
+            // pool: up to 4 GiB of rows (HPRT_VOXEL_POOL_MB), never more than there are voxels, at least one
+            const uint64_t poolFloats = [] { const char *e = getenv("HPRT_VOXEL_POOL_MB"); return (e ? (uint64_t)atoll(e) : 4096ull) * (1ull << 18); }();
+            rows = std::max<uint64_t>(1, std::min<uint64_t>(nVox, poolFloats / rowFloats));
+        }
+        HIP_TRY(sc->voxFunc.alloc(rows * d->n_lights * sizeof(float)));
+        HIP_TRY(sc->voxCdf.alloc(rows * (d->n_lights + 1ull) * sizeof(float)));
+        HIP_TRY(sc->voxFuncInt.alloc(rows * sizeof(float)));
         std::vector<float> ri(5 * 128);
         VoxelSamplePoints(ri.data());
         HIP_TRY(upload(sc->voxRi, ri));
         dv.spatial = 1;
         dv.voxFunc = sc->voxFunc.as<float>(); dv.voxCdf = sc->voxCdf.as<float>(); dv.voxFuncInt = sc->voxFuncInt.as<float>();
-        LaunchVoxelDistributions(nullptr, dv, sc->voxRi.as<float>(), (uint32_t)nVox, sc->voxFunc.as<float>(), sc->voxCdf.as<float>(), sc->voxFuncInt.as<float>());
+        sc->nVoxels = (uint32_t)nVox; sc->voxRows = (uint32_t)rows; sc->voxRowsUsed = 0;
+        if (dense) LaunchVoxelDistributions(nullptr, dv, sc->voxRi.as<float>(), (uint32_t)nVox, sc->voxFunc.as<float>(), sc->voxCdf.as<float>(), sc->voxFuncInt.as<float>());
+        else {
+            HIP_TRY(sc->voxSlot.alloc(nVox * sizeof(int32_t)));
+            HIP_TRY(hipMemset(sc->voxSlot.p, 0xff, nVox * sizeof(int32_t)));      // VOX_EMPTY
+            HIP_TRY(sc->voxRequest.alloc(nVox * sizeof(uint32_t)));
+            HIP_TRY(sc->voxRequestCount.alloc(256));
+            HIP_TRY(hipMemset(sc->voxRequestCount.p, 0, 256));
+            dv.voxSlot = sc->voxSlot.as<int32_t>(); dv.voxRequest = sc->voxRequest.as<uint32_t>(); dv.voxRequestCount = sc->voxRequestCount.as<uint32_t>();
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
@@ -1024,13 +1049,31 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         const QueueSet &cur = q[bounce & 1];
         const PathStream &in = w.path[bounce & 1], &out = w.path[(bounce + 1) & 1];
         HIP_TRY(hipMemsetAsync(cur.nextCount, 0, 256 * sizeof(uint32_t), st));   // the four counters, 64 words apart
-        HIP_TRY(hipMemsetAsync(bins.count, 0, 4 * BIN_STRIDE * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(bins.count, 0, 7 * BIN_STRIDE * sizeof(uint32_t), st));
         LaunchBin(st, s->dev, in, w.hit, activeQ, nullptr, active, active, rp.maxDepth, bounce, bins, w.Lfinal);
-        HIP_TRY(hipMemcpyAsync(bins.count + 3 * BIN_STRIDE, bins.count + 2 * BIN_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));   // bin 2 before deferrals
+        HIP_TRY(hipMemcpyAsync(bins.count + 4 * BIN_STRIDE, bins.count + 2 * BIN_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));   // bin 2 before deferrals
         // one launch per material bin; grids are sized for the upper bound, surplus blocks exit on the bin's count
-        for (int mode = 0; mode < 3; ++mode)
+        for (int mode = 0; mode < (s->dev.textures ? 4 : 3); ++mode)      // (bin 3: vertices on image-textured materials, the generic variant with the lookup code)
             LaunchShade(st, mode, s->dev, rp, in, w.hit, active, s0, out, w.vs, cur, bins, w.Lfinal, bounce == 0);
         HIP_TRY(hipMemcpyAsync(s->hostCounts + 4096, cur.nextCount, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (s->dev.voxSlot) {      // on-demand SpatialLightDistribution: vertices whose voxel had no distribution yet wait in the retry lists
+            HIP_TRY(hipMemcpyAsync(s->hostCounts + 16, bins.count + 5 * BIN_STRIDE, 2 * BIN_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(s->hostCounts + 15, s->dev.voxRequestCount, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const uint32_t nRetry[2] = {s->hostCounts[16], s->hostCounts[16 + BIN_STRIDE]}, nReq = s->hostCounts[15];
+            if (nRetry[0] + nRetry[1] > 0) {
+                if ((uint64_t)s->voxRowsUsed + nReq > s->voxRows)
+                    return SetError(HPRT_E_UNSUPPORTED, "spatial light distribution: the paths touch more voxels than the row pool holds (" + std::to_string(s->voxRows) +
+                                                        " rows of " + std::to_string(s->dev.nLights) + " lights; HPRT_VOXEL_POOL_MB raises it, or use \"power\" / \"uniform\")");
+                // SpatialLightDistribution::ComputeDistribution for the voxels just asked for, then the waiting vertices again
+                LaunchVoxelFill(st, s->dev, s->voxRi.as<float>(), nReq, s->voxRowsUsed, s->voxFunc.as<float>(), s->voxCdf.as<float>(), s->voxFuncInt.as<float>());
+                s->voxRowsUsed += nReq;
+                HIP_TRY(hipMemsetAsync(s->dev.voxRequestCount, 0, sizeof(uint32_t), st));
+                for (int r = 0; r < 2; ++r)
+                    if (nRetry[r]) LaunchShade(st, 2 + r, s->dev, rp, in, w.hit, nRetry[r], s0, out, w.vs, cur, bins, w.Lfinal, bounce == 0, true);
+                HIP_TRY(hipMemcpyAsync(s->hostCounts + 4096, cur.nextCount, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            }
+        }
         HIP_TRY(hipStreamSynchronize(st));
         const uint32_t nNext = s->hostCounts[4096], nShadow = s->hostCounts[4096 + 64], nMis = s->hostCounts[4096 + 128], nResolve = s->hostCounts[4096 + 192];
         if (s->capture.out7 && s->capture.bounce == bounce && s0 == 0) {      // diagnostics (hprt_debug_capture_rays)
@@ -1076,7 +1119,7 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
 int EnsureWorkspace(HprtScene *s, size_t nSlots, Workspace *ps, QueueSet *qa, QueueSet *qb, BinSet *bins) {
     HIP_TRY(s->planes.alloc(PlaneBytes(nSlots)));
     CarvePlanes(s->planes.as<char>(), nSlots, ps);
-    HIP_TRY(s->queues.alloc(12 * nSlots * sizeof(uint32_t) + 4096));
+    HIP_TRY(s->queues.alloc(13 * nSlots * sizeof(uint32_t) + 4096));
     HIP_TRY(s->queueCounts.alloc(1024 * sizeof(uint32_t)));
     uint32_t *qbase = s->queues.as<uint32_t>(), *cbase = s->queueCounts.as<uint32_t>();
     QueueSet *qs[2] = {qa, qb};
@@ -1086,9 +1129,14 @@ int EnsureWorkspace(HprtScene *s, size_t nSlots, Workspace *ps, QueueSet *qa, Qu
         // one counter per 256-byte line: atomics of different queues do not serialise on a shared line
         qs[k]->nextCount = cbase + 256 * k; qs[k]->shadowCount = cbase + 256 * k + 64; qs[k]->misCount = cbase + 256 * k + 128; qs[k]->resolveCount = cbase + 256 * k + 192;
     }
-    for (int k = 0; k < 3; ++k) bins->q[k] = qbase + (8 + k) * nSlots;
-    bins->aux = qbase + 11 * nSlots;
+    for (int k = 0; k < 4; ++k) bins->q[k] = qbase + (8 + k) * nSlots;
+    bins->aux = qbase + 12 * nSlots;
     bins->count = cbase + 512;
+    bins->retry[0] = bins->retry[1] = nullptr;
+    if (s->dev.voxSlot) {      // (on-demand voxel tables only)
+        HIP_TRY(s->retryQueues.alloc(2 * nSlots * sizeof(uint2) + 256));
+        bins->retry[0] = s->retryQueues.as<uint2>(); bins->retry[1] = bins->retry[0] + nSlots;
+    }
     return HPRT_OK;
 }
 
@@ -1110,7 +1158,7 @@ int ChooseBatch(HprtScene *s, int32_t sppChunk, uint32_t nPix, uint32_t spp, uin
         size_t freeB = 0, totalB = 0;
         HIP_TRY(hipMemGetInfo(&freeB, &totalB));
         freeB += s->planes.bytes + s->queues.bytes;                 // this scene's previous workspace is reused or released
-        const size_t perPath = kPlaneBytesPerSlot + 12 * sizeof(uint32_t);
+        const size_t perPath = kPlaneBytesPerSlot + 13 * sizeof(uint32_t);
         static const size_t capM = [] { const char *e = getenv("HPRT_BATCH_MPATHS"); return e ? (size_t)atoi(e) : (size_t)256; }();
         const size_t budget = std::min<size_t>(capM << 20, std::max<size_t>(freeB / 2 / perPath, 1ull << 20));
         chunk = std::max<uint32_t>(1u, (uint32_t)(budget / std::max<uint32_t>(nPix, 1u)));

@@ -44,17 +44,19 @@ struct DevPair { float x[4], y[4], z[4]; int32_t ref0, ref1; uint32_t meta, pad;
 enum : uint32_t { PAIR_SINGLE = 4u };
 // The primitive word of a hit record: ordered index (< 2^28) | shading-bin code << 28 (k_bin then needs
 // nothing but this word): HIT_PLASTIC triangle of a plastic material, HIT_GENERIC quadric or hit inside an instance
-enum : uint32_t { HIT_PRIM_MASK = 0x0fffffffu, HIT_PLASTIC = 1u << 28, HIT_GENERIC = 2u << 28 };
+enum : uint32_t { HIT_PRIM_MASK = 0x0fffffffu, HIT_PLASTIC = 1u << 28, HIT_GENERIC = 2u << 28, HIT_TEXTURED = 4u << 28 };      // HIT_TEXTURED: the material has an image texture (bin 3: the generic variant WITH the lookup code)
 __host__ __device__ inline int32_t hit_prim(int32_t word) { return word < 0 ? word : (int32_t)((uint32_t)word & HIT_PRIM_MASK); }
 
 // REF_NONE: nothing left.  REF_EXIT: stack sentinel under an instance's walk — popping it ends the
 // instance (TransformedPrimitive::Intersect returns, core/primitive.cpp:77-93)
 enum : int32_t { REF_NONE = (int32_t)0x80000000, REF_EXIT = (int32_t)0x80000001 };
+enum : int32_t { VOX_EMPTY = -1, VOX_REQUESTED = -2 };
 
 enum : uint32_t { TAG_KIND_MASK = 3u, TAG_SPHERE = 1u, TAG_INSTANCE = 2u, TAG_BOGUS = 4u, TAG_LAST = 8u,
                   TAG_PLASTIC = 16u,     // triangle of a plastic material: the shading bin without chasing shape -> material
-                  TAG_GENERIC = 32u };   // triangle whose material has an image texture: shaded by the generic variant
-// (TAG_PLASTIC | TAG_GENERIC) << 24 are the hit word's HIT_PLASTIC | HIT_GENERIC
+                  TAG_GENERIC = 32u,     // shaded by the generic variant (quadrics, emitters, every material but plain matte / plastic)
+                  TAG_TEXTURED = 64u };  // the material has an image texture: the generic variant compiled with the MIPMap lookups
+// (TAG_PLASTIC | TAG_GENERIC | TAG_TEXTURED) << 24 are the hit word's HIT_PLASTIC | HIT_GENERIC | HIT_TEXTURED
 enum : uint32_t { SHAPE_FLIP = 1u, SHAPE_HAS_N = 2u, SHAPE_HAS_UV = 4u, SHAPE_HAS_S = 8u, SHAPE_REVERSE = 16u };
 
 struct DevShape { int32_t material, areaLight; uint32_t flags; int32_t sphere; };
@@ -93,6 +95,11 @@ struct DevScene {
     // Distribution1D's func[nLights] at voxFunc + v * nLights, cdf[nLights + 1] at voxCdf + v * (nLights + 1), funcInt at voxFuncInt[v]
     int32_t spatial; int32_t voxN[3]; float wbMin[3], wbMax[3];
     const float *voxFunc, *voxCdf, *voxFuncInt;
+    // On-demand mode (the table of EVERY voxel would be too large: many lights): voxSlot[v] = row of voxel v in the tables above, or
+    // VOX_EMPTY / VOX_REQUESTED; a vertex that falls into a voxel without a row asks for it (voxRequest / voxRequestCount) and is
+    // shaded again once the host has had the rows computed — the reference's lazy fill (core/lightdistrib.cpp:149-229), per batch
+    // instead of per thread.  voxSlot == nullptr: every voxel has its row (row = voxel).
+    int32_t *voxSlot; uint32_t *voxRequest; uint32_t *voxRequestCount;
     float worldRadius;                                           // DistantLight::Preprocess
     uint2 *deepStack;                                            // traversal stack entries beyond the LDS ones: [entry][grid thread]
     // Halton tables

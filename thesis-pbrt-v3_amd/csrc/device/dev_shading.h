@@ -1080,10 +1080,22 @@ __device__ __forceinline__ int light_voxel(const DevScene &sc, vec3 p) {
     }
     return (pi[0] * sc.voxN[1] + pi[1]) * sc.voxN[2] + pi[2];
 }
-__device__ __forceinline__ int light_pick(const DevScene &sc, vec3 p, float u, float *pdf) {
+// *miss (on-demand voxel tables only): the vertex's voxel has no distribution yet; it has been requested, and the vertex must be
+// shaded again after the host has had it computed (nothing may be written for it now)
+__device__ __forceinline__ int light_pick(const DevScene &sc, vec3 p, float u, float *pdf, bool *miss) {
+    *miss = false;
     if (sc.spatial) {
-        const int v = light_voxel(sc, p);
+        int v = light_voxel(sc, p);
         const int n = (int)sc.nLights;
+        if (sc.voxSlot) {
+            const int row = sc.voxSlot[v];
+            if (row < 0) {
+                if (row == VOX_EMPTY && atomicCAS(&sc.voxSlot[v], VOX_EMPTY, VOX_REQUESTED) == VOX_EMPTY) sc.voxRequest[atomicAdd(sc.voxRequestCount, 1u)] = (uint32_t)v;
+                *miss = true; *pdf = 0.f;
+                return 0;
+            }
+            v = row;
+        }
         return dist1d_sample_discrete(sc.voxCdf + (size_t)v * (n + 1), sc.voxFunc + (size_t)v * n, sc.voxFuncInt[v], n, u, pdf);
     }
     return dist1d_sample_discrete(sc.lightCdf, sc.lightFunc, sc.lightFuncInt, (int)sc.nLights, u, pdf);

@@ -32,11 +32,14 @@ struct QueueSet {
     uint32_t *next, *shadow, *mis, *resolve;
     uint32_t *nextCount, *shadowCount, *misCount, *resolveCount;
 };
-// material bins: 0 matte, 1 plastic, 2 generic.  count[k * BIN_STRIDE], k = 0..2: sizes; k = 3: size of bin 2 before
-// the specialised variants deferred vertices to it (counters 256 bytes apart: atomics on different bins do not share a
-// line); aux[k] = output index of a deferred entry k.
+// material bins: 0 matte, 1 plastic, 2 generic, 3 generic on an image-textured material (the variant compiled with the MIPMap
+// lookups: scenes with textures only).  count[k * BIN_STRIDE], k = 0..3: sizes; k = 4: size of bin 2 before the specialised
+// variants deferred vertices to it (counters 256 bytes apart: atomics on different bins do not share a line); aux[k] = output
+// index of a deferred entry k of bin 2.  Output indices: bin 0 occupies [0, n0), bin 1 follows, then bin 2 as binned, then bin 3.
 enum : uint32_t { BIN_STRIDE = 64u };
-struct BinSet { uint32_t *q[3]; uint32_t *aux; uint32_t *count; };
+// retry[b - 2], b = 2, 3: {stream index, output index} pairs of vertices whose light-distribution voxel was not there yet
+// (on-demand SpatialLightDistribution): shaded again by bin b's variant after the voxels have been filled; count[(5 + b - 2) * BIN_STRIDE]
+struct BinSet { uint32_t *q[4]; uint32_t *aux; uint32_t *count; uint2 *retry[2]; };
 struct RenderParams {
     DevCamera cam;
     DevHalton hal;
@@ -87,7 +90,7 @@ void LaunchBin(hipStream_t st, const DevScene &sc, const PathStream &in, const H
                float4 *Lfinal);
 void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathStream &in, const HitStream &hit,
                  uint32_t gridItems, uint32_t s0, const PathStream &out, const VertexStreams &vs, const QueueSet &q,
-                 const BinSet &bins, float4 *Lfinal, bool firstBounce);
+                 const BinSet &bins, float4 *Lfinal, bool firstBounce, bool retryPass = false);
 void LaunchResolve(hipStream_t st, const DevScene &sc, const VertexStreams &vs, float4 *L, float4 *Lfinal, const uint32_t *queue,
                    const uint32_t *countPtr, uint32_t gridItems);
 void LaunchStoreRadiance(hipStream_t st, const float4 *Lfinal, float *LallR, float *LallG, float *LallB, uint32_t nPix, uint32_t s0,
@@ -106,6 +109,8 @@ void LaunchFilmForeignExport(hipStream_t st, const RenderParams &rp, const FilmG
                              FilmRecord *out);
 // SpatialLightDistribution for every voxel: ri = RadicalInverse(0..4, i), i < 128, as [5][128] floats on the device
 void LaunchVoxelDistributions(hipStream_t st, const DevScene &sc, const float *ri, uint32_t nVox, float *func, float *cdf, float *funcInt);
+// on-demand mode: the `n` voxels listed in sc.voxRequest get rows rowBase .. rowBase + n - 1 (voxSlot is updated), their distributions are computed
+void LaunchVoxelFill(hipStream_t st, const DevScene &sc, const float *ri, uint32_t n, uint32_t rowBase, float *func, float *cdf, float *funcInt);
 void LaunchStreamCopy(hipStream_t st, const float4 *src, float4 *dst, size_t n);
 // diagnostics: the rays a queue lists, as [7][cap] planes (the layout of the *_device entry points)
 void LaunchCaptureRays(hipStream_t st, const uint32_t *queue, uint32_t n, const RayStream &rays, float *out7, uint32_t cap);

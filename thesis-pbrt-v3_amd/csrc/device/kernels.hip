@@ -488,7 +488,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                                          vec3(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
                                          vec3(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z)), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
                                 if (ANY_HIT) { hit = true; done = true; }
-                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)(pi | ((tag & (TAG_PLASTIC | TAG_GENERIC)) << 24) | (INST && inst >= 0 ? HIT_GENERIC : 0u)); hb0 = b0; hb1 = b1; hb2 = b2; if (INST) { hitInst = inst; instHit = inst >= 0; } }
+                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)(pi | ((tag & (TAG_PLASTIC | TAG_GENERIC | TAG_TEXTURED)) << 24) | (INST && inst >= 0 ? HIT_GENERIC : 0u)); hb0 = b0; hb1 = b1; hb2 = b2; if (INST) { hitInst = inst; instHit = inst >= 0; } }
                             }
                             if (done) cur = REF_NONE;
                             else if (tag & TAG_LAST) cur = pop();
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                                 if (INST && inst >= 0) rr.d = xf_vector(sc.instances[inst].w2i, rr.d);
                                 maybe = sphere_may_hit(sc.spheres[v2.w], rr);
                             }
-                            if (maybe) { wait = 1u; waitInfo = v2.w | ((tag & TAG_LAST) ? 0x80000000u : 0u); }
+                            if (maybe) { wait = 1u; waitInfo = v2.w | ((tag & TAG_LAST) ? 0x80000000u : 0u) | ((tag & TAG_TEXTURED) ? 0x40000000u : 0u); }
                             else { if (COUNT) ++cnt.sphere; if (tag & TAG_LAST) cur = pop(); else --cur; }
                         }
                     }
@@ -556,9 +556,9 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                     DRay robj; vec3 ph; float phi, t;
                     bool done = false;
                     // the cheap exact pre-test (dev_intersect.h) settles most quadrics; the interval arithmetic runs for the rest
-                    if ((HPRT_INLINE_PRETEST || sphere_may_hit(sc.spheres[waitInfo & 0x7fffffffu], rr)) && sphere_test(sc.spheres[waitInfo & 0x7fffffffu], rr, &robj, &ph, &phi, &t)) {
+                    if ((HPRT_INLINE_PRETEST || sphere_may_hit(sc.spheres[waitInfo & 0x3fffffffu], rr)) && sphere_test(sc.spheres[waitInfo & 0x3fffffffu], rr, &robj, &ph, &phi, &t)) {
                         if (ANY_HIT) { hit = true; done = true; }
-                        else { hit = true; rayTMax = t; prim = (int32_t)(pi | HIT_GENERIC); hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; if (INST) { hitInst = inst; instHit = inst >= 0; } }
+                        else { hit = true; rayTMax = t; prim = (int32_t)(pi | HIT_GENERIC | ((waitInfo & 0x40000000u) ? HIT_TEXTURED : 0u)); hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; if (INST) { hitInst = inst; instHit = inst >= 0; } }
                     }
                     if (done) cur = REF_NONE;
                     else if (waitInfo & 0x80000000u) cur = pop();
@@ -659,8 +659,8 @@ __global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, 
 #define HPRT_BIN_ITEMS 4
 __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStream hit, const uint32_t *queue, const uint32_t *countPtr,
                                               uint32_t countImm, int32_t maxDepth, int32_t bounces, BinSet bins, float4 *Lfinal) {
-    __shared__ uint32_t waveCount[3][HPRT_BIN_ITEMS * 16];      // [bin][item round * 16 + wave]
-    __shared__ uint32_t binBase[3];
+    __shared__ uint32_t waveCount[4][HPRT_BIN_ITEMS * 16];      // [bin][item round * 16 + wave]
+    __shared__ uint32_t binBase[4];
     const uint32_t n = countPtr ? *countPtr : countImm;
     const uint32_t first = blockIdx.x * (HPRT_BIN_ITEMS * 1024u);
     if (first >= n) return;      // whole block beyond the queue (grids are sized for the batch)
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
         const uint32_t i = first + k * 1024u + threadIdx.x;
         if (i < n) hitA[k] = hit.a[slot[k]];
     }
-    unsigned long long mask[HPRT_BIN_ITEMS][3];
+    unsigned long long mask[HPRT_BIN_ITEMS][4];
 #pragma unroll
     for (int k = 0; k < HPRT_BIN_ITEMS; ++k) {
         const uint32_t i = first + k * 1024u + threadIdx.x;
@@ -692,8 +692,9 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
                 // object instances (surface interaction transformed back to world space) to the generic one
                 const bool generic = ((uint32_t)word & HIT_GENERIC) != 0u;
                 // at the depth limit only an emitter matters, hit by a camera ray or through a specular bounce (path.cpp:97-110)
-                if (bounces >= maxDepth) { if (generic && (bounces == 0 || (__float_as_uint(in.ray.b[slot[k]].w) >> 31))) bin[k] = 2; }
-                else if (generic) bin[k] = 2;
+                const int gbin = ((uint32_t)word & HIT_TEXTURED) ? 3 : 2;      // (scenes without textures never set the bit)
+                if (bounces >= maxDepth) { if (generic && (bounces == 0 || (__float_as_uint(in.ray.b[slot[k]].w) >> 31))) bin[k] = gbin; }
+                else if (generic) bin[k] = gbin;
                 else bin[k] = ((uint32_t)word & HIT_PLASTIC) ? 1 : 0;
             }
             // an escaped camera or specular segment picks up the infinite lights' radiance (integrators/path.cpp:97-106): the generic variant adds it
@@ -704,14 +705,14 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
             }
         }
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
+        for (int b = 0; b < 4; ++b) {
             mask[k][b] = __ballot(bin[k] == b);
             if (lane == 0) waveCount[b][k * 16 + wave] = (uint32_t)__popcll(mask[k][b]);
         }
     }
     __syncthreads();
     // exclusive scan of the 64 (round, wave) counts of each bin by one wave per bin, then one atomic per bin
-    if (wave < 3) {
+    if (wave < 4) {
         const uint32_t c = waveCount[wave][lane];
         uint32_t incl = c;
 #pragma unroll
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
     for (int k = 0; k < HPRT_BIN_ITEMS; ++k) {
         if (bin[k] < 0) continue;
         const int b = bin[k];
-        const unsigned long long m = b == 0 ? mask[k][0] : b == 1 ? mask[k][1] : mask[k][2];
+        const unsigned long long m = b == 0 ? mask[k][0] : b == 1 ? mask[k][1] : b == 2 ? mask[k][2] : mask[k][3];
         const uint32_t pos = binBase[b] + waveCount[b][k * 16 + wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         bins.q[b][pos] = slot[k];
     }
@@ -754,10 +755,12 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
 #endif
 template <int MODE, int BS, bool TEX = false>
 __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 ? HPRT_SHADE_WAVES_PLASTIC : HPRT_SHADE_WAVES_GENERIC) void k_shade(DevScene sc, RenderParams rp, PathStream in, HitStream hit, uint32_t s0,
-                                               PathStream out, VertexStreams vs, QueueSet q, BinSet bins, float4 *Lfinal, uint32_t firstBounce) {
+                                               PathStream out, VertexStreams vs, QueueSet q, BinSet bins, float4 *Lfinal, uint32_t firstBounce, uint32_t retryPass) {
     __shared__ HaltonLds hl;
     __shared__ BlockAppendLds al;
-    const uint32_t n = bins.count[MODE * BIN_STRIDE];
+    constexpr int BIN = MODE == 2 && TEX ? 3 : MODE;      // the variant with the texture lookups shades bin 3
+    constexpr int RETRY = BIN == 3 ? 1 : 0;               // voxel misses of bins 0-2 are shaded again by the generic variant, bin 3's by its own
+    const uint32_t n = retryPass ? bins.count[(5 + RETRY) * BIN_STRIDE] : bins.count[BIN * BIN_STRIDE];
     if (blockIdx.x * blockDim.x >= n) return;      // whole block beyond the bin (grids are sized for the upper bound)
     halton_lds_load(sc, &hl);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -765,13 +768,16 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
     unsigned long long spT[8] = {0, 0, 0, 0, 0, 0, 0, 0}, spLast = clock64();
     bool spFull = false;
 #endif
-    bool wantNext = false, wantShadow = false, wantMis = false, wantResolve = false, defer = false;
+    bool wantNext = false, wantShadow = false, wantMis = false, wantResolve = false, defer = false, voxelMiss = false;
     uint32_t slot = 0;          // index in the input streams
     uint32_t j = 0;             // index in the output streams
     if (i < n) {
-        slot = bins.q[MODE][i];
-        j = (MODE == 0 ? 0u : MODE == 1 ? bins.count[0] : bins.count[0] + bins.count[BIN_STRIDE]) + i;
-        if (MODE == 2 && i >= bins.count[3 * BIN_STRIDE]) j = bins.aux[i];       // deferred by a specialised variant: keeps that variant's index
+        if (retryPass) { const uint2 e = bins.retry[RETRY][i]; slot = e.x; j = e.y; }
+        else {
+        slot = bins.q[BIN][i];
+        j = (BIN == 0 ? 0u : BIN == 1 ? bins.count[0] : BIN == 2 ? bins.count[0] + bins.count[BIN_STRIDE] : bins.count[0] + bins.count[BIN_STRIDE] + bins.count[4 * BIN_STRIDE]) + i;
+        if (BIN == 2 && i >= bins.count[4 * BIN_STRIDE]) j = bins.aux[i];       // deferred by a specialised variant: keeps that variant's index
+        }
         const float4 rayA = in.ray.a[slot], rayB = in.ray.b[slot], hitA = hit.a[slot];
         // a fresh path's throughput and radiance are constants (k_generate does not store them)
         const float4 beta4 = firstBounce ? make_float4(1.f, 1.f, 1.f, __uint_as_float(slot)) : in.beta[slot];
@@ -890,8 +896,9 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
                 // every pick value selects light 0 with pdf 1, and point / distant lights ignore uLight (lights/point.cpp:44-53,
                 // lights/distant.cpp:49-59) and never reach the BSDF-sampling branch (core/integrator.cpp:168).
                 float pickPdf;
-                const int lightNum = light_pick(sc, si.p, sc.nLights > 1u ? halton_dim(sc, rp.hal, index, dim, &hl) : 0.f, &pickPdf);
+                const int lightNum = light_pick(sc, si.p, sc.nLights > 1u ? halton_dim(sc, rp.hal, index, dim, &hl) : 0.f, &pickPdf, &voxelMiss);
                 dim += 1;
+                if (voxelMiss) defer = true;      // nothing has been written for this vertex: it is shaded again once its voxel is there
                 if (pickPdf != 0) {
                     const DevLight light = sc.lights[lightNum];
                     const bool isDelta = light.type < 2;
@@ -1033,8 +1040,13 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
 #endif
     // queue appends in block-uniform control flow
     if (MODE != 2) {   // (almost) never
-        const uint32_t p2 = wave_append(bins.count + 2 * BIN_STRIDE, defer);
-        if (defer) { bins.q[2][p2] = slot; bins.aux[p2] = j; }
+        const bool toGeneric = defer && !voxelMiss;
+        const uint32_t p2 = wave_append(bins.count + 2 * BIN_STRIDE, toGeneric);
+        if (toGeneric) { bins.q[2][p2] = slot; bins.aux[p2] = j; }
+    }
+    if (sc.voxSlot) {   // (kernel-uniform) on-demand voxel tables: the vertices that missed, for the pass after the fill
+        const uint32_t pr = wave_append(bins.count + (5 + RETRY) * BIN_STRIDE, voxelMiss && !retryPass);
+        if (voxelMiss && !retryPass) bins.retry[RETRY][pr] = make_uint2(slot, j);
     }
     uint32_t *const ctr[4] = {q.nextCount, q.shadowCount, q.misCount, q.resolveCount};
     const bool pred[4] = {wantNext, wantShadow, wantMis, wantResolve};
@@ -1230,11 +1242,13 @@ __global__ __launch_bounds__(64) void k_film_apply_records(const FilmRecord *rec
 // SpatialLightDistribution::ComputeDistribution (core/lightdistrib.cpp:231-298) for EVERY voxel, at scene creation.
 // k_voxel_contrib: one thread per (voxel, light): the 128 Halton points of the voxel (ri: RadicalInverse(0..4, i), [5][128], from the
 // host), each light sampled from each point with the point's (ri[3], ri[4]); lightContrib += Li.y() / pdf in sample order.
-__global__ __launch_bounds__(256) void k_voxel_contrib(DevScene sc, const float *ri, uint32_t nVox, float *contrib) {
+// voxList (on-demand mode): row k of the output belongs to voxel voxList[k]; null: row = voxel
+__global__ __launch_bounds__(256) void k_voxel_contrib(DevScene sc, const float *ri, uint32_t nVox, float *contrib, const uint32_t *voxList) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = sc.nLights;
     if (g >= (size_t)nVox * n) return;
-    const uint32_t v = (uint32_t)(g / n), j = (uint32_t)(g % n);
+    const uint32_t row = (uint32_t)(g / n), j = (uint32_t)(g % n);
+    const uint32_t v = voxList ? voxList[row] : row;
     int pi[3]; pi[2] = (int)(v % (uint32_t)sc.voxN[2]); pi[1] = (int)((v / (uint32_t)sc.voxN[2]) % (uint32_t)sc.voxN[1]); pi[0] = (int)(v / ((uint32_t)sc.voxN[2] * (uint32_t)sc.voxN[1]));
     float vMin[3], vMax[3];
 #pragma unroll
@@ -1355,7 +1369,7 @@ void LaunchBin(hipStream_t st, const DevScene &sc, const PathStream &in, const H
 }
 void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParams &rp, const PathStream &in, const HitStream &hit,
                  uint32_t gridItems, uint32_t s0, const PathStream &out, const VertexStreams &vs, const QueueSet &q,
-                 const BinSet &bins, float4 *Lfinal, bool firstBounce) {
+                 const BinSet &bins, float4 *Lfinal, bool firstBounce, bool retryPass) {
     if (gridItems == 0) return;
     // workgroup size of the specialised variants (HPRT_SHADE_BLOCK = 1024 | 512 | 256); measured on
     // killeroo-simple: 512 is 3 % faster per frame than 1024 (two decoupled workgroups per CU instead of
@@ -1365,11 +1379,12 @@ void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParam
         const std::string v = e ? e : "512";
         return v == "1024" ? 0 : v == "256" ? 2 : 1;
     }();
-    const uint32_t bs = mode == 2 ? 256u : (shadeCfg == 0 ? 1024u : shadeCfg == 1 ? 512u : 256u);
+    const uint32_t bs = mode >= 2 ? 256u : (shadeCfg == 0 ? 1024u : shadeCfg == 1 ? 512u : 256u);
     dim3 grid(blocks_for(gridItems, bs)), block(bs);
-#define HPRT_SHADE_LAUNCH(M, B) hipLaunchKernelGGL((k_shade<M, B>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal, firstBounce ? 1u : 0u)
+#define HPRT_SHADE_LAUNCH(M, B) hipLaunchKernelGGL((k_shade<M, B>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal, firstBounce ? 1u : 0u, retryPass ? 1u : 0u)
 #define HPRT_SHADE_PICK(M) switch (shadeCfg) { case 0: HPRT_SHADE_LAUNCH(M, 1024); break; case 1: HPRT_SHADE_LAUNCH(M, 512); break; default: HPRT_SHADE_LAUNCH(M, 256); break; }
-    if (mode == 2) { if (sc.textures) hipLaunchKernelGGL((k_shade<2, 256, true>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal, firstBounce ? 1u : 0u); else HPRT_SHADE_LAUNCH(2, 256); }
+    if (mode == 3) hipLaunchKernelGGL((k_shade<2, 256, true>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal, firstBounce ? 1u : 0u, retryPass ? 1u : 0u);
+    else if (mode == 2) { HPRT_SHADE_LAUNCH(2, 256); }
     else if (mode == 0) { HPRT_SHADE_PICK(0) }
     else { HPRT_SHADE_PICK(1) }
 #undef HPRT_SHADE_PICK
@@ -1479,8 +1494,19 @@ void LaunchFilmForeign(hipStream_t st, const RenderParams &rp, const FilmGeom &f
 void LaunchVoxelDistributions(hipStream_t st, const DevScene &sc, const float *ri, uint32_t nVox, float *func, float *cdf, float *funcInt) {
     const size_t total = (size_t)nVox * sc.nLights;
     if (!total) return;
-    hipLaunchKernelGGL(k_voxel_contrib, dim3(blocks_for(total, 256)), dim3(256), 0, st, sc, ri, nVox, func);
+    hipLaunchKernelGGL(k_voxel_contrib, dim3(blocks_for(total, 256)), dim3(256), 0, st, sc, ri, nVox, func, (const uint32_t *)nullptr);
     hipLaunchKernelGGL(k_voxel_dist, dim3(blocks_for(nVox, 256)), dim3(256), 0, st, sc.nLights, nVox, func, cdf, funcInt);
+}
+__global__ __launch_bounds__(256) void k_voxel_assign(const uint32_t *voxList, uint32_t n, uint32_t rowBase, int32_t *voxSlot) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) voxSlot[voxList[k]] = (int32_t)(rowBase + k);
+}
+void LaunchVoxelFill(hipStream_t st, const DevScene &sc, const float *ri, uint32_t n, uint32_t rowBase, float *func, float *cdf, float *funcInt) {
+    if (!n) return;
+    const size_t total = (size_t)n * sc.nLights;
+    hipLaunchKernelGGL(k_voxel_contrib, dim3(blocks_for(total, 256)), dim3(256), 0, st, sc, ri, n, func + (size_t)rowBase * sc.nLights, (const uint32_t *)sc.voxRequest);
+    hipLaunchKernelGGL(k_voxel_dist, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc.nLights, n, func + (size_t)rowBase * sc.nLights, cdf + (size_t)rowBase * (sc.nLights + 1), funcInt + rowBase);
+    hipLaunchKernelGGL(k_voxel_assign, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const uint32_t *)sc.voxRequest, n, rowBase, sc.voxSlot);
 }
 void LaunchFilmForeignExport(hipStream_t st, const RenderParams &rp, const FilmGeom &fg, const float *LallR, const float *LallG,
                              const float *LallB, const FilmExtras &ex, uint32_t nGroups, const uint32_t *groupDest, const uint32_t *groupTile,

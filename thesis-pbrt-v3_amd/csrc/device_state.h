@@ -67,6 +67,8 @@ struct HprtScene {
     struct Capture { int bounce = -1, kind = 0; float *out7 = nullptr; size_t cap = 0, n = 0; } capture;
     int poisonByte = -1;      // hprt_debug_poison_workspace (tests): fill every stream, queue and stack with this byte before each render
     hprt::DevBuf voxFunc, voxCdf, voxFuncInt, voxRi;      // SpatialLightDistribution tables (lightsamplestrategy "spatial")
+    hprt::DevBuf voxSlot, voxRequest, voxRequestCount, retryQueues;      // on-demand mode: voxel -> table row, the request list, the vertices to shade again
+    uint32_t voxRows = 0, voxRowsUsed = 0, nVoxels = 0;                   // rows the tables can hold / hold
     hprt::DevBuf rayStats, pixelStatsLocal, pixelStatsFilm; bool pixelStatsValid = false;   // HPRT_RENDER_PIXEL_STATS
     // render-time state
     hprt::DevBuf planes;                                    // backing store of the path streams (Workspace)
