@@ -409,8 +409,12 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
                     const int32_t triLight = sh.area_light >= 0 ? sh.area_light + (int32_t)e.local : -1;
                     if (triLight >= 0) lightPrim[triLight] = (int32_t)i;
                     const bool textured = md.kd_texture >= 0 || md.ks_texture >= 0 || (md.type == 6 && md.opacity_texture >= 0);
-                    uint32_t tag = (bogus ? TAG_BOGUS : 0u) | (md.type == 1 ? TAG_PLASTIC : 0u) | (textured || triLight >= 0 || md.type >= 2 || (md.type == 0 && clampf(md.sigma, 0.f, 90.f) != 0.f) ? TAG_GENERIC : 0u) |      // (mirror, substrate, metal, OrenNayar: generic variant)
-                                   (textured ? TAG_TEXTURED : 0u);
+                    // the shading bin: plain matte / plastic / substrate triangles have kernels of their own; emitters, textured and every other
+                    // material (OrenNayar, mirror, metal, glass, uber) are shaded by the generic variant
+                    const uint32_t bin = textured ? BIN_TEXTURED : triLight >= 0 ? BIN_GENERIC : md.type == 1 ? BIN_PLASTIC : md.type == 3 ? BIN_SUBSTRATE :
+                                         (md.type == 0 && clampf(md.sigma, 0.f, 90.f) == 0.f) ? BIN_MATTE : BIN_GENERIC;
+                    uint32_t tag = (bogus ? TAG_BOGUS : 0u) | (bin << TAG_BIN_SHIFT);
+                    if (bin == BIN_SUBSTRATE) sc->hasSubstrateBin = true;
                     r0 = make_float4(a[0], a[1], a[2], u2f(tag)); r1 = make_float4(b[0], b[1], b[2], u2f(s)); r2 = make_float4(c[0], c[1], c[2], u2f((uint32_t)(triLight + 1)));
                     for (int k = 0; k < 3; ++k) {
                         primVtx[3 * i + k] = (uint32_t)(vtxBase[s] + (uint32_t)v[k]);
@@ -419,7 +423,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
                 } else {
                     const HprtMaterialDesc &md = d->materials[sh.material];
                     const bool textured = md.kd_texture >= 0 || md.ks_texture >= 0 || (md.type == 6 && md.opacity_texture >= 0);
-                    r0 = make_float4(0, 0, 0, u2f(TAG_SPHERE | (textured ? TAG_TEXTURED : 0u))); r1 = make_float4(0, 0, 0, u2f(s)); r2 = make_float4(0, 0, 0, u2f((uint32_t)sphereOfShape[s]));
+                    r0 = make_float4(0, 0, 0, u2f(TAG_SPHERE | ((textured ? BIN_TEXTURED : BIN_GENERIC) << TAG_BIN_SHIFT))); r1 = make_float4(0, 0, 0, u2f(s)); r2 = make_float4(0, 0, 0, u2f((uint32_t)sphereOfShape[s]));
                 }
             }
             tris[3 * i] = r0; tris[3 * i + 1] = r1; tris[3 * i + 2] = r2;
@@ -1049,15 +1053,20 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
         const QueueSet &cur = q[bounce & 1];
         const PathStream &in = w.path[bounce & 1], &out = w.path[(bounce + 1) & 1];
         HIP_TRY(hipMemsetAsync(cur.nextCount, 0, 256 * sizeof(uint32_t), st));   // the four counters, 64 words apart
-        HIP_TRY(hipMemsetAsync(bins.count, 0, 7 * BIN_STRIDE * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(bins.count, 0, 8 * BIN_STRIDE * sizeof(uint32_t), st));
         LaunchBin(st, s->dev, in, w.hit, activeQ, nullptr, active, active, rp.maxDepth, bounce, bins, w.Lfinal);
-        HIP_TRY(hipMemcpyAsync(bins.count + 4 * BIN_STRIDE, bins.count + 2 * BIN_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));   // bin 2 before deferrals
+        HIP_TRY(hipMemcpyAsync(bins.count + 5 * BIN_STRIDE, bins.count + 2 * BIN_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));   // bin 2 before deferrals
         // one launch per material bin; grids are sized for the upper bound, surplus blocks exit on the bin's count
-        for (int mode = 0; mode < (s->dev.textures ? 4 : 3); ++mode)      // (bin 3: vertices on image-textured materials, the generic variant with the lookup code)
+        // (the specialised variants first: they may hand vertices over to the generic one; bin 3: vertices on image-textured materials)
+        static const int order[5] = {BIN_MATTE, BIN_PLASTIC, BIN_SUBSTRATE, BIN_GENERIC, BIN_TEXTURED};
+        for (int k = 0; k < (s->dev.textures ? 5 : 4); ++k) {
+            const int mode = order[k];
+            if (mode == (int)BIN_SUBSTRATE && !s->hasSubstrateBin) continue;
             LaunchShade(st, mode, s->dev, rp, in, w.hit, active, s0, out, w.vs, cur, bins, w.Lfinal, bounce == 0);
+        }
         HIP_TRY(hipMemcpyAsync(s->hostCounts + 4096, cur.nextCount, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         if (s->dev.voxSlot) {      // on-demand SpatialLightDistribution: vertices whose voxel had no distribution yet wait in the retry lists
-            HIP_TRY(hipMemcpyAsync(s->hostCounts + 16, bins.count + 5 * BIN_STRIDE, 2 * BIN_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(s->hostCounts + 16, bins.count + 6 * BIN_STRIDE, 2 * BIN_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(s->hostCounts + 15, s->dev.voxRequestCount, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             const uint32_t nRetry[2] = {s->hostCounts[16], s->hostCounts[16 + BIN_STRIDE]}, nReq = s->hostCounts[15];
@@ -1119,8 +1128,8 @@ int RunBatch(HprtScene *s, hipStream_t st, const RenderParams &rp, const Workspa
 int EnsureWorkspace(HprtScene *s, size_t nSlots, Workspace *ps, QueueSet *qa, QueueSet *qb, BinSet *bins) {
     HIP_TRY(s->planes.alloc(PlaneBytes(nSlots)));
     CarvePlanes(s->planes.as<char>(), nSlots, ps);
-    HIP_TRY(s->queues.alloc(13 * nSlots * sizeof(uint32_t) + 4096));
-    HIP_TRY(s->queueCounts.alloc(1024 * sizeof(uint32_t)));
+    HIP_TRY(s->queues.alloc(14 * nSlots * sizeof(uint32_t) + 4096));
+    HIP_TRY(s->queueCounts.alloc(2048 * sizeof(uint32_t)));
     uint32_t *qbase = s->queues.as<uint32_t>(), *cbase = s->queueCounts.as<uint32_t>();
     QueueSet *qs[2] = {qa, qb};
     for (int k = 0; k < 2; ++k) {
@@ -1129,8 +1138,8 @@ int EnsureWorkspace(HprtScene *s, size_t nSlots, Workspace *ps, QueueSet *qa, Qu
         // one counter per 256-byte line: atomics of different queues do not serialise on a shared line
         qs[k]->nextCount = cbase + 256 * k; qs[k]->shadowCount = cbase + 256 * k + 64; qs[k]->misCount = cbase + 256 * k + 128; qs[k]->resolveCount = cbase + 256 * k + 192;
     }
-    for (int k = 0; k < 4; ++k) bins->q[k] = qbase + (8 + k) * nSlots;
-    bins->aux = qbase + 12 * nSlots;
+    for (int k = 0; k < (int)N_BINS; ++k) bins->q[k] = qbase + (8 + k) * nSlots;
+    bins->aux = qbase + 13 * nSlots;
     bins->count = cbase + 512;
     bins->retry[0] = bins->retry[1] = nullptr;
     if (s->dev.voxSlot) {      // (on-demand voxel tables only)
@@ -1158,7 +1167,7 @@ int ChooseBatch(HprtScene *s, int32_t sppChunk, uint32_t nPix, uint32_t spp, uin
         size_t freeB = 0, totalB = 0;
         HIP_TRY(hipMemGetInfo(&freeB, &totalB));
         freeB += s->planes.bytes + s->queues.bytes;                 // this scene's previous workspace is reused or released
-        const size_t perPath = kPlaneBytesPerSlot + 13 * sizeof(uint32_t);
+        const size_t perPath = kPlaneBytesPerSlot + 14 * sizeof(uint32_t);
         static const size_t capM = [] { const char *e = getenv("HPRT_BATCH_MPATHS"); return e ? (size_t)atoi(e) : (size_t)256; }();
         const size_t budget = std::min<size_t>(capM << 20, std::max<size_t>(freeB / 2 / perPath, 1ull << 20));
         chunk = std::max<uint32_t>(1u, (uint32_t)(budget / std::max<uint32_t>(nPix, 1u)));

@@ -44,7 +44,11 @@ struct DevPair { float x[4], y[4], z[4]; int32_t ref0, ref1; uint32_t meta, pad;
 enum : uint32_t { PAIR_SINGLE = 4u };
 // The primitive word of a hit record: ordered index (< 2^28) | shading-bin code << 28 (k_bin then needs
 // nothing but this word): HIT_PLASTIC triangle of a plastic material, HIT_GENERIC quadric or hit inside an instance
-enum : uint32_t { HIT_PRIM_MASK = 0x0fffffffu, HIT_PLASTIC = 1u << 28, HIT_GENERIC = 2u << 28, HIT_TEXTURED = 4u << 28 };      // HIT_TEXTURED: the material has an image texture (bin 3: the generic variant WITH the lookup code)
+// Shading bins (k_bin -> k_shade variants): matte and plastic and substrate triangles reached directly have variants of their own;
+// everything else (quadrics, emitters, hits inside instances, the other materials) goes to the generic variant — the one compiled
+// with the MIPMap lookups when the material has an image texture.
+enum : uint32_t { BIN_MATTE = 0u, BIN_PLASTIC = 1u, BIN_GENERIC = 2u, BIN_TEXTURED = 3u, BIN_SUBSTRATE = 4u, N_BINS = 5u };
+enum : uint32_t { HIT_PRIM_MASK = 0x0fffffffu, HIT_BIN_SHIFT = 28u };      // bits 28-30 of a hit's primitive word: its bin (bit 31 stays the sign: -1 = miss)
 __host__ __device__ inline int32_t hit_prim(int32_t word) { return word < 0 ? word : (int32_t)((uint32_t)word & HIT_PRIM_MASK); }
 
 // REF_NONE: nothing left.  REF_EXIT: stack sentinel under an instance's walk — popping it ends the
@@ -53,10 +57,8 @@ enum : int32_t { REF_NONE = (int32_t)0x80000000, REF_EXIT = (int32_t)0x80000001 
 enum : int32_t { VOX_EMPTY = -1, VOX_REQUESTED = -2 };
 
 enum : uint32_t { TAG_KIND_MASK = 3u, TAG_SPHERE = 1u, TAG_INSTANCE = 2u, TAG_BOGUS = 4u, TAG_LAST = 8u,
-                  TAG_PLASTIC = 16u,     // triangle of a plastic material: the shading bin without chasing shape -> material
-                  TAG_GENERIC = 32u,     // shaded by the generic variant (quadrics, emitters, every material but plain matte / plastic)
-                  TAG_TEXTURED = 64u };  // the material has an image texture: the generic variant compiled with the MIPMap lookups
-// (TAG_PLASTIC | TAG_GENERIC | TAG_TEXTURED) << 24 are the hit word's HIT_PLASTIC | HIT_GENERIC | HIT_TEXTURED
+                  TAG_BIN_SHIFT = 4u, TAG_BIN_MASK = 7u << 4 };   // bits 4-6: the primitive's shading bin (BIN_*), decided on the host
+// (tag & TAG_BIN_MASK) << 24 is the bin field of the hit word: k_bin needs nothing but that word
 enum : uint32_t { SHAPE_FLIP = 1u, SHAPE_HAS_N = 2u, SHAPE_HAS_UV = 4u, SHAPE_HAS_S = 8u, SHAPE_REVERSE = 16u };
 
 struct DevShape { int32_t material, areaLight; uint32_t flags; int32_t sphere; };

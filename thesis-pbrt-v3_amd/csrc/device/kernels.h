@@ -32,14 +32,15 @@ struct QueueSet {
     uint32_t *next, *shadow, *mis, *resolve;
     uint32_t *nextCount, *shadowCount, *misCount, *resolveCount;
 };
-// material bins: 0 matte, 1 plastic, 2 generic, 3 generic on an image-textured material (the variant compiled with the MIPMap
-// lookups: scenes with textures only).  count[k * BIN_STRIDE], k = 0..3: sizes; k = 4: size of bin 2 before the specialised
-// variants deferred vertices to it (counters 256 bytes apart: atomics on different bins do not share a line); aux[k] = output
-// index of a deferred entry k of bin 2.  Output indices: bin 0 occupies [0, n0), bin 1 follows, then bin 2 as binned, then bin 3.
+// material bins (BIN_*, dev_scene.h): 0 matte, 1 plastic, 2 generic, 3 generic on an image-textured material (the variant compiled
+// with the MIPMap lookups: scenes with textures only), 4 substrate.  count[k * BIN_STRIDE], k = 0..4: sizes; k = 5: size of bin 2
+// before the specialised variants deferred vertices to it (counters 256 bytes apart: atomics on different bins do not share a line);
+// k = 6, 7: the retry lists; aux[k] = output index of a deferred entry k of bin 2.  Output indices: bin 0 occupies [0, n0), then
+// bins 1, 4, 2 (as binned) and 3.
 enum : uint32_t { BIN_STRIDE = 64u };
 // retry[b - 2], b = 2, 3: {stream index, output index} pairs of vertices whose light-distribution voxel was not there yet
-// (on-demand SpatialLightDistribution): shaded again by bin b's variant after the voxels have been filled; count[(5 + b - 2) * BIN_STRIDE]
-struct BinSet { uint32_t *q[4]; uint32_t *aux; uint32_t *count; uint2 *retry[2]; };
+// (on-demand SpatialLightDistribution): shaded again by bin b's variant after the voxels have been filled; count[(6 + b - 2) * BIN_STRIDE]
+struct BinSet { uint32_t *q[5]; uint32_t *aux; uint32_t *count; uint2 *retry[2]; };
 struct RenderParams {
     DevCamera cam;
     DevHalton hal;

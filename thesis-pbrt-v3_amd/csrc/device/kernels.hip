@@ -214,8 +214,8 @@ __device__ __forceinline__ void slab_test_pair(f32x2 nx, f32x2 fx, f32x2 ny, f32
 __device__ unsigned long long g_traceProf[32];   // [0..15] closest hit, [16..31] any hit
 // HPRT_SHADE_PROF (variant builds only, tools/build_variant.sh): wave clocks between program points of k_shade, per MODE
 #ifdef HPRT_SHADE_PROF
-__device__ unsigned long long g_shadeProf[3 * 8];
-__device__ unsigned long long g_shadeLanes[3 * 8 * 2];      // per MODE and mark: sum of active lanes, number of times reached
+__device__ unsigned long long g_shadeProf[4 * 8];
+__device__ unsigned long long g_shadeLanes[4 * 8 * 2];      // per MODE and mark: sum of active lanes, number of times reached
 #define SP_MARK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); spT[k] += t_ - spLast; spLast = t_; \
                         const unsigned long long m_ = __ballot(1); if (__lane_id() == (uint32_t)(__ffsll((long long)m_) - 1)) { atomicAdd(&g_shadeLanes[(MODE * 8 + k) * 2], (unsigned long long)__popcll(m_)); atomicAdd(&g_shadeLanes[(MODE * 8 + k) * 2 + 1], 1ull); } } while (0)
 #else
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                                          vec3(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
                                          vec3(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z)), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
                                 if (ANY_HIT) { hit = true; done = true; }
-                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)(pi | ((tag & (TAG_PLASTIC | TAG_GENERIC | TAG_TEXTURED)) << 24) | (INST && inst >= 0 ? HIT_GENERIC : 0u)); hb0 = b0; hb1 = b1; hb2 = b2; if (INST) { hitInst = inst; instHit = inst >= 0; } }
+                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)(pi | (((INST && inst >= 0) ? (((tag & TAG_BIN_MASK) >> TAG_BIN_SHIFT) == BIN_TEXTURED ? BIN_TEXTURED : BIN_GENERIC) << TAG_BIN_SHIFT : (tag & TAG_BIN_MASK)) << 24)); hb0 = b0; hb1 = b1; hb2 = b2; if (INST) { hitInst = inst; instHit = inst >= 0; } }
                             }
                             if (done) cur = REF_NONE;
                             else if (tag & TAG_LAST) cur = pop();
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                                 if (INST && inst >= 0) rr.d = xf_vector(sc.instances[inst].w2i, rr.d);
                                 maybe = sphere_may_hit(sc.spheres[v2.w], rr);
                             }
-                            if (maybe) { wait = 1u; waitInfo = v2.w | ((tag & TAG_LAST) ? 0x80000000u : 0u) | ((tag & TAG_TEXTURED) ? 0x40000000u : 0u); }
+                            if (maybe) { wait = 1u; waitInfo = v2.w | ((tag & TAG_LAST) ? 0x80000000u : 0u) | ((tag & TAG_BIN_MASK) == (BIN_TEXTURED << TAG_BIN_SHIFT) ? 0x40000000u : 0u); }
                             else { if (COUNT) ++cnt.sphere; if (tag & TAG_LAST) cur = pop(); else --cur; }
                         }
                     }
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                     // the cheap exact pre-test (dev_intersect.h) settles most quadrics; the interval arithmetic runs for the rest
                     if ((HPRT_INLINE_PRETEST || sphere_may_hit(sc.spheres[waitInfo & 0x3fffffffu], rr)) && sphere_test(sc.spheres[waitInfo & 0x3fffffffu], rr, &robj, &ph, &phi, &t)) {
                         if (ANY_HIT) { hit = true; done = true; }
-                        else { hit = true; rayTMax = t; prim = (int32_t)(pi | HIT_GENERIC | ((waitInfo & 0x40000000u) ? HIT_TEXTURED : 0u)); hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; if (INST) { hitInst = inst; instHit = inst >= 0; } }
+                        else { hit = true; rayTMax = t; prim = (int32_t)(pi | (((waitInfo & 0x40000000u) ? BIN_TEXTURED : BIN_GENERIC) << HIT_BIN_SHIFT)); hb0 = 0.f; hb1 = 0.f; hb2 = 0.f; if (INST) { hitInst = inst; instHit = inst >= 0; } }
                     }
                     if (done) cur = REF_NONE;
                     else if (waitInfo & 0x80000000u) cur = pop();
@@ -659,8 +659,8 @@ __global__ __launch_bounds__(256) void k_generate(DevScene sc, RenderParams rp, 
 #define HPRT_BIN_ITEMS 4
 __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStream hit, const uint32_t *queue, const uint32_t *countPtr,
                                               uint32_t countImm, int32_t maxDepth, int32_t bounces, BinSet bins, float4 *Lfinal) {
-    __shared__ uint32_t waveCount[4][HPRT_BIN_ITEMS * 16];      // [bin][item round * 16 + wave]
-    __shared__ uint32_t binBase[4];
+    __shared__ uint32_t waveCount[N_BINS][HPRT_BIN_ITEMS * 16];      // [bin][item round * 16 + wave]
+    __shared__ uint32_t binBase[N_BINS];
     const uint32_t n = countPtr ? *countPtr : countImm;
     const uint32_t first = blockIdx.x * (HPRT_BIN_ITEMS * 1024u);
     if (first >= n) return;      // whole block beyond the queue (grids are sized for the batch)
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
         const uint32_t i = first + k * 1024u + threadIdx.x;
         if (i < n) hitA[k] = hit.a[slot[k]];
     }
-    unsigned long long mask[HPRT_BIN_ITEMS][4];
+    unsigned long long mask[HPRT_BIN_ITEMS][N_BINS];
 #pragma unroll
     for (int k = 0; k < HPRT_BIN_ITEMS; ++k) {
         const uint32_t i = first + k * 1024u + threadIdx.x;
@@ -690,12 +690,11 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
             if (word >= 0) {
                 // triangles reached directly go to the material-specialised variants; quadrics and hits inside
                 // object instances (surface interaction transformed back to world space) to the generic one
-                const bool generic = ((uint32_t)word & HIT_GENERIC) != 0u;
+                const int code = (int)(((uint32_t)word >> HIT_BIN_SHIFT) & 7u);
+                const bool generic = code == (int)BIN_GENERIC || code == (int)BIN_TEXTURED;
                 // at the depth limit only an emitter matters, hit by a camera ray or through a specular bounce (path.cpp:97-110)
-                const int gbin = ((uint32_t)word & HIT_TEXTURED) ? 3 : 2;      // (scenes without textures never set the bit)
-                if (bounces >= maxDepth) { if (generic && (bounces == 0 || (__float_as_uint(in.ray.b[slot[k]].w) >> 31))) bin[k] = gbin; }
-                else if (generic) bin[k] = gbin;
-                else bin[k] = ((uint32_t)word & HIT_PLASTIC) ? 1 : 0;
+                if (bounces >= maxDepth) { if (generic && (bounces == 0 || (__float_as_uint(in.ray.b[slot[k]].w) >> 31))) bin[k] = code; }
+                else bin[k] = code;
             }
             // an escaped camera or specular segment picks up the infinite lights' radiance (integrators/path.cpp:97-106): the generic variant adds it
             if (word < 0 && sc.nEnvLights != 0u && (bounces == 0 || (__float_as_uint(in.ray.b[slot[k]].w) >> 31))) bin[k] = 2;
@@ -705,14 +704,14 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
             }
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < (int)N_BINS; ++b) {
             mask[k][b] = __ballot(bin[k] == b);
             if (lane == 0) waveCount[b][k * 16 + wave] = (uint32_t)__popcll(mask[k][b]);
         }
     }
     __syncthreads();
     // exclusive scan of the 64 (round, wave) counts of each bin by one wave per bin, then one atomic per bin
-    if (wave < 4) {
+    if (wave < N_BINS) {
         const uint32_t c = waveCount[wave][lane];
         uint32_t incl = c;
 #pragma unroll
@@ -725,7 +724,7 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
     for (int k = 0; k < HPRT_BIN_ITEMS; ++k) {
         if (bin[k] < 0) continue;
         const int b = bin[k];
-        const unsigned long long m = b == 0 ? mask[k][0] : b == 1 ? mask[k][1] : b == 2 ? mask[k][2] : mask[k][3];
+        const unsigned long long m = b == 0 ? mask[k][0] : b == 1 ? mask[k][1] : b == 2 ? mask[k][2] : b == 3 ? mask[k][3] : mask[k][4];
         const uint32_t pos = binBase[b] + waveCount[b][k * 16 + wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         bins.q[b][pos] = slot[k];
     }
@@ -753,14 +752,18 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
 #ifndef HPRT_SHADE_WAVES_GENERIC
 #define HPRT_SHADE_WAVES_GENERIC 3
 #endif
+#ifndef HPRT_SHADE_WAVES_SUBSTRATE
+#define HPRT_SHADE_WAVES_SUBSTRATE 4
+#endif
 template <int MODE, int BS, bool TEX = false>
-__global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 ? HPRT_SHADE_WAVES_PLASTIC : HPRT_SHADE_WAVES_GENERIC) void k_shade(DevScene sc, RenderParams rp, PathStream in, HitStream hit, uint32_t s0,
+__global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 ? HPRT_SHADE_WAVES_PLASTIC : MODE == 3 ? HPRT_SHADE_WAVES_SUBSTRATE : HPRT_SHADE_WAVES_GENERIC) void k_shade(DevScene sc, RenderParams rp, PathStream in, HitStream hit, uint32_t s0,
                                                PathStream out, VertexStreams vs, QueueSet q, BinSet bins, float4 *Lfinal, uint32_t firstBounce, uint32_t retryPass) {
     __shared__ HaltonLds hl;
     __shared__ BlockAppendLds al;
-    constexpr int BIN = MODE == 2 && TEX ? 3 : MODE;      // the variant with the texture lookups shades bin 3
-    constexpr int RETRY = BIN == 3 ? 1 : 0;               // voxel misses of bins 0-2 are shaded again by the generic variant, bin 3's by its own
-    const uint32_t n = retryPass ? bins.count[(5 + RETRY) * BIN_STRIDE] : bins.count[BIN * BIN_STRIDE];
+    // MODE: the code variant — 0 matte, 1 plastic, 3 substrate (FresnelBlend only, materials/substrate.cpp:44-65), 2 generic; BIN: the bin it shades
+    constexpr int BIN = MODE == 2 ? (TEX ? (int)BIN_TEXTURED : (int)BIN_GENERIC) : MODE == 3 ? (int)BIN_SUBSTRATE : MODE;
+    constexpr int RETRY = BIN == (int)BIN_TEXTURED ? 1 : 0;      // voxel misses of the other bins are shaded again by the generic variant, the textured bin's by its own
+    const uint32_t n = retryPass ? bins.count[(6 + RETRY) * BIN_STRIDE] : bins.count[BIN * BIN_STRIDE];
     if (blockIdx.x * blockDim.x >= n) return;      // whole block beyond the bin (grids are sized for the upper bound)
     halton_lds_load(sc, &hl);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -775,8 +778,11 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
         if (retryPass) { const uint2 e = bins.retry[RETRY][i]; slot = e.x; j = e.y; }
         else {
         slot = bins.q[BIN][i];
-        j = (BIN == 0 ? 0u : BIN == 1 ? bins.count[0] : BIN == 2 ? bins.count[0] + bins.count[BIN_STRIDE] : bins.count[0] + bins.count[BIN_STRIDE] + bins.count[4 * BIN_STRIDE]) + i;
-        if (BIN == 2 && i >= bins.count[4 * BIN_STRIDE]) j = bins.aux[i];       // deferred by a specialised variant: keeps that variant's index
+        // output index: bins in the order matte, plastic, substrate, generic (as binned), textured
+        j = (BIN == (int)BIN_MATTE ? 0u : BIN == (int)BIN_PLASTIC ? bins.count[0] : BIN == (int)BIN_SUBSTRATE ? bins.count[0] + bins.count[BIN_STRIDE]
+             : BIN == (int)BIN_GENERIC ? bins.count[0] + bins.count[BIN_STRIDE] + bins.count[4 * BIN_STRIDE]
+             : bins.count[0] + bins.count[BIN_STRIDE] + bins.count[4 * BIN_STRIDE] + bins.count[5 * BIN_STRIDE]) + i;
+        if (BIN == (int)BIN_GENERIC && i >= bins.count[5 * BIN_STRIDE]) j = bins.aux[i];       // deferred by a specialised variant: keeps that variant's index
         }
         const float4 rayA = in.ray.a[slot], rayB = in.ray.b[slot], hitA = hit.a[slot];
         // a fresh path's throughput and radiance are constants (k_generate does not store them)
@@ -887,7 +893,8 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
             }
             bsdf_init(sc, si, &bsdf, useKd ? &kdTex : nullptr, useKs ? &ksTex : nullptr, useOp ? &opTex : nullptr);
             if (MODE == 0) { bsdf.hasS = false; bsdf.Rs = rgb(0.f); bsdf.alpha = 0.f; }   // matte: no microfacet lobe (matte.cpp:45-62)
-            if (MODE != 2) { bsdf.hasR = false; bsdf.oren = false; bsdf.kind = 0; }      // mirror, substrate, metal and OrenNayar surfaces are shaded by the generic variant
+            if (MODE != 2) { bsdf.hasR = false; bsdf.oren = false; bsdf.kind = 0; }      // mirror, metal, glass, uber and OrenNayar surfaces are shaded by the generic variant
+            if (MODE == 3) { bsdf.kind = 2; bsdf.hasD = false; }      // substrate: the one FresnelBlend lobe (bsdf_init set hasS unless both reflectances are black)
             SP_MARK(1);      // textures + bsdf_init
             // ---- direct lighting (UniformSampleOneLight + EstimateDirect) ----
             if (bsdf_num(bsdf) > 0 && sc.nLights > 0) {
@@ -1045,7 +1052,7 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
         if (toGeneric) { bins.q[2][p2] = slot; bins.aux[p2] = j; }
     }
     if (sc.voxSlot) {   // (kernel-uniform) on-demand voxel tables: the vertices that missed, for the pass after the fill
-        const uint32_t pr = wave_append(bins.count + (5 + RETRY) * BIN_STRIDE, voxelMiss && !retryPass);
+        const uint32_t pr = wave_append(bins.count + (6 + RETRY) * BIN_STRIDE, voxelMiss && !retryPass);
         if (voxelMiss && !retryPass) bins.retry[RETRY][pr] = make_uint2(slot, j);
     }
     uint32_t *const ctr[4] = {q.nextCount, q.shadowCount, q.misCount, q.resolveCount};
@@ -1379,13 +1386,15 @@ void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParam
         const std::string v = e ? e : "512";
         return v == "1024" ? 0 : v == "256" ? 2 : 1;
     }();
-    const uint32_t bs = mode >= 2 ? 256u : (shadeCfg == 0 ? 1024u : shadeCfg == 1 ? 512u : 256u);
+    const bool specialised = mode == (int)BIN_MATTE || mode == (int)BIN_PLASTIC || mode == (int)BIN_SUBSTRATE;
+    const uint32_t bs = !specialised ? 256u : (shadeCfg == 0 ? 1024u : shadeCfg == 1 ? 512u : 256u);
     dim3 grid(blocks_for(gridItems, bs)), block(bs);
 #define HPRT_SHADE_LAUNCH(M, B) hipLaunchKernelGGL((k_shade<M, B>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal, firstBounce ? 1u : 0u, retryPass ? 1u : 0u)
 #define HPRT_SHADE_PICK(M) switch (shadeCfg) { case 0: HPRT_SHADE_LAUNCH(M, 1024); break; case 1: HPRT_SHADE_LAUNCH(M, 512); break; default: HPRT_SHADE_LAUNCH(M, 256); break; }
     if (mode == 3) hipLaunchKernelGGL((k_shade<2, 256, true>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal, firstBounce ? 1u : 0u, retryPass ? 1u : 0u);
     else if (mode == 2) { HPRT_SHADE_LAUNCH(2, 256); }
     else if (mode == 0) { HPRT_SHADE_PICK(0) }
+    else if (mode == (int)BIN_SUBSTRATE) { HPRT_SHADE_PICK(3) }
     else { HPRT_SHADE_PICK(1) }
 #undef HPRT_SHADE_PICK
 #undef HPRT_SHADE_LAUNCH

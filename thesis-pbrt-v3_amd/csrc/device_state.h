@@ -84,6 +84,7 @@ struct HprtScene {
     uint32_t *hostCounts = nullptr;                   // pinned
     size_t filmPixels = 0;
     uint32_t nPrims = 0;
+    bool hasSubstrateBin = false;                     // some triangle carries BIN_SUBSTRATE: the substrate shading variant is launched
     ~HprtScene() { if (hostCounts) (void)hipHostFree(hostCounts); if (lastUse) (void)hipEventDestroy(lastUse); }
 };
 
