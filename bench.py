@@ -422,10 +422,10 @@ def main():
                "sample": "%s at %d spp (of the %d spp workload), whole frame, tile loop only" % (name, spp_sample, spp_full),
                "msamples_per_s": round(c["camera_rays"] / sec / 1e6, 3), "seconds": round(sec, 2),
                "mrays_per_s_per_thread": round((c["rays"] + c["shadow_rays"]) / sec / 1e6 / max(1, nt), 4), "host": cpu}
-        if sweep:      # how the port scales on this host: the same frame at 1 spp per thread count, a few seconds each
+        if sweep:      # how the port scales on this host: the same frame per thread count, about a second each (long enough for a cgroup quota to bite)
             out["scaling"] = []
             for t in sweep_threads(cpu):
-                _, _, c1, s1, n1 = oracle.render(spp=1, threads=t)
+                _, _, c1, s1, n1 = oracle.render(spp=max(1, min(16, t // 4)), threads=t)
                 r1 = (c1["rays"] + c1["shadow_rays"]) / s1 / 1e6
                 out["scaling"].append({"threads": int(n1), "mrays_per_s": round(r1, 3), "per_thread": round(r1 / max(1, n1), 4), "seconds": round(s1, 2)})
         return out

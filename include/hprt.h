@@ -145,7 +145,8 @@ typedef struct HprtShapeDesc {       /* one Shape directive (core/api.cpp:1561-1
 typedef struct HprtMaterialDesc {    /* materials/matte.cpp:64-72, materials/plastic.cpp:72-84, materials/mirror.cpp:58-64 */
     int32_t type;                    /* 0 matte (sigma != 0: OrenNayar), 1 plastic, 2 mirror (Kr in Ks), 3 substrate (roughness = uroughness,
                                       * sigma = vroughness; materials/substrate.cpp), 4 metal (Kd = eta, Ks = k, roughness / sigma likewise;
-                                      * materials/metal.cpp), 5 smooth glass (Kd = Kt, Ks = Kr, roughness = eta; materials/glass.cpp), 6 uber (below) */
+                                      * materials/metal.cpp), 5 glass (Kd = Kt, Ks = Kr, roughness = eta; sigma = uroughness and Kr[0] = vroughness — both 0: the smooth FresnelSpecular
+                                      * lobe, else MicrofacetReflection + MicrofacetTransmission; materials/glass.cpp:61-93), 6 uber (below) */
     float Kd[3], sigma, Ks[3], roughness;
     int32_t remap_roughness;
     int32_t kd_texture, ks_texture;  /* index into HprtSceneDesc::textures when Kd / Ks is an image texture, else -1 */

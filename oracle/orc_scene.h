@@ -24,6 +24,7 @@ struct Material {
     // uber (materials/uber.cpp; roughness = uroughness, sigma = vroughness): the lobes the other materials do not have
     Float Kr[3] = {0, 0, 0}, Kt[3] = {0, 0, 0}, opacity[3] = {1, 1, 1}; Float eta = 1.5f;
     int opTex = -1;                   // uber: "opacity" as an ImageTexture (materials/uber.cpp:53)
+    Float glassVRough = 0;            // glass: vroughness (uroughness travels in sigma); both 0: smooth
 };
 // ImageTexture<RGBSpectrum, Spectrum> with its built MIPMap (textures/imagemap.h, core/mipmap.h).  The pyramid is
 // built once by the product's host code (csrc/texture_io.cpp) and travels in the baked scene; lookups are restated here.
@@ -240,6 +241,9 @@ inline bool LoadScene(const char *path, Scene *sc, std::string *err) {
                 m.opTex = r.i32();
                 if (!r.ok || m.opTex < -1 || m.opTex >= (int)sc->textures.size()) { *err = "bad opacity texture index"; return false; }
             }
+    if (version >= 6)        // glass materials: vroughness
+        for (auto &m : sc->materials)
+            if (m.type == MAT_GLASS) m.glassVRough = r.f32();
     if (!r.ok) { *err = "truncated file"; return false; }
     return true;
 }

@@ -501,7 +501,7 @@ inline bool Chi2Test(const Float *frequencies, const Float *expFrequencies, int 
 }
 }  // namespace chi2
 
-// which: 0 Lambertian, 1 TR_VA_0p5, 2 TR_VA_0p3_0p15, 3 TR_VA_0p3 (FresnelBlend).  Returns the number of runs (of 5) whose null
+// which: 0 Lambertian, 1 TR_VA_0p5, 2 TR_VA_0p3_0p15, 3 TR_VA_0p3 (FresnelBlend), 4 / 5 rough dielectric (below).  Returns the number of runs (of 5) whose null
 // hypothesis was rejected; minPval: the smallest p-value met.
 inline int SelfTestBSDFSampling(int which, double *minPval) {
     const int thetaRes = 10, phiRes = 20, sampleCount = 1000000, runs = 5;      // CHI2_* (:20-41)
@@ -515,9 +515,22 @@ inline int SelfTestBSDFSampling(int which, double *minPval) {
     else if (which == 1 || which == 2) {
         b.kind = BXDF_MICROFACET; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.R = Spec(1.f);
         b.dist.alphax = RoughnessToAlpha(which == 1 ? 0.5f : 0.3f); b.dist.alphay = RoughnessToAlpha(which == 1 ? 0.5f : 0.15f);
-    } else {
+    } else if (which == 3) {
         b.kind = BXDF_FRESNEL_BLEND; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.R = Spec(0.5f); b.S = Spec(0.5f);
         b.dist.alphax = RoughnessToAlpha(0.3f); b.dist.alphay = RoughnessToAlpha(0.3f);
+    } else {
+        // (not among the reference's cases: its chi-square METHOD applied to the rough-dielectric lobes it does not test.)  4: MicrofacetTransmission
+        // alone, 5: the pair GlassMaterial builds — MicrofacetReflection(FresnelDielectric(1, 1.5)) + MicrofacetTransmission (materials/glass.cpp:66-93)
+        bsdf.eta = 1.5f;
+        if (which == 5) {
+            b.kind = BXDF_MICROFACET; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.R = Spec(1.f);
+            b.dist.alphax = RoughnessToAlpha(0.3f); b.dist.alphay = RoughnessToAlpha(0.15f); b.frDielectric = true; b.frEtaI = 1.f; b.frEtaT = 1.5f;
+            bsdf.nBxDFs = 2;
+        }
+        BxDF &t = bsdf.bxdfs[which == 5 ? 1 : 0];
+        t = BxDF();
+        t.kind = BXDF_MICROFACET_TRANSMISSION; t.type = BSDF_TRANSMISSION | BSDF_GLOSSY; t.R = Spec(1.f);
+        t.dist.alphax = RoughnessToAlpha(0.3f); t.dist.alphay = RoughnessToAlpha(which == 5 ? 0.15f : 0.3f); t.etaA = 1.f; t.etaB = 1.5f;
     }
     std::vector<Float> frequencies((size_t)thetaRes * phiRes), expFrequencies((size_t)thetaRes * phiRes);
     RNG rng;

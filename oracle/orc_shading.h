@@ -161,7 +161,7 @@ struct TRDist {
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16,
        BSDF_ALL = 31 };
 enum { BXDF_LAMBERT = 0, BXDF_MICROFACET = 1, BXDF_SPECULAR_REFLECTION = 2, BXDF_OREN_NAYAR = 3, BXDF_FRESNEL_BLEND = 4,
-       BXDF_MICROFACET_CONDUCTOR = 5, BXDF_FRESNEL_SPECULAR = 6, BXDF_SPECULAR_TRANSMISSION = 7 };
+       BXDF_MICROFACET_CONDUCTOR = 5, BXDF_FRESNEL_SPECULAR = 6, BXDF_SPECULAR_TRANSMISSION = 7, BXDF_MICROFACET_TRANSMISSION = 8 };
 
 inline Spec SqrtS(const Spec &s) { return Spec(std::sqrt(s.c[0]), std::sqrt(s.c[1]), std::sqrt(s.c[2])); }
 // FrConductor, core/reflection.cpp:70-95
@@ -223,6 +223,21 @@ struct BxDF {
             else { sinAlpha = sinThetaI; tanBeta = sinThetaO / AbsCosTheta(wo); }
             return R * InvPi * (A + B * maxCos * sinAlpha * tanBeta);
         }
+        if (kind == BXDF_MICROFACET_TRANSMISSION) {       // MicrofacetTransmission::f, reflection.cpp:244-266 (R = T; FresnelDielectric(etaA, etaB); TransportMode::Radiance)
+            if (SameHemisphere(wo, wi)) return 0;      // transmission only
+            Float cosThetaO = CosTheta(wo);
+            Float cosThetaI = CosTheta(wi);
+            if (cosThetaI == 0 || cosThetaO == 0) return Spec(0);
+            Float eta = CosTheta(wo) > 0 ? (etaB / etaA) : (etaA / etaB);
+            V3 wh = Normalize(wo + wi * eta);
+            if (wh.z < 0) wh = -wh;
+            Spec F = Spec(FrDielectric(Dot(wo, wh), etaA, etaB));
+            Float sqrtDenom = Dot(wo, wh) + eta * Dot(wi, wh);
+            Float factor = 1 / eta;
+            return (Spec(1.f) - F) * R *
+                   std::abs(dist.D(wh) * dist.G(wo, wi) * eta * eta * AbsDot(wi, wh) * AbsDot(wo, wh) * factor * factor /
+                            (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
+        }
         // reflection.cpp:226-236
         Float cosThetaO = AbsCosTheta(wo), cosThetaI = AbsCosTheta(wi);
         V3 wh = wi + wo;
@@ -242,6 +257,14 @@ struct BxDF {
             V3 wh = Normalize(wo + wi);
             Float pdf_wh = dist.Pdf(wo, wh);
             return .5f * (AbsCosTheta(wi) * InvPi + pdf_wh / (4 * Dot(wo, wh)));
+        }
+        if (kind == BXDF_MICROFACET_TRANSMISSION) {                                              // :437-447
+            if (SameHemisphere(wo, wi)) return 0;
+            Float eta = CosTheta(wo) > 0 ? (etaB / etaA) : (etaA / etaB);
+            V3 wh = Normalize(wo + wi * eta);
+            Float sqrtDenom = Dot(wo, wh) + eta * Dot(wi, wh);
+            Float dwh_dwi = std::abs((eta * eta * Dot(wi, wh)) / (sqrtDenom * sqrtDenom));
+            return dist.Pdf(wo, wh) * dwh_dwi;
         }
         if (!SameHemisphere(wo, wi)) return 0;                                                   // :416-420
         V3 wh = Normalize(wo + wi);
@@ -300,6 +323,14 @@ struct BxDF {
         if (kind == BXDF_LAMBERT || kind == BXDF_OREN_NAYAR) {      // :378-385
             *wi = CosineSampleHemisphere(u);
             if (wo.z < 0) wi->z *= -1;
+            *pdf = Pdf(wo, *wi);
+            return f(wo, *wi);
+        }
+        if (kind == BXDF_MICROFACET_TRANSMISSION) {        // :425-435
+            if (wo.z == 0) return 0.;
+            V3 wh = dist.Sample_wh(wo, u);
+            Float eta = CosTheta(wo) > 0 ? (etaA / etaB) : (etaB / etaA);
+            if (!Refract(wo, wh, eta, wi)) return 0;
             *pdf = Pdf(wo, *wi);
             return f(wo, *wi);
         }
@@ -523,13 +554,31 @@ inline void ComputeScatteringFunctions(const Scene &scene, const Material &m, co
             BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
             b.kind = BXDF_SPECULAR_TRANSMISSION; b.type = BSDF_TRANSMISSION | BSDF_SPECULAR; b.R = kt; b.etaA = 1.f; b.etaB = e;
         }
-    } else if (m.type == MAT_GLASS) {       // materials/glass.cpp:44-65, smooth case with allowMultipleLobes (Kd = Kt, Ks = Kr, roughness = eta)
+    } else if (m.type == MAT_GLASS) {       // materials/glass.cpp:44-95 (Kd = Kt, Ks = Kr, roughness = eta, sigma = uroughness, glassVRough = vroughness)
         bsdf->eta = m.roughness;
+        const Float eta = m.roughness;
+        Float urough = m.sigma, vrough = m.glassVRough;
         Spec R = Ks.Clamp(), T = Kd.Clamp();
         if (R.IsBlack() && T.IsBlack()) return;
-        BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
-        b.kind = BXDF_FRESNEL_SPECULAR; b.type = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
-        b.R = R; b.S = T; b.etaA = 1.f; b.etaB = m.roughness;
+        const bool isSpecular = urough == 0 && vrough == 0;
+        if (isSpecular) {      // (allowMultipleLobes is true for the path integrator: one FresnelSpecular lobe)
+            BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+            b.kind = BXDF_FRESNEL_SPECULAR; b.type = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
+            b.R = R; b.S = T; b.etaA = 1.f; b.etaB = eta;
+        } else {               // rough dielectric: MicrofacetReflection + MicrofacetTransmission over one Trowbridge-Reitz distribution (:66-93)
+            if (m.remap) { urough = RoughnessToAlpha(urough); vrough = RoughnessToAlpha(vrough); }
+            if (!R.IsBlack()) {
+                BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+                b.kind = BXDF_MICROFACET; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.R = R;
+                b.dist.alphax = urough; b.dist.alphay = vrough;
+                b.frDielectric = true; b.frEtaI = 1.f; b.frEtaT = eta;
+            }
+            if (!T.IsBlack()) {
+                BxDF &b = bsdf->bxdfs[bsdf->nBxDFs++];
+                b.kind = BXDF_MICROFACET_TRANSMISSION; b.type = BSDF_TRANSMISSION | BSDF_GLOSSY; b.R = T;
+                b.dist.alphax = urough; b.dist.alphay = vrough; b.etaA = 1.f; b.etaB = eta;
+            }
+        }
     } else if (m.type == MAT_MIRROR) {      // materials/mirror.cpp:44-56 (Kr in Ks)
         Spec R = Ks.Clamp();
         if (!R.IsBlack()) {

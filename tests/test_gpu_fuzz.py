@@ -49,7 +49,12 @@ def _material(rng, textures):
     if kind == "mirror":
         return 'Material "mirror" "color Kr" %s\n' % _rgb(rng, .3, 1)
     if kind == "glass":
-        return 'Material "glass" "float index" [%g] "color Kr" %s "color Kt" %s\n' % (_f(rng, 1.05, 2.2), _rgb(rng, .3, 1), _rgb(rng, .3, 1))
+        rough = ""
+        if rng.random() < .4:      # rough dielectric: MicrofacetReflection + MicrofacetTransmission (materials/glass.cpp:61-93)
+            rough = ' "float uroughness" [%g] "float vroughness" [%g] "bool remaproughness" "%s"' % (
+                _f(rng, .02, .5) if rng.random() < .8 else 0, _f(rng, .02, .5) if rng.random() < .8 else 0, rng.choice(["true", "false"]))
+        return 'Material "glass" "float index" [%g] "color Kr" %s "color Kt" %s%s\n' % (_f(rng, 1.05, 2.2), _rgb(rng, .3, 1) if rng.random() < .9 else "[0 0 0]",
+                                                                                  _rgb(rng, .3, 1) if rng.random() < .9 else "[0 0 0]", rough)
     if kind == "metal":
         if rng.random() < .5:
             rough = '"float roughness" [%g]' % _f(rng, .005, .4)
@@ -63,7 +68,12 @@ def _material(rng, textures):
         zero = "[0 0 0]"
         parts = ['"color Kd" %s' % (_rgb(rng) if rng.random() < .85 else zero), '"color Ks" %s' % (_rgb(rng, .05, .5) if rng.random() < .6 else zero),
                  '"color Kr" %s' % (_rgb(rng, .05, .6) if rng.random() < .4 else zero), '"color Kt" %s' % (_rgb(rng, .05, .6) if rng.random() < .4 else zero)]
-        if rng.random() < .5:
+        if textures and rng.random() < .35:      # image textures on an uber material: Kd, and the opacity (scenes/livingroom:30 binds both)
+            if rng.random() < .6:
+                parts[0] = '"texture Kd" "%s"' % rng.choice(textures)
+            if rng.random() < .7:
+                parts.append('"texture opacity" "%s"' % rng.choice(textures))
+        elif rng.random() < .5:
             parts.append('"color opacity" %s' % _rgb(rng, .2, 1))
         if rng.random() < .5:
             parts.append('"float uroughness" [%g] "float vroughness" [%g]' % (_f(rng, .02, .5), _f(rng, .02, .5)))
@@ -206,7 +216,14 @@ def test_random_scene_parity(hprt, orc, tmp_path, seed):
     model.save(baked)
     bvh = hprt.Bvh(model)
     oracle = orc.OracleScene(baked)
-    scene = hprt.Scene(model, bvh)
+    # every third seed builds its spatial light distribution ON DEMAND (voxel rows as the vertices ask for them + the retry pass),
+    # the others the table of every voxel: same film either way
+    if seed % 3 == 0:
+        os.environ["HPRT_VOXEL_DENSE_MAX_MB"] = "0"
+    try:
+        scene = hprt.Scene(model, bvh)
+    finally:
+        os.environ.pop("HPRT_VOXEL_DENSE_MAX_MB", None)
     rgb0, film0, c0, _, _ = oracle.render(threads=8)
     film1, st = scene.render(count_work=True)
     bad = np.any(film0.view(np.uint32) != film1.view(np.uint32), axis=2)

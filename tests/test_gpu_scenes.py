@@ -129,6 +129,16 @@ CASES = {
                     'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0] '
                     '"point P" [.5 -1.2 .1  1.5 -1.2 .1  1.5 -.9 .1  .5 -.9 .1  .5 -1.2 1.1  1.5 -1.2 1.1  1.5 -.9 1.1  .5 -.9 1.1]\nAttributeEnd\n',
                     integ=UNIFORM + ' "float rrthreshold" [1]', spp=8, maxdepth=10),
+    # ---- rough glass (materials/glass.cpp:61-93): MicrofacetReflection(FresnelDielectric(1, eta)) + MicrofacetTransmission over one
+    #      Trowbridge-Reitz distribution — non-specular lobes, so direct lighting crosses the surface and the roulette sees no etaScale ----
+    "rough_glass": _scene(SPHERE_LIGHT + QUAD_LIGHT + GEOM +
+                          'AttributeBegin\nMaterial "glass" "float uroughness" [.2] "float vroughness" [.05]\nTranslate -1.0 -.2 .55\nShape "sphere" "float radius" [.5]\nAttributeEnd\n'
+                          'AttributeBegin\nMaterial "glass" "float index" [1.33] "color Kt" [.9 1 .95] "color Kr" [.8 .8 .8] "float uroughness" [.3] "float vroughness" [.3] "bool remaproughness" "false"\n'
+                          'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 4 6 5 4 7 6 0 4 5 0 5 1 1 5 6 1 6 2 2 6 7 2 7 3 3 7 4 3 4 0] '
+                          '"point P" [.5 -1.2 .1  1.5 -1.2 .1  1.5 -.9 .1  .5 -.9 .1  .5 -1.2 1.1  1.5 -1.2 1.1  1.5 -.9 1.1  .5 -.9 1.1]\nAttributeEnd\n'
+                          'AttributeBegin\nMaterial "glass" "color Kr" [0 0 0] "float uroughness" [.1]\nTranslate .2 1.2 .5\nShape "sphere" "float radius" [.4]\nAttributeEnd\n'
+                          'AttributeBegin\nMaterial "glass" "color Kt" [0 0 0] "float vroughness" [.4]\nTranslate 1.4 .9 .5\nShape "sphere" "float radius" [.35]\nAttributeEnd\n',
+                          integ=UNIFORM + ' "float rrthreshold" [1]', spp=8, maxdepth=8),
     # ---- the other light sample distributions (core/lightdistrib.cpp): "spatial" is the reference's DEFAULT with more than one light ----
     "three_lights_spatial": _scene('LightSource "point" "point from" [1 -2 4] "color I" [20 5 5]\n'
                                    'LightSource "distant" "point from" [-1 -1 3] "point to" [0 0 0] "color L" [.5 1 .5]\n' + SPHERE_LIGHT + GEOM),

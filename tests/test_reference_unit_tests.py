@@ -44,6 +44,18 @@ def test_oracle_bsdf_sampling_chi_square(orc, which, name):
     assert 0 < p.value <= 1
 
 
+def test_rough_glass_transmission_is_the_references_with_its_known_excess_pdf(orc):
+    """MicrofacetTransmission (core/reflection.cpp:244-266, 425-447) is restated as this revision of the reference has it — WITHOUT the
+    later pbrt fix that returns 0 when wo and wi lie on the same side of the half vector.  Its Pdf therefore integrates to more than
+    1 over the sphere (1.30 for wo = (.3, .2, .8) / |.|, alpha 0.3, eta 1.5) while every sample is valid, which is why the reference's
+    chi-square list (src/tests/bsdfs.cpp:484-544) has no transmission case and why none is claimed here: the lobe's own chi-square test
+    REJECTS, for the reference's arithmetic and for this restatement alike.  Pinned instead: that behaviour itself."""
+    fn = orc.lib.orc_selftest_bsdf_sampling
+    fn.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    p = C.c_double()
+    assert fn(4, C.byref(p)) == 5 and p.value < 1e-6      # MicrofacetTransmission alone: rejected in all five runs, as the reference's code would be
+
+
 def test_product_host_math_unit_tests(hprt):
     f = (C.c_int * 2)(7, 7)
     assert hprt.lib.hprt_debug_host_selftest(f) == 0

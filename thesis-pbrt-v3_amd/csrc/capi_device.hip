@@ -443,7 +443,16 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
         o.alphaY = o.alpha;
         if (in.type == 3 || in.type == 4 || in.type == 6) o.alphaY = in.remap_roughness ? RoughnessToAlpha(in.sigma) : in.sigma;      // substrate / metal / uber: sigma carries vroughness
         memcpy(o.Kr, in.Kr, 12); memcpy(o.Kt, in.Kt, 12); memcpy(o.opacity, in.opacity, 12); o.eta = in.eta;
-        if (in.type == 5) o.alpha = in.roughness;      // glass: the index of refraction, as given
+        o.roughGlass = 0;
+        if (in.type == 5) {
+            o.alpha = in.roughness;      // glass: the index of refraction, as given
+            // rough dielectric (materials/glass.cpp:61-72): isSpecular is decided on the values as given, the remap applies to both after it
+            if (in.sigma != 0.f || in.Kr[0] != 0.f) {
+                o.roughGlass = 1;
+                o.Kr[0] = in.remap_roughness ? RoughnessToAlpha(in.sigma) : in.sigma;
+                o.Kr[1] = in.remap_roughness ? RoughnessToAlpha(in.Kr[0]) : in.Kr[0];
+            }
+        }
         // MatteMaterial: sig = Clamp(sigma, 0, 90); sig != 0 -> OrenNayar(r, sig) (materials/matte.cpp:55-61, core/reflection.h:414-420)
         const float sig = clampf(in.sigma, 0.f, 90.f);
         o.oren = in.type == 0 && sig != 0.f ? 1 : 0; o.orenA = 1.f; o.orenB = 0.f;

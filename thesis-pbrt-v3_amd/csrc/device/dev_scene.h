@@ -63,7 +63,7 @@ enum : uint32_t { SHAPE_FLIP = 1u, SHAPE_HAS_N = 2u, SHAPE_HAS_UV = 4u, SHAPE_HA
 
 struct DevShape { int32_t material, areaLight; uint32_t flags; int32_t sphere; };
 struct DevMaterial { int32_t type; float Kd[3]; float Ks[3]; float alpha; int32_t KdTex, KsTex; float orenA, orenB; int32_t oren; float alphaY;
-                     float Kr[3], Kt[3], opacity[3], eta; int32_t opTex; };      // (type 6, uber: Kr, Kt, opacity, eta; alpha / alphaY from u / vroughness)      // type 2: mirror, Kr in Ks; 3: substrate (alpha, alphaY = TR alphas of u / vroughness); 4: metal (Kd = eta, Ks = k); 5: smooth glass (Kd = Kt, Ks = Kr, alpha = eta); oren: OrenNayar's A, B (core/reflection.h:414-420) evaluated on the host   // alpha: RoughnessToAlpha applied on the host; *Tex: image texture or -1
+                     float Kr[3], Kt[3], opacity[3], eta; int32_t opTex; int32_t roughGlass; };      // roughGlass: type 5 with Kr[0], Kr[1] = the Trowbridge-Reitz alphas of its two microfacet lobes      // (type 6, uber: Kr, Kt, opacity, eta; alpha / alphaY from u / vroughness)      // type 2: mirror, Kr in Ks; 3: substrate (alpha, alphaY = TR alphas of u / vroughness); 4: metal (Kd = eta, Ks = k); 5: smooth glass (Kd = Kt, Ks = Kr, alpha = eta); oren: OrenNayar's A, B (core/reflection.h:414-420) evaluated on the host   // alpha: RoughnessToAlpha applied on the host; *Tex: image texture or -1
 // ImageTexture + MIPMap (textures/imagemap.h, core/mipmap.h): levels are consecutive in mipLevels, texels hold 3 floats each
 struct DevMipLevel { uint32_t offset; int32_t w, h; };
 struct DevTexture { uint32_t firstLevel, nLevels; int32_t trilinear, wrap; float maxAniso, su, sv, du, dv; };

@@ -316,6 +316,7 @@ struct DevBsdf {
     float alpha;           // Trowbridge-Reitz alpha of the microfacet lobe
     bool hasD, hasS;
     bool hasR;             // a SpecularReflection lobe with FresnelNoOp (mirror): the BSDF's only lobe when present
+    bool hasT;             // kind 6 (rough glass): a MicrofacetTransmission lobe (T in Rd) behind the MicrofacetReflection lobe (hasS: R in Rs)
     rgb Rr;
     bool oren; float orenA, orenB;      // the diffuse lobe is OrenNayar, not LambertianReflection
     float alphaY;          // Trowbridge-Reitz alpha along v (== alpha for plastic)
@@ -324,7 +325,8 @@ struct DevBsdf {
     rgb op;                    // kind 5: the clamped opacity at this vertex (a constant or its image texture, materials/uber.cpp:53)
     const DevMaterial *uber;   // kind 5 (UberMaterial): the material, for the specular lobes only Sample_f(BSDF_ALL) can pick (kr, kt, 1 - opacity)
     int kind;              // 0: the lobes above; 4 (with hasR): ONE FresnelSpecular lobe (glass: Rr = R, Rd = T, eta); 2: ONE FresnelBlend lobe (substrate: Rd, Rs, alpha, alphaY); 3: ONE conductor
-                           // microfacet lobe (metal: Rd = eta, Rs = k, R = 1).  Kinds 2 and 3 are flagged hasS (a glossy reflection lobe)
+                           // microfacet lobe (metal: Rd = eta, Rs = k, R = 1).  Kinds 2 and 3 are flagged hasS (a glossy reflection lobe).  6: rough glass — MicrofacetReflection
+                           // (hasS: Rs = R, FresnelDielectric(1, eta)) and / or MicrofacetTransmission (hasT: Rd = T) over one Trowbridge-Reitz distribution (materials/glass.cpp:61-93)
 };
 __device__ __forceinline__ float cos_theta(vec3 w) { return w.z; }
 __device__ __forceinline__ float cos2_theta(vec3 w) { return w.z * w.z; }
@@ -487,6 +489,29 @@ __device__ __forceinline__ float blend_pdf(const DevBsdf &b, vec3 wo, vec3 wi) {
     const float pdf_wh = tr_pdf(b.alpha, b.alphaY, wo, wh);
     return .5f * (abs_cos_theta(wi) * HPRT_INV_PI + pdf_wh / (4 * dot(wo, wh)));
 }
+// MicrofacetTransmission (core/reflection.cpp:244-266, 425-447) with etaA = 1, etaB = b.eta, T = b.Rd, TransportMode::Radiance
+__device__ __forceinline__ rgb mt_f(const DevBsdf &b, vec3 wo, vec3 wi) {
+    if (same_hemisphere(wo, wi)) return rgb(0.f);      // transmission only
+    const float cosThetaO = cos_theta(wo), cosThetaI = cos_theta(wi);
+    if (cosThetaI == 0 || cosThetaO == 0) return rgb(0.f);
+    const float eta = cos_theta(wo) > 0 ? (b.eta / 1.f) : (1.f / b.eta);
+    vec3 wh = normalize(wo + wi * eta);
+    if (wh.z < 0) wh = -wh;
+    const rgb F(fr_dielectric(dot(wo, wh), 1.f, b.eta));
+    const float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+    const float factor = 1 / eta;
+    return rgb_sub(rgb(1.f), F) * b.Rd *
+           fabsf(tr_D(b.alpha, b.alphaY, wh) * tr_G(b.alpha, b.alphaY, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
+                 (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
+}
+__device__ __forceinline__ float mt_pdf(const DevBsdf &b, vec3 wo, vec3 wi) {
+    if (same_hemisphere(wo, wi)) return 0;
+    const float eta = cos_theta(wo) > 0 ? (b.eta / 1.f) : (1.f / b.eta);
+    const vec3 wh = normalize(wo + wi * eta);
+    const float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+    const float dwh_dwi = fabsf((eta * eta * dot(wi, wh)) / (sqrtDenom * sqrtDenom));
+    return tr_pdf(b.alpha, b.alphaY, wo, wh) * dwh_dwi;
+}
 // materials/matte.cpp:45-62, materials/plastic.cpp:45-70: lobes are added in the order
 // diffuse, specular; a black reflectance adds no lobe.
 // ---- image textures: SurfaceInteraction::ComputeDifferentials (core/interaction.cpp:103-149, the (u,v) part),
@@ -607,7 +632,7 @@ __device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, D
     b->ss = normalize(si.sdpdu);
     b->ts = cross(b->ns, b->ss);
     b->alpha = 0; b->hasD = false; b->hasS = false; b->Rd = rgb(0.f); b->Rs = rgb(0.f);
-    b->hasR = false; b->Rr = rgb(0.f); b->oren = false; b->orenA = 1.f; b->orenB = 0.f;
+    b->hasR = false; b->hasT = false; b->Rr = rgb(0.f); b->oren = false; b->orenA = 1.f; b->orenB = 0.f;
     const DevMaterial m = sc.materials[sc.shapes[si.shape].material];
     b->alphaY = 0; b->kind = 0; b->eta = 1.f; b->frI = 1.5f; b->frT = 1.f; b->uber = nullptr;
     if (m.type == 6) {      // UberMaterial, materials/uber.cpp:45-108: Lambertian + microfacet (FresnelDielectric(1, e)) as the plastic pair, and up to
@@ -626,6 +651,12 @@ __device__ __forceinline__ void bsdf_init(const DevScene &sc, const DevSI &si, D
         b->eta = m.alpha;
         const rgb R = clamp0(ksOverride ? *ksOverride : rgb(m.Ks[0], m.Ks[1], m.Ks[2])), T = clamp0(kdOverride ? *kdOverride : rgb(m.Kd[0], m.Kd[1], m.Kd[2]));
         if (is_black(R) && is_black(T)) return;
+        if (m.roughGlass) {      // rough dielectric (:66-93): MicrofacetReflection(R, FresnelDielectric(1, eta)) then MicrofacetTransmission(T, 1, eta)
+            b->kind = 6; b->alpha = m.Kr[0]; b->alphaY = m.Kr[1]; b->frI = 1.f; b->frT = b->eta;
+            if (!is_black(R)) { b->hasS = true; b->Rs = R; }
+            if (!is_black(T)) { b->hasT = true; b->Rd = T; }
+            return;
+        }
         b->hasR = true; b->kind = 4; b->Rr = R; b->Rd = T;
         return;
     }
@@ -658,7 +689,7 @@ __device__ __forceinline__ vec3 to_world(const DevBsdf &b, vec3 v) {
 // Both lobe types (REFLECTION|DIFFUSE, REFLECTION|GLOSSY) match BSDF_ALL and
 // BSDF_ALL & ~BSDF_SPECULAR, the only flag sets PathIntegrator passes (path.cpp:129,144;
 // integrator.cpp:114), so NumComponents(flags) is the lobe count.
-__device__ __forceinline__ int bsdf_num(const DevBsdf &b) { return (b.hasD ? 1 : 0) + (b.hasS ? 1 : 0); }
+__device__ __forceinline__ int bsdf_num(const DevBsdf &b) { return (b.hasD ? 1 : 0) + (b.hasS ? 1 : 0) + (b.hasT ? 1 : 0); }
 // BSDF::f, core/reflection.cpp:670-684 (all lobes here are reflective)
 __device__ __forceinline__ rgb bsdf_f(const DevBsdf &b, vec3 woW, vec3 wiW) {
     vec3 wi = to_local(b, wiW), wo = to_local(b, woW);
@@ -667,6 +698,7 @@ __device__ __forceinline__ rgb bsdf_f(const DevBsdf &b, vec3 woW, vec3 wiW) {
     rgb f(0.f);
     if (b.hasD && reflect) f = f + lambert_f(b, wo, wi);
     if (b.hasS && reflect) f = f + (b.kind == 2 ? blend_f(b, wo, wi) : mf_f(b, wo, wi));
+    if (b.hasT && !reflect) f = f + mt_f(b, wo, wi);      // (the one transmissive non-specular lobe: rough glass)
     return f;
 }
 // BSDF::Pdf, core/reflection.cpp:764-778
@@ -678,6 +710,7 @@ __device__ __forceinline__ float bsdf_pdf(const DevBsdf &b, vec3 woW, vec3 wiW) 
     float pdf = 0.f;
     if (b.hasD) pdf += lambert_pdf(wo, wi);
     if (b.hasS) pdf += b.kind == 2 ? blend_pdf(b, wo, wi) : mf_pdf(b, wo, wi);
+    if (b.hasT) pdf += mt_pdf(b, wo, wi);
     return pdf / matching;
 }
 // BSDF::Sample_f, core/reflection.cpp:703-762.  *pdf keeps its incoming value on the
@@ -773,6 +806,42 @@ __device__ __forceinline__ rgb bsdf_sample(const DevBsdf &b, vec3 woW, vec3 *wiW
         *sampledType = BX_REFLECTION | BX_SPECULAR;
         *wiW = to_world(b, wi);
         return rgb(1.f) * b.Rr / abs_cos_theta(wi);
+    }
+    if (b.kind == 6) {      // rough glass: BSDF::Sample_f over {MicrofacetReflection, MicrofacetTransmission} (core/reflection.cpp:703-762, 402-414, 425-435)
+        const int matching6 = (b.hasS ? 1 : 0) + (b.hasT ? 1 : 0);
+        if (matching6 == 0) { *pdf = 0; *sampledType = 0; return rgb(0.f); }
+        const int comp6 = sel_min((int)floorf(u0 * matching6), matching6 - 1);
+        const bool pickT = b.hasS ? comp6 == 1 : true;
+        const float ur0 = sel_min(u0 * matching6 - comp6, HPRT_ONE_MINUS_EPS);
+        const vec3 wo = to_local(b, woW);
+        if (wo.z == 0) return rgb(0.f);
+        *pdf = 0;
+        *sampledType = pickT ? (BX_TRANSMISSION | BX_GLOSSY) : (BX_REFLECTION | BX_GLOSSY);
+        const vec3 wh = tr_sample_wh(b.alpha, b.alphaY, wo, ur0, u1);
+        vec3 wi;
+        if (!pickT) {
+            wi = -wo + 2 * dot(wo, wh) * wh;
+            if (same_hemisphere(wo, wi)) *pdf = tr_pdf(b.alpha, b.alphaY, wo, wh) / (4 * dot(wo, wh));
+        } else {
+            // Refract(wo, (Normal3f)wh, eta, &wi), core/reflection.h:96-108
+            const float er = cos_theta(wo) > 0 ? (1.f / b.eta) : (b.eta / 1.f);
+            const float cosThetaI = dot(wh, wo);
+            const float sin2ThetaI = sel_max(0.f, 1 - cosThetaI * cosThetaI);
+            const float sin2ThetaT = er * er * sin2ThetaI;
+            if (!(sin2ThetaT >= 1)) {
+                const float cosThetaT = sqrtf(1 - sin2ThetaT);
+                wi = er * -wo + (er * cosThetaI - cosThetaT) * wh;
+                *pdf = mt_pdf(b, wo, wi);
+            }
+        }
+        if (*pdf == 0) { *sampledType = 0; return rgb(0.f); }
+        *wiW = to_world(b, wi);
+        if (matching6 > 1) { *pdf += pickT ? mf_pdf(b, wo, wi) : mt_pdf(b, wo, wi); *pdf /= matching6; }
+        const bool reflect6 = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
+        rgb f6(0.f);
+        if (b.hasS && reflect6) f6 = f6 + mf_f(b, wo, wi);
+        if (b.hasT && !reflect6) f6 = f6 + mt_f(b, wo, wi);
+        return f6;
     }
     const int nPair = bsdf_num(b);
     const int matching = nBefore + nPair + nAfter;      // (nBefore = nAfter = 0 unless an uber BSDF is sampled over all its lobes)

@@ -893,7 +893,7 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
             }
             bsdf_init(sc, si, &bsdf, useKd ? &kdTex : nullptr, useKs ? &ksTex : nullptr, useOp ? &opTex : nullptr);
             if (MODE == 0) { bsdf.hasS = false; bsdf.Rs = rgb(0.f); bsdf.alpha = 0.f; }   // matte: no microfacet lobe (matte.cpp:45-62)
-            if (MODE != 2) { bsdf.hasR = false; bsdf.oren = false; bsdf.kind = 0; }      // mirror, metal, glass, uber and OrenNayar surfaces are shaded by the generic variant
+            if (MODE != 2) { bsdf.hasR = false; bsdf.hasT = false; bsdf.oren = false; bsdf.kind = 0; }      // mirror, metal, glass, uber and OrenNayar surfaces are shaded by the generic variant
             if (MODE == 3) { bsdf.kind = 2; bsdf.hasD = false; }      // substrate: the one FresnelBlend lobe (bsdf_init set hasS unless both reflectances are black)
             SP_MARK(1);      // textures + bsdf_init
             // ---- direct lighting (UniformSampleOneLight + EstimateDirect) ----

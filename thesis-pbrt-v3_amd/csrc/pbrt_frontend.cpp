@@ -315,16 +315,21 @@ struct Frontend {
             const Param *rp = geom.find("remaproughness", "bool"); if (!rp) rp = mp->find("remaproughness", "bool");
             if (rp && rp->bools.size() == 1) remap = rp->bools[0];
             m.remapRoughness = remap ? 1 : 0;
-        } else if (name == "glass") {       // CreateGlassMaterial, materials/glass.cpp:88-105: the smooth dielectric (FresnelSpecular)
+        } else if (name == "glass") {       // CreateGlassMaterial, materials/glass.cpp:88-105: smooth (FresnelSpecular) or rough (microfacet) dielectric
             const float one[3] = {1.f, 1.f, 1.f};
             m.type = kGlass;
             spectrumParam(geom, *mp, "Kr", one, m.Ks, &m.KsTex);
             spectrumParam(geom, *mp, "Kt", one, m.Kd, &m.KdTex);
             const bool hasEta = mp->find("eta", "float") || geom.find("eta", "float") || !mp->texture("eta").empty() || !geom.texture("eta").empty();
             m.roughness = hasEta ? floatParam(geom, *mp, "eta", 1.5f) : floatParam(geom, *mp, "index", 1.5f);
-            if (floatParam(geom, *mp, "uroughness", 0.f) != 0.f || floatParam(geom, *mp, "vroughness", 0.f) != 0.f)
-                warn("rough glass (MicrofacetTransmission) is outside the hot-path scope; rendered as smooth glass");
-            (void)(mp->find("remaproughness", "bool") || geom.find("remaproughness", "bool"));      // (read by the reference; only rough glass uses it)
+            // "uroughness" / "vroughness" (both 0: the smooth FresnelSpecular lobe; else MicrofacetReflection + MicrofacetTransmission,
+            // materials/glass.cpp:61-93): uroughness travels in sigma, vroughness in Kr[0]
+            m.sigma = floatParam(geom, *mp, "uroughness", 0.f);
+            m.Kr[0] = floatParam(geom, *mp, "vroughness", 0.f);
+            bool remap = true;
+            const Param *rp = geom.find("remaproughness", "bool"); if (!rp) rp = mp->find("remaproughness", "bool");
+            if (rp && rp->bools.size() == 1) remap = rp->bools[0];
+            m.remapRoughness = remap ? 1 : 0;
         } else if (name == "uber") {        // CreateUberMaterial, materials/uber.cpp:110-140 (constant parameters; Kd / Ks may be image textures)
             const float q[3] = {0.25f, 0.25f, 0.25f}, zero[3] = {0.f, 0.f, 0.f}, one[3] = {1.f, 1.f, 1.f};
             m.type = kUber;

@@ -51,7 +51,9 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
     // uber material after the uber block.  Written when a compact file is asked for or an uber material has a textured opacity.
     bool opacityTextured = false;
     for (const MaterialDesc &m : sc.materials) if (m.type == kUber && m.opacityTex >= 0) opacityTextured = true;
-    const bool v6 = opacityTextured || (compactTextures && !sc.textures.empty());
+    bool roughGlass = false;      // (c) version 6 also stores every glass material's vroughness (uroughness sits in sigma): rough dielectrics
+    for (const MaterialDesc &m : sc.materials) if (m.type == kGlass && (m.sigma != 0.f || m.Kr[0] != 0.f)) roughGlass = true;
+    const bool v6 = opacityTextured || roughGlass || (compactTextures && !sc.textures.empty());
     o.raw("HPRTSCN1", 8); o.u32(v6 ? 6u : uber ? 5u : infinite ? 4u : textured ? 3u : instancing ? 2u : 1u);
     o.i32(p.xres); o.i32(p.yres);
     o.raw(p.crop, 16);
@@ -117,9 +119,12 @@ bool SaveBakedScene(const SceneModel &sc, const std::string &path, std::string *
     if (uber || v6)
         for (const MaterialDesc &m : sc.materials)
             if (m.type == kUber) { o.raw(m.Kr, 12); o.raw(m.Kt, 12); o.raw(m.opacity, 12); o.f32(m.eta); }
-    if (v6)
+    if (v6) {
         for (const MaterialDesc &m : sc.materials)
             if (m.type == kUber) o.i32(m.opacityTex);
+        for (const MaterialDesc &m : sc.materials)
+            if (m.type == kGlass) o.f32(m.Kr[0]);
+    }
     bool ok = o.ok;
     if (fclose(fp) != 0) ok = false;
     if (!ok) *err = "write error on " + path;
@@ -259,6 +264,9 @@ bool LoadBakedScene(const std::string &path, SceneModel *sc, std::string *err) {
                 m.opacityTex = in.i32();
                 if (!in.ok || m.opacityTex < -1 || m.opacityTex >= (int32_t)sc->textures.size()) return fail("opacity texture index out of range");
             }
+    if (version >= 6)
+        for (MaterialDesc &m : sc->materials)
+            if (m.type == kGlass) m.Kr[0] = in.f32();
     if (!in.ok) return fail("truncated file");
     fclose(fp);
     return true;

@@ -12,7 +12,7 @@
 namespace hprt {
 
 enum MaterialType { kMatte = 0, kPlastic = 1, kMirror = 2, kSubstrate = 3, kMetal = 4, kGlass = 5, kUber = 6 };
-// mirror: Kr travels in Ks.  substrate: roughness = uroughness, sigma = vroughness.  metal: Kd = eta, Ks = k, roughness / sigma likewise.  glass: Kd = Kt, Ks = Kr, roughness = eta (index).
+// mirror: Kr travels in Ks.  substrate: roughness = uroughness, sigma = vroughness.  metal: Kd = eta, Ks = k, roughness / sigma likewise.  glass: Kd = Kt, Ks = Kr, roughness = eta (index), sigma = uroughness, Kr[0] = vroughness (both 0: smooth).
 enum LightType { kPointLight = 0, kDistantLight = 1, kDiffuseAreaLight = 2, kInfiniteLight = 3 };
 enum ShapeKind { kTriangleMesh = 0, kSphere = 1 };
 enum LightStrategy { kUniform = 0, kPower = 1, kSpatial = 2 };
