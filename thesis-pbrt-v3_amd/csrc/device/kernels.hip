@@ -851,10 +851,12 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
                     rgb Le = area_L(sc.lights[al], si.n, -rayD);
                     rgb add = beta * Le;
                     L = rgb(L.r + add.r, L.g + add.g, L.b + add.b);
-                } else {
-                    // L += beta * Spectrum(0): adds +0 (or -0) and leaves L's value unchanged
+                } else if (specularBounce) {
+                    // L += beta * Spectrum(0) (path.cpp:97-100 with isect.Le == 0): +-0 for a finite throughput — L unchanged — but NaN where a
+                    // specular bounce left beta infinite or NaN, and the reference then zeroes the whole sample (core/integrator.cpp:300-321)
+                    L = rgb(L.r + beta.r * 0.f, L.g + beta.g * 0.f, L.b + beta.b * 0.f);
                 }
-            }
+            } else if (MODE != 2 && specularBounce) L = rgb(L.r + beta.r * 0.f, L.g + beta.g * 0.f, L.b + beta.b * 0.f);      // (the same term on a non-emitter reached directly; beta == 1 at bounce 0)
         }
         SP_MARK(0);      // loads + surface interaction
         if (MODE == 2 && !found && (bounces == 0 || specularBounce))
@@ -988,6 +990,11 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
                     }
                 }
             }
+            // "L += beta * UniformSampleOneLight(...)" (path.cpp:129-137) runs for every vertex with a non-specular lobe, also when the estimate
+            // is Spectrum(0) (no light, pick pdf 0, black f, zero light pdf): beta * 0 is +-0 for a finite throughput — which is why such a vertex
+            // queues no resolve work — but NaN for an infinite or NaN one (a degenerate microfacet alpha, a vanishing pdf), and the
+            // reference's NaN guard then zeroes the whole sample.  Found by the random scenes (rough glass with alpha 0 along one axis).
+            if (!defer && !wantResolve && bsdf_num(bsdf) > 0) L = rgb(L.r + beta.r * 0.f, L.g + beta.g * 0.f, L.b + beta.b * 0.f);
             SP_MARK(4);      // BSDF-sampled light term + pending stores
             // ---- sample the BSDF for the next path segment (path.cpp:141-164) ----
             if (!defer) {
