@@ -5,8 +5,10 @@ HEADLINE workload (config.workload) = BASELINE.json configs[2], the largest sing
 geometry and textures are git-ignored), so the geometry is a STAND-IN, labelled as such everywhere: the procedural
 312 k-triangle atrium of tools/scene_gen.py (two storeys of arcades, tessellated columns and arches, curtains; matte and
 plastic; one point light as scenes/sponza has), 700x700, Halton 1024 spp, PathIntegrator maxdepth 5, Accelerator "bvh".
-Secondary workloads ride in the same JSON line (`secondary`): configs[1] killeroo-simple 256 spp (the reference's own
-asset, baked) and the reference's living-room meshes at 1280x720, 256 spp (configs[3]'s class with real geometry).
+Secondary workloads ride in the same JSON line (`secondary`): configs[1] killeroo-simple 256 spp (the reference's own asset,
+baked), configs[3]'s class — the reference's living-room meshes at 1280x720 with the image textures it ships, at that
+configuration's 2,048 spp — and configs[4] as SURVEY.md §8(d)-5 defines it (the killeroo mesh x 301 ObjectInstances, 10.01 M
+triangles) at its 4,096 spp; each with its own `roofline` and `cpu_baseline`.
 
 A STEP is one complete Render() of the headline frame: every camera sample traced through the wavefront kernels and
 folded into the film; scene, BVH and sampler tables are resident in HBM before the timed region.  With N > 1 the
@@ -15,7 +17,8 @@ image's 16x16 tiles are dealt round-robin to the ranks at FIXED total spp (stron
 hprt_film_gather: one RCCL reduce over xGMI plus the ordered merge of the cross-tile records (csrc/capi_gather.hip).
 
 `python bench.py --gpus N` without WORLD_SIZE in the environment starts N fresh rank processes itself (before this
-process touches the GPU) and relays rank 0's line; under torch.distributed.run it reads RANK/LOCAL_RANK/WORLD_SIZE.
+process touches the GPU), watches ALL of them (the first non-zero exit ends the run at once) and relays rank 0's line; under
+torch.distributed.run it reads RANK/LOCAL_RANK/WORLD_SIZE.  Every rank checks that its GPU exists before it enters a collective.
 `n_gpus` is the size the RCCL communicator reports, never the flag (a --rehearse-on-one-gpu run says 1, with `world_size` ranks;
 if the library's communicator cannot be created the films are merged through torch.distributed's RCCL group instead, `n_gpus` is
 the number of distinct devices the ranks sit on, and `config.film_merge` says what happened).
@@ -23,15 +26,20 @@ the number of distinct devices the ranks sit on, and `config.film_merge` says wh
 Rays = closest-hit + shadow rays, as the reference counts them (core/scene.cpp:40-55), TRACED rays only.
 
 Extra objects in the line:
-  roofline      dominant kernel = k_trace<closest>.  achieved/frac = ALGORITHMIC bytes (32 B per BVH node fetched + 48 B
-                per primitive test + 28 B ray read + 20 B hit write; V and T counted by the kernel) /
-                HIP-event time of that kernel's launches, against the 8 TB/s HBM3E peak — the contract's figure.  The
-                BVH lives in L2/MALL, so that figure is NOT an HBM utilisation; the measured ones are beside it:
-                traffic / hbm_counter_frac (FETCH_SIZE/WRITE_SIZE PMC passes), lane_utilisation and wait_frac (SQ
-                counters) per kernel, and the whole frame's hbm_bytes_per_step, all read from the committed summary
-                profiles/r02_counters.json that tools/counters_passes.sh made from `bench.py --profile-step`.
-  cpu_baseline  the oracle (CPU port of the same path, kind "port") on all host threads, on a bounded sample of the
-                same frame.  BASELINE.md §3 relates the port's speed to the reference binary's.
+  roofline      dominant kernel = k_trace<closest>.  `frac` = MEASURED HBM traffic of that kernel (FETCH_SIZE / WRITE_SIZE PMC passes of
+                the committed summary profiles/rNN_counters.json, per launch) / this run's HIP-event launch time / the 8 TB/s HBM3E
+                peak: at most 1 by construction; `peak_measured` = a float4 stream copy run inside this process (what a stream kernel
+                reaches on THIS box) with `frac_of_measured_peak`.  `bound` is read off the counters: "valu_issue" when the VALU issue
+                fraction (SQ_ACTIVE_INST_VALU * 4 / (1,024 SIMDs * kernel cycles), cycles = GRBM_GUI_ACTIVE / 8) exceeds the HBM fraction —
+                it does: the walk is issue-bound on divergent lanes — with `lane_utilisation` and `useful_lane_frac` = issue x lanes.
+                The summary is stamped with the sha256 of the code objects it was measured on; `counters_stale` says when the loaded
+                library's differ (then `frac` falls back to the summary's own launch time and the flag tells).  The contract's model
+                figure — algorithmic bytes (32 B per BVH node fetched + 48 B per primitive test + 28 B ray + 20 B hit; V
+                and T counted by the kernel) / kernel time — rides in `roofline.algorithmic` labelled as what it is: the BVH is served by
+                L1 / L2 / MALL, so that rate exceeds the HBM peak and is NOT a roofline fraction.
+  cpu_baseline  the oracle (CPU port of the same path, kind "port") on the CPUs this process can really use — min(affinity, cgroup
+                quota): the box shows 256 logical CPUs and grants 16 — on a bounded sample of the same frame, with the host's
+                description and a thread sweep (`scaling`).  BASELINE.md §3 relates the port's speed to the reference binary's.
 """
 import argparse
 import importlib

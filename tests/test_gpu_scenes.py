@@ -139,6 +139,16 @@ CASES = {
                           'AttributeBegin\nMaterial "glass" "color Kr" [0 0 0] "float uroughness" [.1]\nTranslate .2 1.2 .5\nShape "sphere" "float radius" [.4]\nAttributeEnd\n'
                           'AttributeBegin\nMaterial "glass" "color Kt" [0 0 0] "float vroughness" [.4]\nTranslate 1.4 .9 .5\nShape "sphere" "float radius" [.35]\nAttributeEnd\n',
                           integ=UNIFORM + ' "float rrthreshold" [1]', spp=8, maxdepth=8),
+    # a DEGENERATE rough dielectric: alpha 0 along one axis (remaproughness false) makes TrowbridgeReitzDistribution::D return NaN for
+    # every direction (0 * inf in its denominator), so the path's throughput turns NaN at such a vertex.  The reference then adds
+    # "beta * Spectrum(0)" at later vertices whose light estimate is zero — NaN, not 0 — and its NaN guard zeroes the sample
+    # (core/integrator.cpp:300-321); a device that skips the zero estimate keeps a finite radiance.  Found by the random scenes.
+    "rough_glass_degenerate_alpha": _scene('LightSource "point" "point from" [1 -2 4] "color I" [20 18 15]\n' + SPHERE_LIGHT + GEOM +
+                                           'AttributeBegin\nMaterial "glass" "float index" [1.31] "float uroughness" [0] "float vroughness" [.4] "bool remaproughness" "false"\n'
+                                           'Translate -1.0 -.2 .55\nShape "sphere" "float radius" [.5]\nAttributeEnd\n'
+                                           'AttributeBegin\nMaterial "glass" "color Kt" [0 0 0] "float uroughness" [.05] "float vroughness" [0] "bool remaproughness" "false"\n'
+                                           'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [.3 -1.4 .05  1.7 -1.4 .05  1.7 -.6 .6  .3 -.6 .6]\nAttributeEnd\n',
+                                           integ='"string lightsamplestrategy" "power"', spp=4, maxdepth=6),
     # ---- the other light sample distributions (core/lightdistrib.cpp): "spatial" is the reference's DEFAULT with more than one light ----
     "three_lights_spatial": _scene('LightSource "point" "point from" [1 -2 4] "color I" [20 5 5]\n'
                                    'LightSource "distant" "point from" [-1 -1 3] "point to" [0 0 0] "color L" [.5 1 .5]\n' + SPHERE_LIGHT + GEOM),

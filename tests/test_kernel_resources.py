@@ -52,3 +52,21 @@ def test_plain_traversal_kernels_fit_their_occupancy(kernels, any_hit, quad, max
     assert k[".vgpr_count"] <= max_vgpr and k[".vgpr_spill_count"] <= max_spill, (k[".vgpr_count"], k[".vgpr_spill_count"])
     assert lds <= k[".group_segment_fixed_size"] <= lds + 64, k[".group_segment_fixed_size"]
     assert k[".wavefront_size"] == 64
+
+
+@pytest.mark.parametrize("mode,tex,max_vgpr,max_scratch", [
+    (0, 0, 128, 0),        # matte: four waves per SIMD, nothing in scratch
+    (1, 0, 128, 0),        # plastic
+    (3, 0, 128, 0),        # substrate (round 3): the FresnelBlend-only variant must stay a four-wave kernel — that is what it was split off for
+    (2, 0, 170, 512),      # generic: three waves (512 / 170 registers); a small call stack
+    (2, 1, 170, 1024),     # generic with the MIPMap lookups: shades bin 3 only, so that its stack is not every generic vertex's
+])
+def test_shading_variants_keep_their_occupancy(kernels, mode, tex, max_vgpr, max_scratch):
+    bs = 256 if mode == 2 else 512
+    key = "k_shadeILi%dELi%dELb%dE" % (mode, bs, tex)
+    found = [v for n, v in kernels.items() if key in n]
+    assert len(found) == 1, key
+    k = found[0]
+    assert k[".vgpr_count"] <= max_vgpr and k[".private_segment_fixed_size"] <= max_scratch, (k[".vgpr_count"], k[".private_segment_fixed_size"])
+    if mode != 2:
+        assert k[".vgpr_spill_count"] == 0

@@ -700,7 +700,14 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
             if (word < 0 && sc.nEnvLights != 0u && (bounces == 0 || (__float_as_uint(in.ray.b[slot[k]].w) >> 31))) bin[k] = 2;
             if (bin[k] < 0) {      // the path ends here
                 if (bounces == 0) Lfinal[slot[k]] = make_float4(0.f, 0.f, 0.f, 1.f);      // fresh path: path id = slot, L = 0 (k_generate)
-                else Lfinal[__float_as_uint(in.beta[slot[k]].w)] = in.L[slot[k]];
+                else {
+                    const float4 b4 = in.beta[slot[k]];
+                    float4 L4 = in.L[slot[k]];
+                    // a specular segment that ends on a non-emitter at the depth limit still adds beta * isect.Le(-ray.d) = beta * 0 (path.cpp:97-100
+                    // precedes the depth test, :110): +-0 unless the throughput is infinite or NaN — then NaN, and the reference zeroes the sample
+                    if (word >= 0 && (__float_as_uint(in.ray.b[slot[k]].w) >> 31)) { L4.x += b4.x * 0.f; L4.y += b4.y * 0.f; L4.z += b4.z * 0.f; }
+                    Lfinal[__float_as_uint(b4.w)] = L4;
+                }
             }
         }
 #pragma unroll
