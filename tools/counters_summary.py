@@ -56,8 +56,16 @@ for k, v in K.items():
             # kernel cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs; MI355X_MICROARCH.md "DVFS give-back"); a wave64 VALU
             # instruction holds its SIMD's issue slot for 4 cycles: fraction of all SIMD issue slots that issued VALU work
             cycles = v["GRBM_GUI_ACTIVE"] / 8.0
+            # Two readings of "how busy is the VALU": (1) valu_issue_frac — VERDICT r2's figure — SQ_ACTIVE_INST_VALU * 4 / (SIMDs * cycles): the
+            # counter sums, per wave, the (quad-)cycles a VALU instruction of that wave is in execution; instructions that occupy the pipe for
+            # longer than one issue slot (64-bit integer multiplies, double-precision transcendental sequences) overlap between waves, so the
+            # sum can exceed the wall cycles (k_generate, k_shade<plastic>: > 1).  (2) valu_inst_frac — SQ_INSTS_VALU * 4 / (SIMDs * cycles):
+            # instructions ISSUED times the four cycles a wave64 instruction needs at least: a strict lower bound of the pipe's busy
+            # fraction, never above 1.  The traversal kernels' instructions are single-slot ones: the two agree there to a few per cent.
             e["valu_issue_frac"] = round(v["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * cycles), 4)
-            e["useful_lane_frac"] = round(e["valu_issue_frac"] * e["lane_utilisation"], 4)
+            if v.get("SQ_INSTS_VALU"):
+                e["valu_inst_frac"] = round(v["SQ_INSTS_VALU"] * 4.0 / (N_SIMDS * cycles), 4)
+            e["useful_lane_frac"] = round(min(1.0, e["valu_issue_frac"]) * e["lane_utilisation"], 4)
             e["effective_clock_mhz"] = round(cycles / (v["total_ns"] * 1e-9) / 1e6, 1)
     if v.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
         e["l1_accesses"] = round(v["TCP_TOTAL_CACHE_ACCESSES_sum"]); e["l1_miss_rate"] = round(v.get("TCP_TCC_READ_REQ_sum", 0.0) / v["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
