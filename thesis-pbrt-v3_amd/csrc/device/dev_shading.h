@@ -563,7 +563,7 @@ __device__ __forceinline__ rgb mip_triangle(const DevScene &sc, const DevTexture
 }
 __device__ __forceinline__ float log2_f(float x) { const float invLog2 = 1.442695040888963387004650940071; return det_logf(x) * invLog2; }   // core/pbrt.h:328-331
 __device__ __forceinline__ rgb lerp_rgb(float t, rgb a, rgb b) { return (1 - t) * a + t * b; }
-__device__ __noinline__ rgb mip_ewa(const DevScene &sc, const DevTexture &tx, int level, float su, float sv, float d0x, float d0y, float d1x, float d1y) {
+__device__ __forceinline__ rgb mip_ewa(const DevScene &sc, const DevTexture &tx, int level, float su, float sv, float d0x, float d0y, float d1x, float d1y) {
     if (level >= (int)tx.nLevels) return mip_texel(sc, tx, (int)tx.nLevels - 1, 0, 0);
     const DevMipLevel l = sc.mipLevels[tx.firstLevel + level];
     su = su * l.w - 0.5f; sv = sv * l.h - 0.5f;
@@ -596,7 +596,7 @@ __device__ __noinline__ rgb mip_ewa(const DevScene &sc, const DevTexture &tx, in
     return sum / sumWts;
 }
 // ImageTexture::Evaluate (textures/imagemap.h:82-89): UVMapping2D::Map, then MIPMap::Lookup(st, dstdx, dstdy)
-__device__ __noinline__ rgb eval_image_texture(const DevScene &sc, int texId, const DevTexGeom &tg, const DevUvDiff &uv) {
+__device__ __forceinline__ rgb eval_image_texture(const DevScene &sc, int texId, const DevTexGeom &tg, const DevUvDiff &uv) {
     const DevTexture tx = sc.textures[texId];
     float d0x = tx.su * uv.dudx, d0y = tx.sv * uv.dvdx, d1x = tx.su * uv.dudy, d1y = tx.sv * uv.dvdy;
     const float su = tx.su * tg.u + tx.du, sv = tx.sv * tg.v + tx.dv;
@@ -620,7 +620,12 @@ __device__ __noinline__ rgb eval_image_texture(const DevScene &sc, int texId, co
     if (minorLength == 0) return mip_triangle(sc, tx, 0, su, sv);
     const float lod = sel_max((float)0, (int)tx.nLevels - (float)1 + log2_f(minorLength));
     const int ilod = (int)floorf(lod);
-    const rgb a = mip_ewa(sc, tx, ilod, su, sv, d0x, d0y, d1x, d1y), b = mip_ewa(sc, tx, ilod + 1, su, sv, d0x, d0y, d1x, d1y);
+    rgb a(0.f), b(0.f);      // the two levels through one copy of the filter loop (the body is inlined: a call here spills the caller's live state to scratch)
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+        const rgb r = mip_ewa(sc, tx, ilod + k, su, sv, d0x, d0y, d1x, d1y);
+        if (k == 0) a = r; else b = r;
+    }
     return lerp_rgb(lod - ilod, a, b);
 }
 

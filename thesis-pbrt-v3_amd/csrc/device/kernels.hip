@@ -895,9 +895,14 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
                         rd.rxD = rayD + (rd.rxD - rayD) * s; rd.ryD = rayD + (rd.ryD - rayD) * s;
                         compute_differentials(si, tg, rd, &uvd);
                     }
-                    if (m.KdTex >= 0) { kdTex = eval_image_texture(sc, m.KdTex, tg, uvd); useKd = true; }
-                    if (m.KsTex >= 0) { ksTex = eval_image_texture(sc, m.KsTex, tg, uvd); useKs = true; }
-                    if (opTexId >= 0) { opTex = eval_image_texture(sc, opTexId, tg, uvd); useOp = true; }
+                    // one inlined copy of the lookup for the three slots (three call sites of an out-of-line lookup cost a register spill each)
+#pragma unroll 1
+                    for (int k = 0; k < 3; ++k) {
+                        const int id = k == 0 ? m.KdTex : k == 1 ? m.KsTex : opTexId;
+                        if (id < 0) continue;
+                        const rgb r = eval_image_texture(sc, id, tg, uvd);
+                        if (k == 0) { kdTex = r; useKd = true; } else if (k == 1) { ksTex = r; useKs = true; } else { opTex = r; useOp = true; }
+                    }
                 }
             }
             bsdf_init(sc, si, &bsdf, useKd ? &kdTex : nullptr, useKs ? &ksTex : nullptr, useOp ? &opTex : nullptr);
