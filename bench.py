@@ -501,6 +501,25 @@ def main():
         except Exception as e:
             stream_gbs = {"error": repr(e)}
         torch.cuda.empty_cache()
+    # ---- on-box gather ceiling: dependent per-lane fetches of 64-byte records over a BVH-like pick, in k_trace<closest>'s launch
+    # shape and with no arithmetic (kernels.hip, k_gather_probe); the table has as many records as the scene's BVH has child pairs ----
+    gather_peak = None
+    if rank == 0 and world == 1:
+        import ctypes as C
+        try:
+            bi = head.bvh.info()
+            pairs = max(256, bi["nodes"] - bi["leaves"])
+            log2_records = min(26, max(8, int(np.ceil(np.log2(pairs)))))
+            fn = hprt.lib.hprt_debug_gather_probe
+            fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+            best, mean = C.c_double(), C.c_double()
+            if fn(dev.index, log2_records, 2000, 5, C.byref(best), C.byref(mean)) == 0:
+                gather_peak = {"best": round(best.value, 1), "mean": round(mean.value, 1), "records": 1 << log2_records,
+                               "what": "k_gather_probe: every lane fetches its own 64-byte record (4 x b128), next pick depends on the record read, "
+                                       "level of a complete binary tree uniformly then a node of that level; 256 threads, 24 KB LDS, 6 workgroups per CU; 5 launches"}
+        except Exception as e:
+            gather_peak = {"error": repr(e)}
+        torch.cuda.empty_cache()
     lib_hash = code_object_hash(hprt.LIB_PATH)
 
     def attach_counters(roof, workload, live):
@@ -508,6 +527,16 @@ def main():
         bound, HBM traffic and fraction, VALU issue fraction, lane utilisation.  The summary is stamped with the hash of the code
         objects it was taken on; when the loaded library's differs the figures are flagged stale (and `frac` is not filled)."""
         roof["peak_measured"] = stream_gbs
+        if live and gather_peak and gather_peak.get("best"):
+            # what the traversal kernel is actually held against: the rate at which this GPU serves its access pattern.  A child-pair
+            # record is 64 bytes (two nodes of V), a triangle 48 bytes (three of the four 16-byte requests of a record)
+            a = roof["algorithmic"]
+            rec_per_ray = a["nodes_fetched_per_ray"] / 2.0 + 0.75 * a["prim_tests_per_ray"]
+            ach = roof["kernel_mrays_per_s"] * 1e6 * rec_per_ray / 1e9
+            roof["gather"] = {"achieved": round(ach, 1), "peak_measured": gather_peak, "unit": "Grecords/s", "frac": round(ach / gather_peak["best"], 4),
+                              "records_per_ray": round(rec_per_ray, 2),
+                              "note": "child-pair records (V / 2) + triangle records (0.75 T) per ray x k_trace<closest>'s ray rate, over the measured ceiling of "
+                                      "dependent per-lane 64-byte gathers on this GPU: the bound the kernel runs against (its HBM fraction is `frac`)"}
         cf = counters_file()
         if not cf:
             roof["counters_from"] = None

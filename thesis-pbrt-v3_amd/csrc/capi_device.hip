@@ -633,6 +633,23 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) if (o.i2w.m[r][c] != (r == c ? 1.f : 0.f)) ident = false;
         o.identity = ident ? 1u : 0u; o.pad[0] = o.pad[1] = 0u;
     }
+    // Instance primitives of the top level: the transform moves next to the primitive (dev_scene.h, TAG_INST_INLINE / topEntry)
+    std::vector<float4> topEntry;
+    if (d->n_instances) {
+        topEntry.assign(aggs[0].nPrims, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (uint32_t oi = 0; oi < aggs[0].nPrims; ++oi) {
+            const size_t i = (size_t)primBase[0] + oi;
+            const uint32_t tag = f2u(tris[3 * i].w);
+            if ((tag & TAG_KIND_MASK) != TAG_INSTANCE) continue;
+            const DevInstance &in = instances[f2u(tris[3 * i + 2].w)];
+            const float (*m)[4] = in.w2i.m;
+            if (!(m[3][0] == 0.f && m[3][1] == 0.f && m[3][2] == 0.f && m[3][3] == 1.f)) continue;      // projective: the kernel reads DevInstance
+            tris[3 * i] = make_float4(m[0][0], m[0][1], m[0][2], u2f(tag | TAG_INST_INLINE));
+            tris[3 * i + 1] = make_float4(m[1][0], m[1][1], m[1][2], tris[3 * i + 1].w);
+            tris[3 * i + 2] = make_float4(m[2][0], m[2][1], m[2][2], tris[3 * i + 2].w);
+            topEntry[oi] = make_float4(m[0][3], m[1][3], m[2][3], u2f((uint32_t)in.root));
+        }
+    }
     std::vector<int32_t> primes(PrimeTable().begin(), PrimeTable().end()), primeSums(PrimeSumTable().begin(), PrimeSumTable().end());
     std::vector<uint64_t> magic(primes.size());
     for (size_t i = 0; i < primes.size(); ++i) magic[i] = 0xffffffffffffffffull / (uint64_t)primes[i] + 1ull;
@@ -640,7 +657,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     HIP_TRY(upload(sc->nodes, pairs)); HIP_TRY(upload(sc->tris, tris)); HIP_TRY(upload(sc->primVtx, primVtx));
     HIP_TRY(upload(sc->primN, primN)); HIP_TRY(upload(sc->vUV, vUV)); HIP_TRY(upload(sc->vS, vS));
     HIP_TRY(upload(sc->shapes, shapes)); HIP_TRY(upload(sc->materials, mats)); HIP_TRY(upload(sc->lights, lights));
-    HIP_TRY(upload(sc->spheres, spheres)); HIP_TRY(upload(sc->instances, instances)); HIP_TRY(upload(sc->lightFunc, func)); HIP_TRY(upload(sc->lightCdf, cdf));
+    HIP_TRY(upload(sc->spheres, spheres)); HIP_TRY(upload(sc->instances, instances)); HIP_TRY(upload(sc->topEntry, topEntry)); HIP_TRY(upload(sc->lightFunc, func)); HIP_TRY(upload(sc->lightCdf, cdf));
     HIP_TRY(upload(sc->perms, perms)); HIP_TRY(upload(sc->primes, primes)); HIP_TRY(upload(sc->primeSums, primeSums));
     HIP_TRY(upload(sc->primeMagic, magic));
     HIP_TRY(upload(sc->textures, textures)); HIP_TRY(upload(sc->mipLevels, mipLevels)); HIP_TRY(upload(sc->texels, texels)); HIP_TRY(upload(sc->weightLut, weightLut));
@@ -662,6 +679,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     dv.textures = d->n_textures ? sc->textures.as<DevTexture>() : nullptr; dv.mipLevels = sc->mipLevels.as<DevMipLevel>();
     dv.texels = sc->texels.as<float>(); dv.weightLut = sc->weightLut.as<float>();
     dv.instances = sc->instances.as<DevInstance>(); dv.nInstances = d->n_instances;
+    dv.topEntry = topEntry.empty() ? nullptr : sc->topEntry.as<float4>(); dv.nTopPrims = (uint32_t)topEntry.size();
     dv.lightFunc = sc->lightFunc.as<float>(); dv.lightCdf = sc->lightCdf.as<float>(); dv.lightFuncInt = funcInt;
     dv.deepStack = sc->deepStack.as<uint2>();
     dv.perms = sc->perms.as<uint16_t>(); dv.primes = sc->primes.as<int32_t>(); dv.primeSums = sc->primeSums.as<int32_t>();
@@ -783,6 +801,40 @@ __attribute__((visibility("default"))) int hprt_debug_stream_copy(int device, si
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *best_gbs = best; *mean_gbs = sum / iters;
+    return HPRT_OK;
+} catch (...) { return hprt::HandleException(); }
+// Diagnostics hook (not part of include/hprt.h): rate at which the device serves dependent per-lane gathers of 64-byte records
+// over a BVH-like pick from a table of 2^log2_records records (kernels.hip, k_gather_probe) — the measured ceiling bench.py holds
+// k_trace's record rate against.  Out: records per second (1e9), best and mean of `launches` timed launches.
+__attribute__((visibility("default"))) int hprt_debug_gather_probe(int device, int log2_records, int iters_per_lane, int launches, double *best_grecords_s, double *mean_grecords_s) try {
+    if (!best_grecords_s || !mean_grecords_s || log2_records < 8 || log2_records > 26 || iters_per_lane < 1 || iters_per_lane > 100000 || launches < 1 || launches > 100)
+        return SetError(HPRT_E_INVALID, "hprt_debug_gather_probe: bad argument");
+    int dev = 0;
+    if (int rc = CheckDevice(device, &dev)) return rc;
+    HIP_TRY(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 6u * 4u;
+    DevBuf table, sink;
+    const size_t bytes = (size_t)64 << log2_records;
+    HIP_TRY(table.alloc(bytes)); HIP_TRY(sink.alloc(16));
+    HIP_TRY(hipMemset(table.p, 0x5b, bytes));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    LaunchGatherProbe(nullptr, table.as<uint4>(), (uint32_t)log2_records, std::max(1, iters_per_lane / 10), blocks, sink.as<uint32_t>());
+    HIP_TRY(hipDeviceSynchronize());
+    double best = 0, sum = 0;
+    for (int i = 0; i < launches; ++i) {
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        LaunchGatherProbe(nullptr, table.as<uint4>(), (uint32_t)log2_records, iters_per_lane, blocks, sink.as<uint32_t>());
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        const double g = (double)blocks * 256.0 * (double)iters_per_lane / ((double)ms * 1e-3) / 1e9;
+        best = std::max(best, g); sum += g;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *best_grecords_s = best; *mean_grecords_s = sum / launches;
     return HPRT_OK;
 } catch (...) { return hprt::HandleException(); }
 __attribute__((visibility("default"))) int hprt_debug_voxel_points(float out[640]) { if (!out) return HPRT_E_INVALID; VoxelSamplePoints(out); return HPRT_OK; }

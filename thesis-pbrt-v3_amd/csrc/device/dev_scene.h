@@ -57,7 +57,10 @@ enum : int32_t { REF_NONE = (int32_t)0x80000000, REF_EXIT = (int32_t)0x80000001 
 enum : int32_t { VOX_EMPTY = -1, VOX_REQUESTED = -2 };
 
 enum : uint32_t { TAG_KIND_MASK = 3u, TAG_SPHERE = 1u, TAG_INSTANCE = 2u, TAG_BOGUS = 4u, TAG_LAST = 8u,
-                  TAG_BIN_SHIFT = 4u, TAG_BIN_MASK = 7u << 4 };   // bits 4-6: the primitive's shading bin (BIN_*), decided on the host
+                  TAG_BIN_SHIFT = 4u, TAG_BIN_MASK = 7u << 4,      // bits 4-6: the primitive's shading bin (BIN_*), decided on the host
+                  // an instance primitive whose world-to-instance matrix is affine (last row exactly 0 0 0 1) carries the matrix's 3x3
+                  // part in the x, y, z words of its three record words; translation and entry sit in DevScene::topEntry[primitive]
+                  TAG_INST_INLINE = 128u };
 // (tag & TAG_BIN_MASK) << 24 is the bin field of the hit word: k_bin needs nothing but that word
 enum : uint32_t { SHAPE_FLIP = 1u, SHAPE_HAS_N = 2u, SHAPE_HAS_UV = 4u, SHAPE_HAS_S = 8u, SHAPE_REVERSE = 16u };
 
@@ -92,6 +95,9 @@ struct DevScene {
     const DevSphere *spheres; uint32_t nSpheres;
     const DevEnvLight *envLights; const float *envData; uint32_t nEnvLights;      // infinite lights (escaped rays pick up their radiance)
     const DevInstance *instances; uint32_t nInstances;
+    // per top-level primitive (instanced scenes; null when there are none): {m03, m13, m23 of the instance's world-to-instance matrix, its
+    // entry (DevInstance::root)}, fetched together with the primitive record so that entering an instance costs one memory round trip, not two
+    const float4 *topEntry; uint32_t nTopPrims;
     const float *lightFunc, *lightCdf; float lightFuncInt;      // Distribution1D (core/sampling.h:55-109): uniform or power strategy
     // SpatialLightDistribution (core/lightdistrib.cpp:77-300), computed for every voxel at scene creation: per voxel v the
     // Distribution1D's func[nLights] at voxFunc + v * nLights, cdf[nLights + 1] at voxCdf + v * (nLights + 1), funcInt at voxFuncInt[v]

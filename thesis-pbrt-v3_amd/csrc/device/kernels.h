@@ -113,6 +113,7 @@ void LaunchVoxelDistributions(hipStream_t st, const DevScene &sc, const float *r
 // on-demand mode: the `n` voxels listed in sc.voxRequest get rows rowBase .. rowBase + n - 1 (voxSlot is updated), their distributions are computed
 void LaunchVoxelFill(hipStream_t st, const DevScene &sc, const float *ri, uint32_t n, uint32_t rowBase, float *func, float *cdf, float *funcInt);
 void LaunchStreamCopy(hipStream_t st, const float4 *src, float4 *dst, size_t n);
+void LaunchGatherProbe(hipStream_t st, const uint4 *records, uint32_t log2Records, int itersPerLane, uint32_t blocks, uint32_t *sink);
 // diagnostics: the rays a queue lists, as [7][cap] planes (the layout of the *_device entry points)
 void LaunchCaptureRays(hipStream_t st, const uint32_t *queue, uint32_t n, const RayStream &rays, float *out7, uint32_t cap);
 void LaunchFilmApplyRecords(hipStream_t st, const FilmRecord *rec, const uint32_t *destBegin, uint32_t nDest, float *film);

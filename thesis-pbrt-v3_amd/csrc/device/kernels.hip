@@ -261,6 +261,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
     // requests per pair and three per primitive, issued together.
     const auto pairRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.pairs, 0, (int)(sc.nPairs * 64u), 0x00020000);
     const auto triRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.tris, 0, (int)(sc.nPrims * 48u), 0x00020000);
+    // INST: translation and entry of the instance a top-level primitive stands for (dev_scene.h, topEntry); a request past the table reads as zero
+    const auto entryRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(INST ? sc.topEntry : nullptr), 0, (int)(INST ? sc.nTopPrims * 16u : 0u), 0x00020000);
     const float robust = 1 + 2 * gamma_n(3);
     TraceCount cnt = {0u, 0u, 0u, 0u, 0u};
     unsigned int snapEntered = 0u, snapLeaf = 0u, snapPrim = 0u;     // counter values when the lane's current ray started (per-ray statistics)
@@ -455,6 +457,9 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                 if (nPending != 0 && nPending < tune.primMin && __ballot(active && cur >= 0) != 0ull) break;
                 if (nPending != 0) {
                     if (PROF) { pf[7] += 1; pf[8] += nPending; }
+                    // (two-level scenes: leaving an instance, entering one and a triangle test share the iteration.  One kind per iteration — the
+                    // one most lanes wait for — was measured: twice the iterations at 55 % of the cycles each, 13 % fewer rays per second on
+                    // instanced-10m.  An iteration costs its memory round trip, not its instructions.)
                     if (INST && todo && cur == REF_EXIT) {
                         // the instance's walk is over, back to world space: r.tMax = ray.tMax only if the instance was
                         // hit (core/primitive.cpp:85-86); continue with the top-level leaf the instance belongs to
@@ -478,6 +483,13 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                         u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 32, 0, 0);
                         // keep the three requests whole and in flight together (hipcc otherwise narrows the
                         // second one and sinks it behind the tag test: a second, dependent memory round trip)
+                        u32x4 ve = {0u, 0u, 0u, 0u};
+                        if (INST) {
+                            // a top-level primitive may be an instance: its translation and entry travel with the record (one round trip
+                            // for the whole entry instead of record -> DevInstance)
+                            if (inst < 0) ve = __builtin_amdgcn_raw_buffer_load_b128(entryRsrc, pi * 16, 0, 0);
+                            asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(ve));
+                        } else
                         asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2));
                         const uint32_t tag = v0.w;
                         if ((tag & TAG_KIND_MASK) == 0u) {
@@ -499,10 +511,18 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                             inst = (int)v2.w;
                             instPrim = pi | ((tag & TAG_LAST) ? 0x80000000u : 0u);
                             instHit = false;
-                            const DevInstance &in = sc.instances[inst];
+                            mat4 W;
+                            int root;
+                            if (tag & TAG_INST_INLINE) {      // affine: the matrix came with the primitive
+                                W.m[0][0] = __uint_as_float(v0.x); W.m[0][1] = __uint_as_float(v0.y); W.m[0][2] = __uint_as_float(v0.z); W.m[0][3] = __uint_as_float(ve.x);
+                                W.m[1][0] = __uint_as_float(v1.x); W.m[1][1] = __uint_as_float(v1.y); W.m[1][2] = __uint_as_float(v1.z); W.m[1][3] = __uint_as_float(ve.y);
+                                W.m[2][0] = __uint_as_float(v2.x); W.m[2][1] = __uint_as_float(v2.y); W.m[2][2] = __uint_as_float(v2.z); W.m[2][3] = __uint_as_float(ve.z);
+                                W.m[3][0] = 0.f; W.m[3][1] = 0.f; W.m[3][2] = 0.f; W.m[3][3] = 1.f;
+                                root = (int)ve.w;
+                            } else { const DevInstance &in = sc.instances[inst]; W = in.w2i; root = in.root; }
                             vec3 oErr;
-                            vec3 o2 = xf_point_err(in.w2i, ro, &oErr);
-                            const vec3 d2 = xf_vector(in.w2i, vec3(worldRay[3 * HPRT_TRACE_BLOCK], worldRay[4 * HPRT_TRACE_BLOCK], worldRay[5 * HPRT_TRACE_BLOCK]));
+                            vec3 o2 = xf_point_err(W, ro, &oErr);
+                            const vec3 d2 = xf_vector(W, vec3(worldRay[3 * HPRT_TRACE_BLOCK], worldRay[4 * HPRT_TRACE_BLOCK], worldRay[5 * HPRT_TRACE_BLOCK]));
                             const float lengthSquared = d2.x * d2.x + d2.y * d2.y + d2.z * d2.z;
                             float tm = rayTMax;
                             if (lengthSquared > 0) {
@@ -519,7 +539,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                                                     ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
                         if (PACKED) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
                             shear = ray_shear(d2);
-                            cur = in.root;
+                            cur = root;
                         } else if (QUAD) {
                             // a quadric: the cheap exact pre-test (dev_intersect.h) settles most of them here; the rest wait for
                             // the batched interval-arithmetic test
@@ -1358,6 +1378,11 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     if (!anyHit && !tuneFromEnv && sc.nPairs > 100000u) { tune.parkLimit = 32; tune.stepLimit = 14; tune.primMin = 12; }      // (round-2 sweep, tools/sweep_tune.sh: atrium +3.6 %, living room +-0)
     static const bool profile = getenv("HPRT_TRACE_PROFILE") != nullptr;
     const bool inst = sc.nInstances != 0u, quad = sc.nSpheres != 0u;
+    // two-level scenes: a primitive-phase iteration that enters an instance costs two dependent memory round trips (the primitive, then
+    // the instance's transform), so fewer, fuller iterations pay (tools/sweep_inst_tune.sh on instanced-10m: closest +7.6 %, any hit +5 %)
+    static const bool tuneAnyFromEnv = getenv("HPRT_TRACE_TUNE_ANY") != nullptr;
+    if (inst && !anyHit && !tuneFromEnv) { tune.parkLimit = 32; tune.stepLimit = 10; tune.primMin = 12; }
+    if (inst && anyHit && !tuneAnyFromEnv) { tune.refillBelow = 48; tune.parkLimit = 32; tune.stepLimit = 10; tune.primMin = 6; }
 #define HPRT_TRACE_LAUNCH(A, M, I, Q) hipLaunchKernelGGL((k_trace<A, M, I, Q>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, rayStats, workCounter, chunk, tune)
     // (the profiling variant exists with the quadric code only)
 #define HPRT_TRACE_PICK(A, M) do { if (inst) { if (quad || M == 2) HPRT_TRACE_LAUNCH(A, M, true, true); else HPRT_TRACE_LAUNCH(A, M, true, (M == 2)); } \
@@ -1499,6 +1524,27 @@ __global__ __launch_bounds__(256) void k_stream_copy(const float4 *__restrict__ 
 }
 void LaunchStreamCopy(hipStream_t st, const float4 *src, float4 *dst, size_t n) {
     if (n) hipLaunchKernelGGL(k_stream_copy, dim3((uint32_t)((n + 1023) / 1024)), dim3(256), 0, st, src, dst, n);
+}
+// On-box ceiling of the access pattern k_trace lives on (bench.py's roofline.gather): every lane fetches its own 64-byte record
+// with four 16-byte loads, the next record depending on the one just read, records picked the way a traversal picks BVH nodes
+// (a level of a complete binary tree uniformly, then a node of that level: the top of the tree stays in L1 / L2, the bottom does
+// not).  Launch shape of k_trace<closest>: 256 threads, 24 KB of LDS, six workgroups per CU.  No arithmetic besides the pick.
+__global__ __launch_bounds__(256, 6) void k_gather_probe(const uint4 *__restrict__ rec, uint32_t mask, uint32_t levels, int iters, uint32_t *out) {
+    __shared__ uint32_t occupancyPad[6144];
+    uint32_t idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u, acc = 0;
+    if (threadIdx.x == 999u) occupancyPad[0] = 1u;
+    for (int it = 0; it < iters; ++it) {
+        idx = idx * 1664525u + 1013904223u;
+        const uint32_t l = (idx >> 3) % levels;
+        const uint32_t r = ((1u << l) | ((idx >> 8) & ((1u << l) - 1u))) & mask;
+        const uint4 a = rec[4 * r], b = rec[4 * r + 1], c = rec[4 * r + 2], d = rec[4 * r + 3];
+        acc += a.x ^ b.y ^ c.z ^ d.w;
+        idx ^= a.x;
+    }
+    if (acc == 0x12345678u) out[0] = acc + occupancyPad[threadIdx.x];
+}
+void LaunchGatherProbe(hipStream_t st, const uint4 *records, uint32_t log2Records, int itersPerLane, uint32_t blocks, uint32_t *sink) {
+    hipLaunchKernelGGL(k_gather_probe, dim3(blocks), dim3(256), 0, st, records, (1u << log2Records) - 1u, log2Records, itersPerLane, sink);
 }
 void LaunchPackRays(hipStream_t st, const float *rays7, uint32_t n, const RayStream &out) {
     if (n) hipLaunchKernelGGL(k_pack_rays, dim3(blocks_for(n, 256)), dim3(256), 0, st, rays7, n, out);

@@ -60,7 +60,7 @@ struct HprtScene {
     hipEvent_t lastUse = nullptr; bool lastUsePending = false;
     hprt::DevScene dev;
     hprt::DevBuf textures, mipLevels, texels, weightLut;
-    hprt::DevBuf nodes, tris, primVtx, primN, vUV, vS, shapes, materials, lights, spheres, instances, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
+    hprt::DevBuf nodes, tris, primVtx, primN, vUV, vS, shapes, materials, lights, spheres, instances, topEntry, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
     hprt::DevBuf envLights, envData;      // infinite lights: DevEnvLight table and their Distribution2D tables
     hprt::DevBuf counters, workCounter, deepStack;
     // hprt_debug_capture_rays (tools/sort_experiment.py): the next render copies the rays one bounce queues into a caller buffer

@@ -22,6 +22,11 @@ elif args.scene == "instanced":
     text, ntri = scene_gen.instanced()
     path = os.path.join(tmp, "instanced.pbrt"); open(path, "w").write(text)
     model = hprt.Model.parse(path)
+elif args.scene == "instanced-10m":      # BASELINE.json configs[4] (bench.py's secondary workload)
+    import scene_gen
+    text, ntri = scene_gen.instanced_killeroo(os.path.join(ROOT, "tests", "golden", "killeroo.hprt"))
+    path = os.path.join(tmp, "instanced10m.pbrt"); open(path, "w").write(text)
+    model = hprt.Model.parse(path)
 elif args.scene.endswith(".hprt"):
     model = hprt.Model.load(args.scene)
 else:

@@ -14,6 +14,13 @@ if which == "killeroo":
     model = hprt.Model.load(FIX)
 elif which.endswith(".hprt"):
     model = hprt.Model.load(which)
+elif which == "instanced-10m":      # BASELINE.json configs[4]
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scene_gen
+    text, _ = scene_gen.instanced_killeroo(os.path.join(ROOT, "tests", "golden", "killeroo.hprt"))
+    path = os.path.join(tempfile.mkdtemp(), "instanced10m.pbrt"); open(path, "w").write(text)
+    model = hprt.Model.parse(path)
 else:
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tools"))
