@@ -29,9 +29,13 @@ Extra objects in the line:
   roofline      dominant kernel = k_trace<closest>.  `frac` = MEASURED HBM traffic of that kernel (FETCH_SIZE / WRITE_SIZE PMC passes of
                 the committed summary profiles/rNN_counters.json, per launch) / this run's HIP-event launch time / the 8 TB/s HBM3E
                 peak: at most 1 by construction; `peak_measured` = a float4 stream copy run inside this process (what a stream kernel
-                reaches on THIS box) with `frac_of_measured_peak`.  `bound` is read off the counters: "valu_issue" when the VALU issue
-                fraction (SQ_ACTIVE_INST_VALU * 4 / (1,024 SIMDs * kernel cycles), cycles = GRBM_GUI_ACTIVE / 8) exceeds the HBM fraction —
-                it does: the walk is issue-bound on divergent lanes — with `lane_utilisation` and `useful_lane_frac` = issue x lanes.
+                reaches on THIS box) with `frac_of_measured_peak`.  `bound` names the largest of three measured fractions
+                (`bound_candidates`), each of a peak and so at most 1: "hbm" (`frac`); "valu_issue" = SQ_INSTS_VALU * 2 / (1,024 SIMDs *
+                kernel cycles), cycles = GRBM_GUI_ACTIVE / 8 — CDNA4's SIMD-32 issues one wave64 instruction per two clocks — with
+                `lane_utilisation` and `useful_lane_frac` = issue x lanes; "l1_gather" (`gather`) = the 64-byte child-pair and 48-byte
+                triangle records the kernel fetches per second (V / 2 + 0.75 T per ray, counted by the kernel, x its ray rate) over the
+                rate at which THIS GPU serves dependent per-lane 64-byte gathers on a BVH-like pick (k_gather_probe, run inside this
+                process in k_trace's launch shape with no arithmetic at all).  That is the one that binds: the walk runs at ~0.9 of it.
                 The summary is stamped with the sha256 of the code objects it was measured on; `counters_stale` says when the loaded
                 library's differ (then `frac` falls back to the summary's own launch time and the flag tells).  The contract's model
                 figure — algorithmic bytes (32 B per BVH node fetched + 48 B per primitive test + 28 B ray + 20 B hit; V
@@ -567,14 +571,21 @@ def main():
             for f in ("valu_issue_frac", "lane_utilisation", "useful_lane_frac", "wait_frac", "effective_clock_mhz"):
                 if tc and f in tc:
                     roof[f] = tc[f]
-            # what binds the kernel, from the counters: the VALU issue rate (fraction of the SIMDs' issue slots taken by VALU
-            # instructions) against the HBM fraction
-            if tc and "valu_issue_frac" in tc and roof.get("frac") is not None:
-                roof["bound"] = "valu_issue" if tc["valu_issue_frac"] >= roof["frac"] else "hbm"
-                roof["bound_frac"] = max(tc["valu_issue_frac"], roof["frac"])
-            elif roof.get("frac") is not None:
-                roof["bound"] = "hbm"
-            roof["per_kernel"] = {name: {f: v[f] for f in ("lane_utilisation", "valu_issue_frac", "useful_lane_frac", "wait_frac", "avg_launch_ms", "launches", "hbm_gbs", "hbm_frac") if f in v}
+            # what binds the kernel: the largest of the three measured fractions — HBM traffic over the HBM peak (counters), VALU
+            # instructions over the SIMDs' issue rate (counters; one wave64 instruction per two clocks, tools/counters_summary.py), and
+            # record fetches over the measured gather ceiling (live, `gather`).  Each is a fraction of a peak: none can exceed 1.
+            cand = {}
+            if roof.get("frac") is not None:
+                cand["hbm"] = roof["frac"]
+            if tc and tc.get("valu_issue_frac") is not None:
+                cand["valu_issue"] = tc["valu_issue_frac"]
+            if roof.get("gather"):
+                cand["l1_gather"] = roof["gather"]["frac"]
+            if cand:
+                roof["bound"] = max(cand, key=cand.get)
+                roof["bound_frac"] = cand[roof["bound"]]
+                roof["bound_candidates"] = cand
+            roof["per_kernel"] = {name: {f: v[f] for f in ("lane_utilisation", "valu_issue_frac", "useful_lane_frac", "wait_frac", "avg_launch_ms", "launches", "hbm_gbs", "hbm_frac", "l1_accesses_per_clk_cu", "l1_miss_rate", "l2_hit_rate") if f in v and v[f] is not None}
                                   for name, v in k.items()}
             roof["hbm_bytes_per_step"] = cj.get("hbm_bytes_per_step")
             roof["step_hbm_frac"] = cj.get("step_hbm_frac")
