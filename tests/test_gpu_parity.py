@@ -515,3 +515,29 @@ def test_few_waves_working_through_many_queue_chunks(tmp_path, killeroo_oracle):
         killeroo_oracle.set_film(crop=(0, 1, 0, 1), spp=8)
     bad = (got.view(np.uint32) != film0.view(np.uint32)).any(axis=2)
     assert not bad.any(), "%d of %d pixels differ from the oracle's film" % (int(bad.sum()), bad.size)
+
+
+def test_bench_line_holds_fractions_of_measured_peaks():
+    """One short single-GPU run of bench.py: every figure the `roofline` object calls a fraction is one (of a peak measured or
+    specified: never above 1), the two probes it runs inside the process report plausible MI355X rates, and the committed counter
+    summary carries the stamp that `counters_stale` is decided by."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "killeroo-simple", "--steps", "1", "--warmup", "1", "--no-secondary", "--no-cpu-baseline",
+           "--no-trace-all"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    roof = line["roofline"]
+    assert line["metric"] and line["n_gpus"] == 1 and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert 3000 < roof["peak_measured"]["best"] <= 8000           # a stream copy on an MI355X: 5-6.5 TB/s
+    g = roof["gather"]
+    assert 100 < g["peak_measured"]["best"] < 400 and 0 < g["frac"] <= 1 and g["peak_measured"]["bvh_like"]["best"] <= g["peak_measured"]["best"] * 1.02
+    assert isinstance(roof["counters_stale"], bool) and roof["counters_code_object_sha256"] and roof["library_code_object_sha256"]
+    if roof["frac"] is not None:
+        assert 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+        assert roof["bound"] in ("hbm", "valu_issue", "l1_gather") and all(0 < v <= 1 for v in roof["bound_candidates"].values())
+        for name, k in roof["per_kernel"].items():
+            for f in ("hbm_frac", "valu_issue_frac", "useful_lane_frac", "lane_utilisation", "wait_frac"):
+                assert f not in k or 0 <= k[f] <= 1.0001, (name, f, k[f])
