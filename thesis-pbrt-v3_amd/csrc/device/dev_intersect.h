@@ -15,6 +15,17 @@ struct DRay { vec3 o, d; float tMax; };
 // and the shear coefficients depend on the ray alone, so they are computed once per ray
 // (same operations, same values) instead of once per triangle test.
 struct RayShear { bool k0, k1; float Sx, Sy, Sz; };     // k0: kz == 0, k1: kz == 1
+// (with the ray's 1 / d at hand — the walk keeps it for the slab tests: Sz = 1.f / d[kz] IS invDir[kz], the same IEEE quotient: one division fewer)
+__device__ __forceinline__ RayShear ray_shear(vec3 rd, vec3 invDir) {
+    RayShear s;
+    const int kz = max_dim(vabs(rd));
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    const float dx = rd.get(kx), dy = rd.get(ky), dz = rd.get(kz);
+    s.k0 = kz == 0; s.k1 = kz == 1;
+    s.Sx = -dx / dz; s.Sy = -dy / dz; s.Sz = invDir.get(kz);
+    return s;
+}
 __device__ __forceinline__ RayShear ray_shear(vec3 rd) {
     RayShear s;
     const int kz = max_dim(vabs(rd));

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                         invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
                                                 ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
                         if (PACKED) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
-                        shear = ray_shear(rd);
+                        shear = ray_shear(rd, invDir);
                         sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
                         wait = 0u; inst = -1; hitInst = -1; instHit = false;
                         if (INST) {
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                         invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
                                                 ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
                         if (PACKED) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
-                        shear = ray_shear(rd);
+                        shear = ray_shear(rd, invDir);
                         rayTMax = worldT;
                         inst = -1; instHit = false;
                         if (instPrim & 0x80000000u) cur = pop();
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                                          vec3(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
                                          vec3(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z)), ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
                                 if (ANY_HIT) { hit = true; done = true; }
-                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)(pi | (((INST && inst >= 0) ? (((tag & TAG_BIN_MASK) >> TAG_BIN_SHIFT) == BIN_TEXTURED ? BIN_TEXTURED : BIN_GENERIC) << TAG_BIN_SHIFT : (tag & TAG_BIN_MASK)) << 24)); hb0 = b0; hb1 = b1; hb2 = b2; if (INST) { hitInst = inst; instHit = inst >= 0; } }
+                                else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)(pi | ((tag & TAG_BIN_MASK) << 24)); hb0 = b0; hb1 = b1; hb2 = b2; if (INST) { hitInst = inst; instHit = inst >= 0; } }
                             }
                             if (done) cur = REF_NONE;
                             else if (tag & TAG_LAST) cur = pop();
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                             invDir = vec3(1 / d2.x, 1 / d2.y, 1 / d2.z);
                                                     ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
                         if (PACKED) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
-                            shear = ray_shear(d2);
+                            shear = ray_shear(d2, invDir);
                             cur = root;
                         } else if (QUAD) {
                             // a quadric: the cheap exact pre-test (dev_intersect.h) settles most of them here; the rest wait for
@@ -785,7 +785,9 @@ __global__ __launch_bounds__(1024) void k_bin(DevScene sc, PathStream in, HitStr
 #ifndef HPRT_SHADE_WAVES_SUBSTRATE
 #define HPRT_SHADE_WAVES_SUBSTRATE 4
 #endif
-template <int MODE, int BS, bool TEX = false>
+// INSTS: the scene has object instances — the specialised variants then carry the instance transform as well (a hit inside an instance keeps
+// its material's bin); without instances that code is compiled out of them.
+template <int MODE, int BS, bool TEX = false, bool INSTS = false>
 __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 ? HPRT_SHADE_WAVES_PLASTIC : MODE == 3 ? HPRT_SHADE_WAVES_SUBSTRATE : HPRT_SHADE_WAVES_GENERIC) void k_shade(DevScene sc, RenderParams rp, PathStream in, HitStream hit, uint32_t s0,
                                                PathStream out, VertexStreams vs, QueueSet q, BinSet bins, float4 *Lfinal, uint32_t firstBounce, uint32_t retryPass) {
     __shared__ HaltonLds hl;
@@ -841,9 +843,9 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
             const float2 hitB = hit.b[slot];
             // A hit inside an object instance was found by the instance-space ray: the surface interaction is
             // filled there and transformed back (TransformedPrimitive::Intersect, core/primitive.cpp:77-93)
-            const int inst = MODE == 2 ? __float_as_int(hitB.y) : -1;
+            const int inst = (MODE == 2 || INSTS) ? __float_as_int(hitB.y) : -1;
             DRay r0; r0.o = rayO; r0.d = rayD; r0.tMax = rayA.w;
-            if (MODE == 2 && inst >= 0) {      // Transform::operator()(const Ray &), core/transform.h:251-264
+            if ((MODE == 2 || INSTS) && inst >= 0) {      // Transform::operator()(const Ray &), core/transform.h:251-264
                 const DevInstance &in = sc.instances[inst];
                 vec3 oErr;
                 r0.o = xf_point_err(in.w2i, rayO, &oErr);
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
                 float tt;
                 fill_sphere(sc, (int)__float_as_uint(sc.tris[3 * prim + 1].w), r0, &si, &tt, texScene ? &tg : nullptr);
             }
-            if (MODE == 2 && inst >= 0 && !sc.instances[inst].identity) {
+            if ((MODE == 2 || INSTS) && inst >= 0 && !sc.instances[inst].identity) {
                 // Transform::operator()(const SurfaceInteraction &), core/transform.cpp:262-297
                 const DevInstance &in = sc.instances[inst];
                 vec3 pErr;
@@ -1436,7 +1438,8 @@ void LaunchShade(hipStream_t st, int mode, const DevScene &sc, const RenderParam
     const bool specialised = mode == (int)BIN_MATTE || mode == (int)BIN_PLASTIC || mode == (int)BIN_SUBSTRATE;
     const uint32_t bs = !specialised ? 256u : (shadeCfg == 0 ? 1024u : shadeCfg == 1 ? 512u : 256u);
     dim3 grid(blocks_for(gridItems, bs)), block(bs);
-#define HPRT_SHADE_LAUNCH(M, B) hipLaunchKernelGGL((k_shade<M, B>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal, firstBounce ? 1u : 0u, retryPass ? 1u : 0u)
+#define HPRT_SHADE_LAUNCH_I(M, B, I) hipLaunchKernelGGL((k_shade<M, B, false, I>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal, firstBounce ? 1u : 0u, retryPass ? 1u : 0u)
+#define HPRT_SHADE_LAUNCH(M, B) do { if (M != 2 && sc.nInstances != 0u) HPRT_SHADE_LAUNCH_I(M, B, (M != 2)); else HPRT_SHADE_LAUNCH_I(M, B, false); } while (0)
 #define HPRT_SHADE_PICK(M) switch (shadeCfg) { case 0: HPRT_SHADE_LAUNCH(M, 1024); break; case 1: HPRT_SHADE_LAUNCH(M, 512); break; default: HPRT_SHADE_LAUNCH(M, 256); break; }
     if (mode == 3) hipLaunchKernelGGL((k_shade<2, 256, true>), grid, block, 0, st, sc, rp, in, hit, s0, out, vs, q, bins, Lfinal, firstBounce ? 1u : 0u, retryPass ? 1u : 0u);
     else if (mode == 2) { HPRT_SHADE_LAUNCH(2, 256); }
