@@ -240,6 +240,16 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
     // measured too: 2 % slower than storage order.  Closest-hit rays keep the reference's order: ties in t (shared edges)
     // are resolved by it.
     constexpr bool FREE_ORDER = ANY_HIT && MODE == 0;
+    // DEFER (order-free any-hit walks of plain triangle scenes; -DHPRT_DEFER_LEAF, an experiment kept for the record): a lane that reaches a
+    // leaf does not wait for the primitive phase with it but keeps it aside (`pend`, one entry) and walks on with its stack, so that the phase
+    // finds more lanes with a leaf.  Bit-identical films; any-hit rays per second -2.8 % on the atrium, -2.0 % in the living
+    // room (profiles/r03_defer_leaf_ab.txt): the steps a lane takes before its leaf is tested are wasted whenever that leaf holds the hit.
+#ifdef HPRT_DEFER_LEAF
+    constexpr bool DEFER = FREE_ORDER && !INST && !QUAD;
+#else
+    constexpr bool DEFER = false;
+#endif
+    int pend = REF_NONE;
     constexpr bool HPRT_INLINE_PRETEST = true;
     unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned int pfPush = 0u, pfSpill = 0u;      // PROF: stack pushes, and those beyond the LDS entries (scratch)
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                         if (PACKED) negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
                         shear = ray_shear(rd, invDir);
                         sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
-                        wait = 0u; inst = -1; hitInst = -1; instHit = false;
+                        wait = 0u; inst = -1; hitInst = -1; instHit = false; pend = REF_NONE;
                         if (INST) {
                             worldRay[0] = ra.x; worldRay[HPRT_TRACE_BLOCK] = ra.y; worldRay[2 * HPRT_TRACE_BLOCK] = ra.z;
                             worldRay[3 * HPRT_TRACE_BLOCK] = rb.x; worldRay[4 * HPRT_TRACE_BLOCK] = rb.y; worldRay[5 * HPRT_TRACE_BLOCK] = rb.z;
@@ -439,6 +449,10 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                         if (COUNT && !single) { ++cnt.fetched; if (hitF) { ++cnt.entered; if (refF < 0) ++cnt.leaf; } }
                         cur = hitF ? refF : pop();
                     }
+                    if (DEFER) {
+                        if (is_parked(cur) && pend == REF_NONE && sp > 0) { pend = cur; cur = pop(); }      // set the leaf aside, walk on
+                        else if (cur == REF_NONE && pend != REF_NONE) { cur = pend; pend = REF_NONE; }      // nothing left to walk: the leaf set aside
+                    }
                 }
                 ++steps;
                 if (steps >= tune.stepLimit || __popcll(__ballot(active && (INST ? wants_prim_phase(cur) : is_parked(cur)) && wait == 0u)) >= tune.parkLimit) break;
@@ -451,11 +465,13 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
             // different times, so a lane that meets one waits (wait = 1) until `sphereLimit`
             // lanes wait or nothing else can run, and the test runs once for all of them.
             while (true) {
-                const bool todo = active && (INST ? wants_prim_phase(cur) : is_parked(cur)) && wait == 0u;
+                const bool hasPend = DEFER && active && pend != REF_NONE && cur >= 0;      // walking, with a leaf set aside
+                const bool todo = active && ((INST ? wants_prim_phase(cur) : is_parked(cur)) || hasPend) && wait == 0u;
                 const int nPending = __popcll(__ballot(todo));
                 // too few parked lanes for a primitive test to pay: let the others walk first
                 if (nPending != 0 && nPending < tune.primMin && __ballot(active && cur >= 0) != 0ull) break;
                 if (nPending != 0) {
+                    if (hasPend) { const int t = cur; cur = pend; pend = t; }      // test the leaf now; the pair to walk on with waits in `pend`
                     if (PROF) { pf[7] += 1; pf[8] += nPending; }
                     // (two-level scenes: leaving an instance, entering one and a triangle test share the iteration.  One kind per iteration — the
                     // one most lanes wait for — was measured: twice the iterations at 55 % of the cycles each, 13 % fewer rays per second on
@@ -505,8 +521,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
                                 if (ANY_HIT) { hit = true; done = true; }
                                 else if (!(tag & TAG_BOGUS)) { hit = true; rayTMax = t; prim = (int32_t)(pi | ((tag & TAG_BIN_MASK) << 24)); hb0 = b0; hb1 = b1; hb2 = b2; if (INST) { hitInst = inst; instHit = inst >= 0; } }
                             }
-                            if (done) cur = REF_NONE;
-                            else if (tag & TAG_LAST) cur = pop();
+                            if (done) { cur = REF_NONE; pend = REF_NONE; }
+                            else if (tag & TAG_LAST) { if (DEFER && pend != REF_NONE) { cur = pend; pend = REF_NONE; } else cur = pop(); }
                             else --cur;                                  // ~(pi + 1)
                         } else if (INST && (tag & TAG_KIND_MASK) == TAG_INSTANCE) {
                             // TransformedPrimitive::Intersect: Ray ray = Inverse(InterpolatedPrimToWorld)(r), i.e.
