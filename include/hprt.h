@@ -343,7 +343,7 @@ int hprt_write_pfm(const char *path, const float *rgb, int width, int height);
 /* r, r+n, ... (HprtRenderDesc::tile_begin / tile_stride) with                */
 /* HPRT_RENDER_EXPORT_FOREIGN and ONE RCCL step over xGMI lands the frame on  */
 /* the root: ncclReduce(sum) of the per-rank films (disjoint addends: exact)  */
-/* plus a grouped ncclSend/ncclRecv of the few cross-tile records, which the  */
+/* then a grouped ncclSend/ncclRecv of the few cross-tile records, which the  */
 /* root adds per pixel in ascending source-tile order — the order of the      */
 /* single-GPU film, so the n-GPU film equals it bit for bit.                  */
 /* ------------------------------------------------------------------------ */
@@ -363,7 +363,7 @@ void hprt_comm_destroy(HprtComm *c);
  * other ranks' buffers are unspecified.  Blocks until `stream` is done.
  * Errors are collective-safe: a rank whose own arguments or state are unusable still takes part in the first (count)
  * exchange and reports the failure through it, so EVERY rank returns an error and none waits for a peer that left;
- * an error inside the grouped reduce / send / recv closes the group before it is returned. */
+ * an error of the reduce or inside the send / recv group is returned only after the group is closed. */
 int hprt_film_gather(HprtComm *c, HprtScene *s, float *d_film_xyzw, size_t n_pixels, int root, void *stream);
 /* The same for ONE process that drives n GPUs with one HprtScene each (how an adapter inside pbrt would: the proposal
  * of SURVEY.md §8(b)); communicators come from ncclCommInitAll on first use.  d_films may be NULL (every scene's own film). */

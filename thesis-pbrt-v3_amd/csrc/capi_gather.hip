@@ -177,8 +177,11 @@ int hprt_film_gather(HprtComm *c, HprtScene *s, float *d_film_xyzw, size_t n_pix
     constexpr size_t kWords = sizeof(FilmRecord) / sizeof(uint32_t);
     ncclResult_t firstErr = ncclSuccess; const char *firstWhat = "";
     auto note = [&](ncclResult_t r, const char *what) { if (r != ncclSuccess && firstErr == ncclSuccess) { firstErr = r; firstWhat = what; } };
-    NCCL_TRY(ncclGroupStart());
+    // (the reduce on its own, the point-to-point transfers as one group after it: every rank issues the same two steps in the same
+    // order on the same stream, and nothing rests on how a group that mixes a collective with send / recv is scheduled)
+    // (an error is kept, not returned at once: this rank still issues its transfers, so that no peer waits for them)
     note(ncclReduce(film, film, 4 * n_pixels, ncclFloat, ncclSum, root, c->comm, st), "ncclReduce");
+    note(ncclGroupStart(), "ncclGroupStart");
     if (c->rank == root) {
         for (int r = 0; r < n; ++r)
             if (r != root && c->hostCounts[r])
