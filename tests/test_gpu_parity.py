@@ -541,3 +541,56 @@ def test_bench_line_holds_fractions_of_measured_peaks():
         for name, k in roof["per_kernel"].items():
             for f in ("hbm_frac", "valu_issue_frac", "useful_lane_frac", "lane_utilisation", "wait_frac"):
                 assert f not in k or 0 <= k[f] <= 1.0001, (name, f, k[f])
+
+
+def _hard_rays(nodes, n, seed):
+    """Rays that exercise the corners of the bounds test: zero direction components of either sign (1 / 0 = inf, 0 * inf = NaN),
+    origins exactly on planes of BVH nodes, finite segments, rays aimed at leaves from far outside."""
+    lo = nodes[:, 0:3].view(np.float32); hi = nodes[:, 3:6].view(np.float32)
+    rng = np.random.default_rng(seed)
+    ext = hi[0] - lo[0]
+    o = (lo[0] + rng.uniform(-0.2, 1.2, (n, 3)) * ext).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    k = n // 8
+    d[:k, 0] = 0.0; d[k:2 * k, 1] = -0.0; d[2 * k:3 * k, 0] = 0.0; d[2 * k:3 * k, 2] = -0.0
+    pick = rng.integers(0, nodes.shape[0], 2 * k); ax = rng.integers(0, 3, 2 * k)
+    o[np.arange(2 * k), ax] = np.where(rng.integers(0, 2, 2 * k) == 1, hi[pick, ax], lo[pick, ax])
+    aim = rng.integers(0, nodes.shape[0], k)
+    d[3 * k:4 * k] = ((lo[aim] + hi[aim]) * np.float32(0.5) - o[3 * k:4 * k]).astype(np.float32)
+    tmax = np.full(n, np.inf, np.float32)
+    tmax[n // 2:] = rng.uniform(0, 2.0, n - n // 2).astype(np.float32) * np.float32(np.linalg.norm(ext) / max(1e-6, float(np.abs(d).mean())))
+    return o, d, tmax
+
+
+@pytest.mark.parametrize("fixture", ["killeroo.hprt", "living_room.hprt"])
+def test_wide_and_binary_walks_agree(hprt, orc, fixture):
+    """Plain calls take the leaf-exact four-wide walk (k_walk4, csrc/wide_bvh.h); hprt_debug_wide_walk(0) keeps the binary walk
+    (k_trace).  Both must return the oracle's hits bit for bit — also for rays on which the bounds test meets inf and NaN."""
+    import ctypes as C
+    import os
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, fixture)
+    model = hprt.Model.load(path)
+    if fixture == "living_room.hprt":      # the oracle reads finished pyramids only (DESIGN.md section 6)
+        import tempfile
+        path = os.path.join(tempfile.mkdtemp(), "expanded.hprt"); model.save(path)
+    bvh = hprt.Bvh(model)
+    scene = hprt.Scene(model, bvh)
+    oracle = orc.OracleScene(path)
+    nodes, _ = bvh.arrays()
+    n = 400000 if fixture == "killeroo.hprt" else 150000
+    o, d, tmax = _hard_rays(nodes, n, 17)
+    t0, p0, b0, _ = oracle.intersect(o, d, tmax)
+    occ0, _ = oracle.occluded(o, d, tmax)
+    hprt.lib.hprt_debug_wide_walk.argtypes = [C.c_int]
+    try:
+        for wide in (1, 0):
+            hprt.lib.hprt_debug_wide_walk(wide)
+            t1, p1, b1 = scene.intersect(o, d, tmax)
+            occ1 = scene.occluded(o, d, tmax)
+            assert np.array_equal(p0, p1), (wide, int((p0 != p1).sum()))
+            assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(b0.view(np.uint32), b1.view(np.uint32)), wide
+            assert np.array_equal(occ0, occ1), (wide, int((occ0 != occ1).sum()))
+    finally:
+        hprt.lib.hprt_debug_wide_walk(-1)
+    assert 0.02 < (p0 >= 0).mean() < 0.98 and 0.02 < occ0.mean() < 0.98

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib")
-HOST_SRCS = ["pbrt_frontend.cpp", "loop_subdiv.cpp", "scene_io.cpp", "texture_io.cpp", "bvh_builder.cpp", "halton_tables.cpp", "capi_host.cpp"]
+HOST_SRCS = ["pbrt_frontend.cpp", "loop_subdiv.cpp", "scene_io.cpp", "texture_io.cpp", "bvh_builder.cpp", "wide_bvh.cpp", "halton_tables.cpp", "capi_host.cpp"]
 HIP_SRCS = ["device/kernels.hip", "capi_device.hip", "capi_gather.hip"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

@@ -18,6 +18,7 @@
 #include "host_transform.h"
 #include "hprt_internal.h"
 #include "device_state.h"
+#include "wide_bvh.h"
 
 using namespace hprt;
 
@@ -574,6 +575,8 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     const std::vector<uint16_t> &perms = HaltonPermutations();
     // ---- child-pair layout of the BVHs (device/dev_scene.h): one run of pairs per aggregate ----
     std::vector<DevPair> pairs((size_t)pairBase[aggs.size()]);
+    std::vector<DevWide> wide;
+    std::vector<float4> leafBox;
     // The ordered walk keeps at most one pending sibling per level, plus the sentinel of an instance: the kernel's
     // stack has HPRT_STACK_TOTAL = 64 entries (LDS + HBM part), as the reference's nodesToVisit[64]
     // (accelerators/bvh.cpp:365).  Deeper trees are refused here rather than walked wrongly.
@@ -618,6 +621,39 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
             const uint32_t c[2] = {i + 1u, (uint32_t)nd[i].offset};
             fill(pairs[(size_t)ref[i]], c[0], c[1], nd[i].countAxis & 3u);
         }
+        // The leaf-exact walk of plain renders (wide_bvh.h): four-wide records over the same leaves, for scenes without object instances.
+        // A leaf that holds exactly one triangle needs no stored box: Triangle::WorldBound is the min / max of its vertices
+        // (shapes/triangle.cpp:180-186) — provided that is, bit for bit, what the node holds (a zero of either sign among the
+        // coordinates would make the minimum's sign a matter of operand order: such leaves read their box like the others).
+        if (ai == 0 && d->n_instances == 0 && totalPrims < (1u << 28)) {
+            std::vector<int32_t> leafRefW(g.nNodes, WIDE_NONE);
+            leafBox.assign(2 * (size_t)totalPrims, make_float4(0.f, 0.f, 0.f, 0.f));
+            for (uint32_t i = 0; i < g.nNodes; ++i) {
+                if ((nd[i].countAxis & 3u) != 3u) continue;
+                const uint32_t firstPrim = primBase[ai] + (uint32_t)nd[i].offset, count = nd[i].countAxis >> 2;
+                bool single = count == 1u && (f2u(tris[3 * (size_t)firstPrim].w) & TAG_KIND_MASK) == 0u;
+                if (single) {
+                    const float4 *v = &tris[3 * (size_t)firstPrim];
+                    const float c[3][3] = {{v[0].x, v[1].x, v[2].x}, {v[0].y, v[1].y, v[2].y}, {v[0].z, v[1].z, v[2].z}};
+                    for (int a = 0; a < 3 && single; ++a) {
+                        bool posZero = false, negZero = false;
+                        for (int k = 0; k < 3; ++k) { if (c[a][k] != c[a][k]) single = false; if (c[a][k] == 0.f) { if (f2u(c[a][k]) >> 31) negZero = true; else posZero = true; } }
+                        const float mn = std::min(std::min(c[a][0], c[a][1]), c[a][2]), mx = std::max(std::max(c[a][0], c[a][1]), c[a][2]);
+                        if ((posZero && negZero) || f2u(mn) != f2u(nd[i].bmin[a]) || f2u(mx) != f2u(nd[i].bmax[a])) single = false;
+                    }
+                }
+                uint32_t r = ~firstPrim;
+                if (!single) r &= ~WIDE_LEAF_BOXED;
+                leafRefW[i] = (int32_t)r;
+                for (uint32_t k = 0; k < count; ++k) {
+                    leafBox[2 * (size_t)(firstPrim + k)] = make_float4(nd[i].bmin[0], nd[i].bmin[1], nd[i].bmin[2], nd[i].bmax[0]);
+                    leafBox[2 * (size_t)(firstPrim + k) + 1] = make_float4(nd[i].bmax[1], nd[i].bmax[2], 0.f, 0.f);
+                }
+            }
+            int need = 0;
+            // (the walk's stack: LDS entries + the scene's deep-stack area; a tree that could need more keeps the binary walk)
+            if (!BuildWide(nd, g.nNodes, leafRefW.data(), &wide, &need) || need > HPRT_WIDE_STACK_MAX) { wide.clear(); leafBox.clear(); }
+        }
     }
     if (topDepth + (d->n_instances ? 1 + objectDepth : 0) > HPRT_STACK_TOTAL)
         return SetError(HPRT_E_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack (accelerators/bvh.cpp:365 reserves the same)");
@@ -661,12 +697,14 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     HIP_TRY(upload(sc->perms, perms)); HIP_TRY(upload(sc->primes, primes)); HIP_TRY(upload(sc->primeSums, primeSums));
     HIP_TRY(upload(sc->primeMagic, magic));
     HIP_TRY(upload(sc->textures, textures)); HIP_TRY(upload(sc->mipLevels, mipLevels)); HIP_TRY(upload(sc->texels, texels)); HIP_TRY(upload(sc->weightLut, weightLut));
+    HIP_TRY(upload(sc->wide, wide)); HIP_TRY(upload(sc->leafBox, leafBox));
     HIP_TRY(sc->counters.alloc(sizeof(DevCounters)));
     HIP_TRY(hipMemset(sc->counters.p, 0, sizeof(DevCounters)));
     HIP_TRY(sc->deepStack.alloc((size_t)HPRT_SPILL_STACK * HPRT_DEEP_THREADS * sizeof(uint2)));
     HIP_TRY(sc->workCounter.alloc(256));
     DevScene &dv = sc->dev;
     dv.pairs = sc->nodes.as<DevPair>(); dv.nPairs = (uint32_t)pairs.size();
+    dv.wide = wide.empty() ? nullptr : sc->wide.as<DevWide>(); dv.nWide = (uint32_t)wide.size(); dv.leafBox = sc->leafBox.as<float4>();
     dv.tris = sc->tris.as<float4>(); dv.nPrims = totalPrims;
     dv.primVtx = sc->primVtx.as<uint32_t>();
     dv.primN = sc->primN.as<float4>(); dv.vUV = sc->vUV.as<float>(); dv.vS = sc->vS.as<float>();

@@ -17,6 +17,7 @@
 #include "hprt_internal.h"
 #include "scene_model.h"
 #include "hprt_math.h"
+#include "wide_bvh.h"
 
 using namespace hprt;
 
@@ -325,6 +326,23 @@ __attribute__((visibility("default"))) int hprt_debug_host_selftest(int failures
     for (; u <= uMax; u = next_up(u))
         if (dist1d_sample_discrete(cdf, func, funcInt, 4, u, &pdf) != 3) ++f;
     failures[1] = f;
+    return HPRT_OK;
+} catch (...) { return hprt::HandleException(); }
+
+// Diagnostics hook (not part of include/hprt.h; tests/test_wide_walk.py): the four-wide records BuildWide (wide_bvh.h) makes of a
+// linear node array.  Every leaf gets the "boxed" reference ~firstPrimitive & ~WIDE_LEAF_BOXED (the single-triangle shortcut is
+// decided at scene creation, where the vertices are).  out64: cap records of 64 bytes; *n_out: records made; *stack_need: the
+// deepest stack a walk can hold.  HPRT_E_UNSUPPORTED when the tree keeps the binary walk (non-finite box, extent beyond the grid).
+__attribute__((visibility("default"))) int hprt_debug_wide_build(const void *nodes32, uint32_t n_nodes, void *out64, size_t cap, size_t *n_out, int *stack_need) try {
+    if (!nodes32 || !n_out || !stack_need) return SetError(HPRT_E_INVALID, "hprt_debug_wide_build: null argument");
+    const BvhNode *nd = (const BvhNode *)nodes32;
+    std::vector<int32_t> leafRef(n_nodes, WIDE_NONE);
+    for (uint32_t i = 0; i < n_nodes; ++i)
+        if ((nd[i].countAxis & 3u) == 3u) leafRef[i] = (int32_t)(~(uint32_t)nd[i].offset & ~WIDE_LEAF_BOXED);
+    std::vector<DevWide> wide;
+    if (!BuildWide(nd, n_nodes, leafRef.data(), &wide, stack_need)) return SetError(HPRT_E_UNSUPPORTED, "the tree does not fit the four-wide grid");
+    *n_out = wide.size();
+    if (out64 && cap >= wide.size()) memcpy(out64, wide.data(), wide.size() * sizeof(DevWide));
     return HPRT_OK;
 } catch (...) { return hprt::HandleException(); }
 

@@ -235,6 +235,17 @@ __device__ __noinline__ bool sphere_test(const DevSphere &s, const DRay &r, DRay
 #define HPRT_TRACE_BLOCK 256
 #endif
 
+// The leaf-exact walk (k_walk4, dev_wide.h): LDS stack entries per lane — {ref, entry distance} pairs for closest-hit rays, bare
+// references for any-hit rays — and the deepest stack a scene's wide tree may need (LDS + the deep-stack area)
+#ifndef HPRT_WIDE_LDS_CLOSEST
+#define HPRT_WIDE_LDS_CLOSEST 12
+#endif
+#ifndef HPRT_WIDE_LDS_ANY
+#define HPRT_WIDE_LDS_ANY 20
+#endif
+#define HPRT_WIDE_STACK_MAX 60
+static_assert(HPRT_WIDE_STACK_MAX - HPRT_WIDE_LDS_CLOSEST <= HPRT_SPILL_STACK && HPRT_WIDE_STACK_MAX - HPRT_WIDE_LDS_ANY <= HPRT_SPILL_STACK, "deep-stack area too small for the wide walk");
+
 struct TraceCount { unsigned int fetched, entered, tri, sphere, leaf; };   // leaf: of the entered nodes, leaves
 
 // `cur` of a lane: >= 0 interior pair, REF_NONE finished, REF_EXIT leaving an instance, otherwise ~(parked primitive index)

@@ -34,6 +34,7 @@
 //   shapes, materials, lights, spheres, lightCdf: small tables.
 #pragma once
 #include "../hprt_math.h"
+#include "dev_wide.h"
 
 namespace hprt {
 
@@ -84,6 +85,10 @@ struct DevInstance { mat4 i2w, w2i; int32_t root; uint32_t identity; uint32_t pa
 
 struct DevScene {
     const DevPair *pairs; uint32_t nPairs;
+    // The leaf-exact walk of plain renders (dev_wide.h; null when the scene keeps the binary walk): four-wide records over the same
+    // leaves, and per ordered primitive the exact box of its leaf {lo.xyz, hi.x} {hi.yz, -, -} for leaves that are not one triangle
+    const DevWide *wide; uint32_t nWide;
+    const float4 *leafBox;
     const float4 *tris; uint32_t nPrims;
     const uint32_t *primVtx;
     const float4 *primN;                                         // shading normals pre-gathered like the positions: float4[3] per ordered primitive

@@ -635,6 +635,281 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
 }
 
 // ---------------------------------------------------------------------------
+// k_walk4: the leaf-exact walk of plain renders (wide_bvh.h, dev_wide.h) — the same persistent waves, the same two
+// wave-uniform phases and the same primitive tests as k_trace, over four-wide records with quantised child boxes.
+//
+// Why it returns what BVHAccel::Intersect / IntersectP return (accelerators/bvh.cpp:354-437):
+// Bounds3::IntersectP(ray, invDir, dirIsNeg) (core/geometry.h:1754-1780) is monotone under box inclusion and a node's box
+// contains its descendants' boxes exactly (Union of primitive bounds, bvh.cpp:220-222); tMax only shrinks.  So the
+// reference's walk tests the primitives of a leaf if and only if that leaf's OWN box passes against the tMax current when
+// the leaf comes up, and the leaves come up in an order fixed by the tree and the ray's signs.  Here the leaves come up in
+// that same order (slots visited by the nested near / far decisions of the three collapsed split axes; any-hit rays, whose
+// answer is order-free, in storage order), every leaf's own exact box is tested with the reference's arithmetic
+// (slab_test) before its primitives count — for a one-triangle leaf from the vertices just fetched, otherwise from
+// DevScene::leafBox — and the interior tests are conservative: a dequantised box contains the exact one, the same float
+// operations run on it, NaN comparisons never cull, so whatever the exact test passes, this one passes.  What is culled
+// coarser costs work, never a result.  An any-hit ray tests the leaf's exact box only when a triangle reports a hit (the
+// hit counts if the box passes, else the leaf is one the reference never reaches and is left).
+// Counting and profiling renders keep k_trace: their node counts are the reference's.
+// ---------------------------------------------------------------------------
+#ifndef HPRT_WALK4_CLOSEST_WAVES
+#define HPRT_WALK4_CLOSEST_WAVES 5
+#endif
+#ifndef HPRT_WALK4_ANY_WAVES
+#define HPRT_WALK4_ANY_WAVES 5
+#endif
+// two slots (bytes sh / 8 and sh / 8 + 1 of the near / far words) of a wide record: entry and exit distance of the dequantised boxes
+__device__ __forceinline__ void wide_slab2(uint32_t nX, uint32_t fX, uint32_t nY, uint32_t fY, uint32_t nZ, uint32_t fZ, int sh, float sx, float sy, float sz,
+                                           float ox, float oy, float oz, float rox, float roy, float roz, float ivx, float ivy, float ivz, float robust,
+                                           float *tE0, float *tX0, float *tE1, float *tX1) {
+    const f32x2 qnx = {(float)((nX >> sh) & 0xffu), (float)((nX >> (sh + 8)) & 0xffu)}, qfx = {(float)((fX >> sh) & 0xffu), (float)((fX >> (sh + 8)) & 0xffu)};
+    const f32x2 qny = {(float)((nY >> sh) & 0xffu), (float)((nY >> (sh + 8)) & 0xffu)}, qfy = {(float)((fY >> sh) & 0xffu), (float)((fY >> (sh + 8)) & 0xffu)};
+    const f32x2 qnz = {(float)((nZ >> sh) & 0xffu), (float)((nZ >> (sh + 8)) & 0xffu)}, qfz = {(float)((fZ >> sh) & 0xffu), (float)((fZ >> (sh + 8)) & 0xffu)};
+    // grid coordinate -> float: q * step is exact, so the fused form is origin + q * step with its one rounding (what the host rounded outwards against)
+    const f32x2 vsx = {sx, sx}, vsy = {sy, sy}, vsz = {sz, sz}, vox = {ox, ox}, voy = {oy, oy}, voz = {oz, oz};
+    const f32x2 bnx = __builtin_elementwise_fma(qnx, vsx, vox), bfx = __builtin_elementwise_fma(qfx, vsx, vox);
+    const f32x2 bny = __builtin_elementwise_fma(qny, vsy, voy), bfy = __builtin_elementwise_fma(qfy, vsy, voy);
+    const f32x2 bnz = __builtin_elementwise_fma(qnz, vsz, voz), bfz = __builtin_elementwise_fma(qfz, vsz, voz);
+    const f32x2 tnx = (bnx - rox) * ivx, tny = (bny - roy) * ivy, tnz = (bnz - roz) * ivz;
+    f32x2 tfx = (bfx - rox) * ivx, tfy = (bfy - roy) * ivy, tfz = (bfz - roz) * ivz;
+    tfx = tfx * robust; tfy = tfy * robust; tfz = tfz * robust;
+    *tE0 = fmaxf(fmaxf(tnx.x, tny.x), tnz.x); *tE1 = fmaxf(fmaxf(tnx.y, tny.y), tnz.y);
+    *tX0 = fminf(fminf(tfx.x, tfy.x), tfz.x); *tX1 = fminf(fminf(tfx.y, tfy.y), tfz.y);
+}
+
+// PROF (HPRT_TRACE_PROFILE=1, tools/trace_profile.py): phase cycles and lane counts into g_traceProf, as k_trace<., 2>; [11] leaves whose
+// box was tested, [12] leaves whose box passed (closest hit) or hits whose leaf was checked / confirmed (any hit)
+template <bool ANY_HIT, bool PROF>
+__global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_ANY_WAVES : HPRT_WALK4_CLOSEST_WAVES) void k_walk4(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
+                                                            uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ, uint32_t *workCounter, uint32_t chunk, TraceTune tune) {
+    constexpr int LDS_N = ANY_HIT ? HPRT_WIDE_LDS_ANY : HPRT_WIDE_LDS_CLOSEST;
+    // [entry][thread]; closest hit: {ref, entry distance of the dequantised box}; any hit: the reference alone
+    __shared__ uint32_t stackMem[(ANY_HIT ? 1 : 2) * LDS_N * HPRT_TRACE_BLOCK];
+    uint32_t *const ldsRef = &stackMem[threadIdx.x];
+    uint32_t *const ldsT = &stackMem[(ANY_HIT ? 0 : LDS_N * HPRT_TRACE_BLOCK) + threadIdx.x];
+    const uint32_t n = countPtr ? *countPtr : countImm;
+    const uint32_t lane = __lane_id();
+    unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned int pfPush = 0u, pfSpill = 0u, pfLeaf = 0u, pfLeafOk = 0u;
+    const unsigned long long pfStart = PROF ? clock64() : 0ull;
+    const auto wideRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.wide, 0, (int)(sc.nWide * 64u), 0x00020000);
+    const auto triRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.tris, 0, (int)(sc.nPrims * 48u), 0x00020000);
+    const auto boxRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.leafBox, 0, (int)(sc.nPrims * 32u), 0x00020000);
+    const float robust = 1 + 2 * gamma_n(3);
+    bool active = false, hit = false;
+    uint32_t slot = 0;
+    vec3 ro, invDir;
+    float rayTMax = 0.f;
+    RayShear shear; shear.k0 = shear.k1 = false; shear.Sx = shear.Sy = shear.Sz = 0.f;
+    bool ngX = false, ngY = false, ngZ = false;
+    uint32_t negMask = 0u;
+    int sp = 0, cur = REF_NONE;
+    int32_t prim = -1; float hb0 = 0.f, hb1 = 0.f, hb2 = 0.f;
+    auto deepSlot = [&](int entry) -> volatile unsigned long long * {
+        return (volatile unsigned long long *)sc.deepStack + (size_t)(entry - LDS_N) * HPRT_DEEP_THREADS + (blockIdx.x * HPRT_TRACE_BLOCK + threadIdx.x);
+    };
+    auto push = [&](int ref, float t) {
+        if (PROF) { ++pfPush; if (sp >= LDS_N) ++pfSpill; }
+        if (sp < LDS_N) { ldsRef[sp * HPRT_TRACE_BLOCK] = (uint32_t)ref; if (!ANY_HIT) ldsT[sp * HPRT_TRACE_BLOCK] = __float_as_uint(t); ++sp; }
+        else if (sp < HPRT_WIDE_STACK_MAX) { *deepSlot(sp) = (unsigned long long)(uint32_t)ref | ((unsigned long long)__float_as_uint(t) << 32); ++sp; }
+    };
+    // the next pending slot; for closest-hit rays only if it can still matter (its dequantised box is not entered behind the hit found since)
+    auto pop = [&]() -> int {
+        while (sp > 0) {
+            --sp;
+            uint32_t r, t;
+            if (sp < LDS_N) { r = ldsRef[sp * HPRT_TRACE_BLOCK]; t = ANY_HIT ? 0u : ldsT[sp * HPRT_TRACE_BLOCK]; }
+            else { const unsigned long long w = *deepSlot(sp); r = (uint32_t)w; t = (uint32_t)(w >> 32); }
+            if (ANY_HIT || !(__uint_as_float(t) >= rayTMax)) return (int)r;
+        }
+        return REF_NONE;
+    };
+    bool moreWork = n > 0;
+    uint32_t localNext = 0u, localEnd = 0u;
+    uint32_t window = 0u, windowBase = 0xffffffffu;
+    while (true) {
+        // ---- refill idle lanes from the queue (as k_trace) ----
+        if (moreWork) {
+            const unsigned long long idle = __ballot(!active);
+            if (idle != 0ull) {
+                const unsigned long long pfT = PROF ? clock64() : 0ull;
+                if (localNext >= localEnd) {
+                    uint32_t base = 0u;
+                    if (lane == 0) base = atomicAdd(workCounter, chunk);
+                    base = __shfl(base, 0);
+                    localNext = base < n ? base : n;
+                    localEnd = (base + chunk < n) ? base + chunk : n;
+                    if (localNext >= localEnd) moreWork = false;
+                    windowBase = 0xffffffffu;
+                }
+                const uint32_t want = (uint32_t)__popcll(idle);
+                const uint32_t base = localNext;
+                localNext = (localNext + want < localEnd) ? localNext + want : localEnd;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                uint32_t slotW = 0u;
+                if (queue) {
+                    if (windowBase != base) { window = (base + lane < localEnd) ? queue[base + lane] : 0u; windowBase = base; }
+                    slotW = __shfl(window, (int)rank);
+                    window = (localNext + lane < localEnd) ? queue[localNext + lane] : 0u;
+                    windowBase = localNext;
+                }
+                if (!active) {
+                    const uint32_t idx = base + rank;
+                    if (idx < localEnd) {
+                        slot = queue ? slotW : idx;
+                        const float4 ra = rays.a[slot], rb = rays.b[slot];
+                        ro = vec3(ra.x, ra.y, ra.z);
+                        const vec3 rd(rb.x, rb.y, rb.z);
+                        rayTMax = ra.w;
+                        invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
+                        ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
+                        negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
+                        shear = ray_shear(rd, invDir);
+                        sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
+                        active = true;
+                    }
+                }
+                if (PROF) { pf[1] += clock64() - pfT; pf[9] += 1; pf[10] += __popcll(idle); }
+            }
+        }
+        if (__ballot(active) == 0ull) break;
+        while (true) {
+            // phase 1: record steps
+            int steps = 0;
+            const unsigned long long pfT1 = PROF ? clock64() : 0ull;
+            while (true) {
+                const bool trav = active && cur >= 0;
+                if (__ballot(trav) == 0ull) break;
+                if (PROF) { pf[5] += 1; pf[6] += __popcll(__ballot(trav)); }
+                if (trav) {
+                    const uint32_t base = (uint32_t)cur * 64u;
+                    const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(wideRsrc, base, 0, 0);
+                    const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(wideRsrc, base + 16u, 0, 0);
+                    const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(wideRsrc, base + 32u, 0, 0);
+                    const u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(wideRsrc, base + 48u, 0, 0);
+                    const uint32_t em = q0.w;
+                    const float sx = __uint_as_float((em & 0xffu) << 23), sy = __uint_as_float((em & 0xff00u) << 15), sz = __uint_as_float((em & 0xff0000u) << 7);
+                    // dirIsNeg picks, per axis, the bounds that give tMin ("near") and tMax ("far"): one select per word covers the four slots
+                    const uint32_t nX = ngX ? q1.y : q1.x, fX = ngX ? q1.x : q1.y, nY = ngY ? q1.w : q1.z, fY = ngY ? q1.z : q1.w;
+                    const uint32_t nZ = ngZ ? q2.y : q2.x, fZ = ngZ ? q2.x : q2.y;
+                    float tE[4], tX[4];
+                    wide_slab2(nX, fX, nY, fY, nZ, fZ, 0, sx, sy, sz, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), ro.x, ro.y, ro.z,
+                               invDir.x, invDir.y, invDir.z, robust, &tE[0], &tX[0], &tE[1], &tX[1]);
+                    wide_slab2(nX, fX, nY, fY, nZ, fZ, 16, sx, sy, sz, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), ro.x, ro.y, ro.z,
+                               invDir.x, invDir.y, invDir.z, robust, &tE[2], &tX[2], &tE[3], &tX[3]);
+                    int r[4] = {(int)q3.x, (int)q3.y, (int)q3.z, (int)q3.w};
+                    // the reference's rejections, each as "not provably outside": a NaN (0 * inf on a grid plane) never culls
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if ((tE[k] > tX[k]) || (tX[k] <= 0.f) || (tE[k] >= rayTMax)) r[k] = WIDE_NONE;
+                    if (!ANY_HIT) {
+                        // the order of the reference's walk: second child's slots first when the ray is negative along the record's split
+                        // axis, and inside either child by that child's own axis (bvh.cpp:381-388, applied at both collapsed levels)
+                        const uint32_t meta = em >> 24;
+                        const bool n0 = ((negMask >> (meta & 3u)) & 1u) != 0u, nL = ((negMask >> ((meta >> 2) & 3u)) & 1u) != 0u, nR = ((negMask >> ((meta >> 4) & 3u)) & 1u) != 0u;
+                        { const int a = nL ? r[1] : r[0], b = nL ? r[0] : r[1]; const float ta = nL ? tE[1] : tE[0], tb = nL ? tE[0] : tE[1]; r[0] = a; r[1] = b; tE[0] = ta; tE[1] = tb; }
+                        { const int a = nR ? r[3] : r[2], b = nR ? r[2] : r[3]; const float ta = nR ? tE[3] : tE[2], tb = nR ? tE[2] : tE[3]; r[2] = a; r[3] = b; tE[2] = ta; tE[3] = tb; }
+                        { const int a = n0 ? r[2] : r[0], b = n0 ? r[3] : r[1], c = n0 ? r[0] : r[2], d = n0 ? r[1] : r[3];
+                          const float ta = n0 ? tE[2] : tE[0], tb = n0 ? tE[3] : tE[1], tc = n0 ? tE[0] : tE[2], td = n0 ? tE[1] : tE[3];
+                          r[0] = a; r[1] = b; r[2] = c; r[3] = d; tE[0] = ta; tE[1] = tb; tE[2] = tc; tE[3] = td; }
+                    }
+                    const bool v0 = r[0] != WIDE_NONE, v1 = r[1] != WIDE_NONE, v2 = r[2] != WIDE_NONE, v3 = r[3] != WIDE_NONE;
+                    // the first slot hit is walked now, the others wait, the next one on top
+                    if (v3 && (v0 || v1 || v2)) push(r[3], tE[3]);
+                    if (v2 && (v0 || v1)) push(r[2], tE[2]);
+                    if (v1 && v0) push(r[1], tE[1]);
+                    cur = v0 ? r[0] : v1 ? r[1] : v2 ? r[2] : r[3];
+                    if (cur == WIDE_NONE) cur = pop();
+                }
+                ++steps;
+                if (steps >= tune.stepLimit || __popcll(__ballot(active && is_parked(cur))) >= tune.parkLimit) break;
+            }
+            const unsigned long long pfT2 = PROF ? clock64() : 0ull;
+            if (PROF) pf[2] += pfT2 - pfT1;
+            // phase 2: the parked leaves
+            while (true) {
+                const bool todo = active && is_parked(cur);
+                const int nPending = __popcll(__ballot(todo));
+                if (nPending == 0) break;
+                if (nPending < tune.primMin && __ballot(active && cur >= 0) != 0ull) break;
+                if (PROF) { pf[7] += 1; pf[8] += nPending; }
+                if (todo) {
+                    const uint32_t c = (uint32_t)cur;
+                    const uint32_t pi = ~(c | (WIDE_LEAF_BOXED | WIDE_LEAF_FIRST));
+                    const bool entrySingle = (c & (WIDE_LEAF_BOXED | WIDE_LEAF_FIRST)) == (WIDE_LEAF_BOXED | WIDE_LEAF_FIRST), entryBoxed = (c & WIDE_LEAF_BOXED) == 0u;
+                    u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48, 0, 0);
+                    u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 16, 0, 0);
+                    u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 32, 0, 0);
+                    u32x4 x0 = {0u, 0u, 0u, 0u}, x1 = {0u, 0u, 0u, 0u};
+                    if (!ANY_HIT && entryBoxed) { x0 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32, 0, 0); x1 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32 + 16, 0, 0); }
+                    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(x0), "+v"(x1));
+                    const uint32_t tag = v0.w;
+                    const vec3 p0(__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z)), p1(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
+                               p2(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z));
+                    // the leaf's own box, exactly: Bounds3::IntersectP as the reference evaluates it for this node (slab_test + tMin < tMax)
+                    auto leaf_reached = [&](bool fromVertices, u32x4 b0, u32x4 b1) -> bool {
+                        float lx = __uint_as_float(b0.x), ly = __uint_as_float(b0.y), lz = __uint_as_float(b0.z), hx = __uint_as_float(b0.w), hy = __uint_as_float(b1.x), hz = __uint_as_float(b1.y);
+                        if (fromVertices) {
+                            lx = fminf(fminf(p0.x, p1.x), p2.x); ly = fminf(fminf(p0.y, p1.y), p2.y); lz = fminf(fminf(p0.z, p1.z), p2.z);
+                            hx = fmaxf(fmaxf(p0.x, p1.x), p2.x); hy = fmaxf(fmaxf(p0.y, p1.y), p2.y); hz = fmaxf(fmaxf(p0.z, p1.z), p2.z);
+                        }
+                        float tEn;
+                        return slab_test(lx, hx, ly, hy, lz, hz, ro, invDir, ngX, ngY, ngZ, robust, &tEn) && tEn < rayTMax;
+                    };
+                    bool leave = false;      // done with this leaf: next pending slot
+                    if (!ANY_HIT) {
+                        const bool reached = (entrySingle || entryBoxed) ? leaf_reached(entrySingle, x0, x1) : true;
+                        if (PROF && (entrySingle || entryBoxed)) { ++pfLeaf; if (reached) ++pfLeafOk; }
+                        if (!reached) leave = true;
+                        else {
+                            float b0, b1, b2, t;
+                            if ((tag & TAG_KIND_MASK) == 0u && tri_test(p0, p1, p2, ro, rayTMax, shear, &b0, &b1, &b2, &t) && !(tag & TAG_BOGUS)) {
+                                hit = true; rayTMax = t; prim = (int32_t)(pi | ((tag & TAG_BIN_MASK) << 24)); hb0 = b0; hb1 = b1; hb2 = b2;
+                            }
+                            if (tag & TAG_LAST) leave = true;
+                            else cur = (int)((~(pi + 1u)) & ~WIDE_LEAF_FIRST);
+                        }
+                    } else {
+                        float b0, b1, b2, t;
+                        if ((tag & TAG_KIND_MASK) == 0u && tri_test(p0, p1, p2, ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
+                            // a hit counts if the reference's walk reaches this leaf; if it does not, none of the leaf's primitives is ever tested
+                            if (!entrySingle) { x0 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32, 0, 0); x1 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32 + 16, 0, 0); }
+                            if (PROF) ++pfLeaf;
+                            if (leaf_reached(entrySingle, x0, x1)) { hit = true; cur = REF_NONE; if (PROF) ++pfLeafOk; }
+                            else leave = true;
+                        } else if (tag & TAG_LAST) leave = true;
+                        else cur = (int)((~(pi + 1u)) & ~WIDE_LEAF_FIRST);
+                    }
+                    if (leave) cur = pop();
+                }
+            }
+            if (PROF) pf[3] += clock64() - pfT2;
+            // retire finished rays
+            if (active && cur == REF_NONE) {
+                if (ANY_HIT) occ[slot] = hit ? 1 : 0;
+                else {
+                    hits.a[slot] = make_float4(rayTMax, __int_as_float(hit ? prim : -1), hb0, hb1);
+                    if (hits.b) hits.b[slot] = make_float2(hb2, __int_as_float(-1));
+                }
+                active = false;
+            }
+            const int busy = __popcll(__ballot(active));
+            if (busy == 0) break;
+            if (moreWork && busy < tune.refillBelow) break;
+        }
+    }
+    if (PROF) {
+        for (int off = 32; off > 0; off >>= 1) { pfPush += __shfl_down(pfPush, off); pfSpill += __shfl_down(pfSpill, off); pfLeaf += __shfl_down(pfLeaf, off); pfLeafOk += __shfl_down(pfLeafOk, off); }
+        if (lane == 0) {
+            pf[0] = clock64() - pfStart; pf[11] = pfLeaf; pf[12] = pfLeafOk;
+            for (int k = 0; k < 13; ++k) atomicAdd(&g_traceProf[(ANY_HIT ? 16 : 0) + k], pf[k]);
+            atomicAdd(&g_traceProf[(ANY_HIT ? 16 : 0) + 13], 1ull);
+            atomicAdd(&g_traceProf[(ANY_HIT ? 16 : 0) + 14], (unsigned long long)pfPush); atomicAdd(&g_traceProf[(ANY_HIT ? 16 : 0) + 15], (unsigned long long)pfSpill);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_generate: Sampler::GetCameraSample (core/sampler.cpp:46-52) + GenerateRayDifferential.
 // path id = sampleInChunk * nPix + pixelIndex, so consecutive lanes are consecutive pixels
 // of a 16x16 tile (coherent primary rays).  Bounce 0 uses the path id as stream index.
@@ -1365,6 +1640,14 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
 // ---------------------------------------------------------------------------
 static inline uint32_t blocks_for(size_t n, uint32_t bs) { return (uint32_t)((n + bs - 1) / bs); }
 
+// HPRT_WIDE_WALK=0 in the environment, or hprt_debug_wide_walk(0) at run time (diagnostics hook, not part of include/hprt.h): plain
+// renders keep the binary walk
+static int g_wideWalk = -1;
+static bool WideWalkEnabled() {
+    static const bool fromEnv = [] { const char *e = getenv("HPRT_WIDE_WALK"); return !(e && atoi(e) == 0); }();
+    return g_wideWalk < 0 ? fromEnv : g_wideWalk != 0;
+}
+extern "C" __attribute__((visibility("default"))) int hprt_debug_wide_walk(int on) { const int was = WideWalkEnabled() ? 1 : 0; g_wideWalk = on; return was; }
 void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
                  uint32_t countImm, uint32_t gridItems, const RayStream &rays, const HitStream &hits, uint8_t *occ,
                  DevCounters *counters, uint32_t *workCounter, uint4 *rayStats) {
@@ -1404,6 +1687,25 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     static const bool tuneAnyFromEnv = getenv("HPRT_TRACE_TUNE_ANY") != nullptr;
     if (inst && !anyHit && !tuneFromEnv) { tune.parkLimit = 32; tune.stepLimit = 10; tune.primMin = 12; }
     if (inst && anyHit && !tuneAnyFromEnv) { tune.refillBelow = 48; tune.parkLimit = 32; tune.stepLimit = 10; tune.primMin = 6; }
+    // Plain renders of scenes that have the four-wide structure take the leaf-exact walk (k_walk4; HPRT_WIDE_WALK=0 or
+    // hprt_debug_wide_walk(0) keep the binary walk: A/B runs and the tests that hold the two against each other)
+    if (!count && sc.wide != nullptr && !inst && !quad && WideWalkEnabled()) {
+        static const uint32_t wClosestPerCu = [] { const char *e = getenv("HPRT_WALK4_CLOSEST_PER_CU"); return e ? (uint32_t)std::min((int)HPRT_WALK4_CLOSEST_WAVES, std::max(1, atoi(e))) : (uint32_t)HPRT_WALK4_CLOSEST_WAVES; }();
+        static const uint32_t wAnyPerCu = [] { const char *e = getenv("HPRT_WALK4_ANY_PER_CU"); return e ? (uint32_t)std::min((int)HPRT_WALK4_ANY_WAVES, std::max(1, atoi(e))) : (uint32_t)HPRT_WALK4_ANY_WAVES; }();
+        static const TraceTune wTuneClosest = [] { TraceTune t{52, 32, 8, 4, 12}; if (const char *e = getenv("HPRT_WALK4_TUNE")) sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin); return t; }();
+        static const TraceTune wTuneAny = [] { TraceTune t{40, 24, 6, 4, 3}; if (const char *e = getenv("HPRT_WALK4_TUNE_ANY")) sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin); return t; }();
+        const uint32_t wBlocks = std::min(256u * (profile ? 4u : anyHit ? wAnyPerCu : wClosestPerCu), blockCap);
+        dim3 wGrid(std::min(blocks_for(gridItems, HPRT_TRACE_BLOCK), wBlocks));
+        const uint32_t wWaves = wGrid.x * (HPRT_TRACE_BLOCK / 64);
+        uint32_t wChunk = gridItems / (wWaves * chunkDiv);
+        wChunk = std::max(64u, std::min(chunkMax, wChunk)) & ~63u;
+        if (profile) {
+            if (anyHit) hipLaunchKernelGGL((k_walk4<true, true>), wGrid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, workCounter, wChunk, wTuneAny);
+            else hipLaunchKernelGGL((k_walk4<false, true>), wGrid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, workCounter, wChunk, wTuneClosest);
+        } else if (anyHit) hipLaunchKernelGGL((k_walk4<true, false>), wGrid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, workCounter, wChunk, wTuneAny);
+        else hipLaunchKernelGGL((k_walk4<false, false>), wGrid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, workCounter, wChunk, wTuneClosest);
+        return;
+    }
 #define HPRT_TRACE_LAUNCH(A, M, I, Q) hipLaunchKernelGGL((k_trace<A, M, I, Q>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, rayStats, workCounter, chunk, tune)
     // (the profiling variant exists with the quadric code only)
 #define HPRT_TRACE_PICK(A, M) do { if (inst) { if (quad || M == 2) HPRT_TRACE_LAUNCH(A, M, true, true); else HPRT_TRACE_LAUNCH(A, M, true, (M == 2)); } \

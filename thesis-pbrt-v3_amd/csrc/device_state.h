@@ -62,6 +62,7 @@ struct HprtScene {
     hprt::DevBuf textures, mipLevels, texels, weightLut;
     hprt::DevBuf nodes, tris, primVtx, primN, vUV, vS, shapes, materials, lights, spheres, instances, topEntry, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
     hprt::DevBuf envLights, envData;      // infinite lights: DevEnvLight table and their Distribution2D tables
+    hprt::DevBuf wide, leafBox;           // the leaf-exact walk structure (wide_bvh.h)
     hprt::DevBuf counters, workCounter, deepStack;
     // hprt_debug_capture_rays (tools/sort_experiment.py): the next render copies the rays one bounce queues into a caller buffer
     struct Capture { int bounce = -1, kind = 0; float *out7 = nullptr; size_t cap = 0, n = 0; } capture;

@@ -47,5 +47,9 @@ for name, b in (("closest", 0), ("any-hit", 16)):
     print("   pair steps: %d iterations, %.1f lanes avg   | cycles/iteration %.0f" % (v[5], v[6] / max(1, v[5]), v[2] / max(1, v[5])))
     print("   prim tests: %d iterations, %.1f lanes avg   | cycles/iteration %.0f" % (v[7], v[8] / max(1, v[7]), v[3] / max(1, v[7])))
     print("   refills   : %d, %.1f lanes avg               | cycles/refill %.0f" % (v[9], v[10] / max(1, v[9]), v[1] / max(1, v[9])))
+    nr = max(1, stats["shadow_rays"] if b else stats["rays"])
+    print("   per ray   : %.2f lane-steps, %.2f primitive (leaf) iterations" % (v[6] / nr, v[8] / nr))
+    if os.environ.get("HPRT_WIDE_WALK", "1") != "0":
+        print("   (wide walk) leaf boxes tested %d (%.2f per ray), passed %d (%.2f per ray)" % (v[11], v[11] / nr, v[12], v[12] / nr))
     print("   stack     : %d pushes, %.3f %% beyond the LDS entries (scratch)" % (v[14], 100.0 * v[15] / max(1, v[14])))
     print("   quadric   : %d batches, %.1f lanes avg       | cycles/batch %.0f" % (v[11], v[12] / max(1, v[11]), v[4] / max(1, v[11])))
