@@ -653,10 +653,10 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
 // Counting and profiling renders keep k_trace: their node counts are the reference's.
 // ---------------------------------------------------------------------------
 #ifndef HPRT_WALK4_CLOSEST_WAVES
-#define HPRT_WALK4_CLOSEST_WAVES 5
+#define HPRT_WALK4_CLOSEST_WAVES 6
 #endif
 #ifndef HPRT_WALK4_ANY_WAVES
-#define HPRT_WALK4_ANY_WAVES 5
+#define HPRT_WALK4_ANY_WAVES 6
 #endif
 // two slots (bytes sh / 8 and sh / 8 + 1 of the near / far words) of a wide record: entry and exit distance of the dequantised boxes
 __device__ __forceinline__ void wide_slab2(uint32_t nX, uint32_t fX, uint32_t nY, uint32_t fY, uint32_t nZ, uint32_t fZ, int sh, float sx, float sy, float sz,
@@ -675,6 +675,31 @@ __device__ __forceinline__ void wide_slab2(uint32_t nX, uint32_t fX, uint32_t nY
     tfx = tfx * robust; tfy = tfy * robust; tfz = tfz * robust;
     *tE0 = fmaxf(fmaxf(tnx.x, tny.x), tnz.x); *tE1 = fmaxf(fmaxf(tnx.y, tny.y), tnz.y);
     *tX0 = fminf(fminf(tfx.x, tfy.x), tfz.x); *tX1 = fminf(fminf(tfx.y, tfy.y), tfz.y);
+}
+
+// The same for the four slots of a record, packed so that the ray's operands are pairs it holds anyway: x and y of one slot share an
+// instruction ({x, y} of the origin, the reciprocal direction, the grid), z takes two slots at a time.  (wide_slab2's {slot, slot}
+// pairs made hipcc keep every ray operand twice, {v, v}: six registers for nothing.)
+__device__ __forceinline__ void wide_slab4(uint32_t nX, uint32_t fX, uint32_t nY, uint32_t fY, uint32_t nZ, uint32_t fZ, f32x2 sxy, float sz, f32x2 oxy, float oz,
+                                           f32x2 roxy, float roz, f32x2 ivxy, float ivz, float robust, float tE[4], float tX[4]) {
+    f32x2 tn[4], tf[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x2 qn = {(float)((nX >> (8 * k)) & 0xffu), (float)((nY >> (8 * k)) & 0xffu)}, qf = {(float)((fX >> (8 * k)) & 0xffu), (float)((fY >> (8 * k)) & 0xffu)};
+        const f32x2 bn = __builtin_elementwise_fma(qn, sxy, oxy), bf = __builtin_elementwise_fma(qf, sxy, oxy);
+        tn[k] = (bn - roxy) * ivxy;
+        tf[k] = ((bf - roxy) * ivxy) * robust;
+    }
+    const f32x2 vsz = {sz, sz}, voz = {oz, oz};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 qn = {(float)((nZ >> (16 * h)) & 0xffu), (float)((nZ >> (16 * h + 8)) & 0xffu)}, qf = {(float)((fZ >> (16 * h)) & 0xffu), (float)((fZ >> (16 * h + 8)) & 0xffu)};
+        const f32x2 bn = __builtin_elementwise_fma(qn, vsz, voz), bf = __builtin_elementwise_fma(qf, vsz, voz);
+        const f32x2 tnz = (bn - roz) * ivz;
+        const f32x2 tfz = ((bf - roz) * ivz) * robust;
+        tE[2 * h] = fmaxf(fmaxf(tn[2 * h].x, tn[2 * h].y), tnz.x); tE[2 * h + 1] = fmaxf(fmaxf(tn[2 * h + 1].x, tn[2 * h + 1].y), tnz.y);
+        tX[2 * h] = fminf(fminf(tf[2 * h].x, tf[2 * h].y), tfz.x); tX[2 * h + 1] = fminf(fminf(tf[2 * h + 1].x, tf[2 * h + 1].y), tfz.y);
+    }
 }
 
 // PROF (HPRT_TRACE_PROFILE=1, tools/trace_profile.py): phase cycles and lane counts into g_traceProf, as k_trace<., 2>; [11] leaves whose
@@ -704,7 +729,6 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_A
     bool ngX = false, ngY = false, ngZ = false;
     uint32_t negMask = 0u;
     int sp = 0, cur = REF_NONE;
-    int32_t prim = -1; float hb0 = 0.f, hb1 = 0.f, hb2 = 0.f;
     auto deepSlot = [&](int entry) -> volatile unsigned long long * {
         return (volatile unsigned long long *)sc.deepStack + (size_t)(entry - LDS_N) * HPRT_DEEP_THREADS + (blockIdx.x * HPRT_TRACE_BLOCK + threadIdx.x);
     };
@@ -736,7 +760,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_A
                 if (localNext >= localEnd) {
                     uint32_t base = 0u;
                     if (lane == 0) base = atomicAdd(workCounter, chunk);
-                    base = __shfl(base, 0);
+                    base = __builtin_amdgcn_readfirstlane(base);      // (wave-uniform from here on: the chunk bounds live in scalar registers)
                     localNext = base < n ? base : n;
                     localEnd = (base + chunk < n) ? base + chunk : n;
                     if (localNext >= localEnd) moreWork = false;
@@ -765,7 +789,7 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_A
                         ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
                         negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
                         shear = ray_shear(rd, invDir);
-                        sp = 0; cur = 0; hit = false; prim = -1; hb0 = hb1 = hb2 = 0.f;
+                        sp = 0; cur = 0; hit = false;
                         active = true;
                     }
                 }
@@ -793,10 +817,15 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_A
                     const uint32_t nX = ngX ? q1.y : q1.x, fX = ngX ? q1.x : q1.y, nY = ngY ? q1.w : q1.z, fY = ngY ? q1.z : q1.w;
                     const uint32_t nZ = ngZ ? q2.y : q2.x, fZ = ngZ ? q2.x : q2.y;
                     float tE[4], tX[4];
+#ifdef HPRT_WALK4_SLOT_PAIRS
                     wide_slab2(nX, fX, nY, fY, nZ, fZ, 0, sx, sy, sz, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), ro.x, ro.y, ro.z,
                                invDir.x, invDir.y, invDir.z, robust, &tE[0], &tX[0], &tE[1], &tX[1]);
                     wide_slab2(nX, fX, nY, fY, nZ, fZ, 16, sx, sy, sz, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), ro.x, ro.y, ro.z,
                                invDir.x, invDir.y, invDir.z, robust, &tE[2], &tX[2], &tE[3], &tX[3]);
+#else
+                    wide_slab4(nX, fX, nY, fY, nZ, fZ, f32x2{sx, sy}, sz, f32x2{__uint_as_float(q0.x), __uint_as_float(q0.y)}, __uint_as_float(q0.z),
+                               f32x2{ro.x, ro.y}, ro.z, f32x2{invDir.x, invDir.y}, invDir.z, robust, tE, tX);
+#endif
                     int r[4] = {(int)q3.x, (int)q3.y, (int)q3.z, (int)q3.w};
                     // the reference's rejections, each as "not provably outside": a NaN (0 * inf on a grid plane) never culls
 #pragma unroll
@@ -864,7 +893,11 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_A
                         else {
                             float b0, b1, b2, t;
                             if ((tag & TAG_KIND_MASK) == 0u && tri_test(p0, p1, p2, ro, rayTMax, shear, &b0, &b1, &b2, &t) && !(tag & TAG_BOGUS)) {
-                                hit = true; rayTMax = t; prim = (int32_t)(pi | ((tag & TAG_BIN_MASK) << 24)); hb0 = b0; hb1 = b1; hb2 = b2;
+                                // the record goes out now (a closer hit overwrites it): four registers fewer to carry through the walk, which is
+                                // what lets this kernel run six waves per SIMD; a ray that ends without a hit writes its miss record when it retires
+                                hit = true; rayTMax = t;
+                                hits.a[slot] = make_float4(t, __int_as_float((int32_t)(pi | ((tag & TAG_BIN_MASK) << 24))), b0, b1);
+                                if (hits.b) hits.b[slot] = make_float2(b2, __int_as_float(-1));
                             }
                             if (tag & TAG_LAST) leave = true;
                             else cur = (int)((~(pi + 1u)) & ~WIDE_LEAF_FIRST);
@@ -887,9 +920,9 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_A
             // retire finished rays
             if (active && cur == REF_NONE) {
                 if (ANY_HIT) occ[slot] = hit ? 1 : 0;
-                else {
-                    hits.a[slot] = make_float4(rayTMax, __int_as_float(hit ? prim : -1), hb0, hb1);
-                    if (hits.b) hits.b[slot] = make_float2(hb2, __int_as_float(-1));
+                else if (!hit) {
+                    hits.a[slot] = make_float4(rayTMax, __int_as_float(-1), 0.f, 0.f);
+                    if (hits.b) hits.b[slot] = make_float2(0.f, __int_as_float(-1));
                 }
                 active = false;
             }
