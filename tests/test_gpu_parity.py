@@ -562,7 +562,7 @@ def _hard_rays(nodes, n, seed):
     return o, d, tmax
 
 
-@pytest.mark.parametrize("fixture", ["killeroo.hprt", "living_room.hprt"])
+@pytest.mark.parametrize("fixture", ["killeroo.hprt", "living_room.hprt", "killeroo_simple.hprt", "simple_instanced.hprt"])
 def test_wide_and_binary_walks_agree(hprt, orc, fixture):
     """Plain calls take the leaf-exact four-wide walk (k_walk4, csrc/wide_bvh.h); hprt_debug_wide_walk(0) keeps the binary walk
     (k_trace).  Both must return the oracle's hits bit for bit — also for rays on which the bounds test meets inf and NaN."""
@@ -580,13 +580,21 @@ def test_wide_and_binary_walks_agree(hprt, orc, fixture):
     nodes, _ = bvh.arrays()
     n = 400000 if fixture == "killeroo.hprt" else 150000
     o, d, tmax = _hard_rays(nodes, n, 17)
-    t0, p0, b0, _ = oracle.intersect(o, d, tmax)
+    instanced = fixture == "simple_instanced.hprt"      # (spheres in an object instance: the two-level walk and the quadric tests)
+    if instanced:
+        t0, p0, i0, b0, _ = oracle.intersect_inst(o, d, tmax)
+    else:
+        t0, p0, b0, _ = oracle.intersect(o, d, tmax)
     occ0, _ = oracle.occluded(o, d, tmax)
     hprt.lib.hprt_debug_wide_walk.argtypes = [C.c_int]
     try:
         for wide in (1, 0):
             hprt.lib.hprt_debug_wide_walk(wide)
-            t1, p1, b1 = scene.intersect(o, d, tmax)
+            if instanced:
+                t1, p1, i1, b1 = scene.intersect_instanced(o, d, tmax)
+                assert np.array_equal(i0, i1), (wide, int((i0 != i1).sum()))
+            else:
+                t1, p1, b1 = scene.intersect(o, d, tmax)
             occ1 = scene.occluded(o, d, tmax)
             assert np.array_equal(p0, p1), (wide, int((p0 != p1).sum()))
             assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(b0.view(np.uint32), b1.view(np.uint32)), wide

@@ -577,6 +577,8 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     std::vector<DevPair> pairs((size_t)pairBase[aggs.size()]);
     std::vector<DevWide> wide;
     std::vector<float4> leafBox;
+    std::vector<int32_t> wideBase(aggs.size(), -1);      // first wide record of every aggregate that has a tree
+    bool wideOk = true; int wideNeedTop = 0, wideNeedObject = 0;
     // The ordered walk keeps at most one pending sibling per level, plus the sentinel of an instance: the kernel's
     // stack has HPRT_STACK_TOTAL = 64 entries (LDS + HBM part), as the reference's nodesToVisit[64]
     // (accelerators/bvh.cpp:365).  Deeper trees are refused here rather than walked wrongly.
@@ -625,9 +627,9 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
         // A leaf that holds exactly one triangle needs no stored box: Triangle::WorldBound is the min / max of its vertices
         // (shapes/triangle.cpp:180-186) — provided that is, bit for bit, what the node holds (a zero of either sign among the
         // coordinates would make the minimum's sign a matter of operand order: such leaves read their box like the others).
-        if (ai == 0 && d->n_instances == 0 && totalPrims < (1u << 28)) {
+        if (wideOk && totalPrims < (1u << 28)) {
             std::vector<int32_t> leafRefW(g.nNodes, WIDE_NONE);
-            leafBox.assign(2 * (size_t)totalPrims, make_float4(0.f, 0.f, 0.f, 0.f));
+            if (leafBox.empty()) leafBox.assign(2 * (size_t)totalPrims, make_float4(0.f, 0.f, 0.f, 0.f));
             for (uint32_t i = 0; i < g.nNodes; ++i) {
                 if ((nd[i].countAxis & 3u) != 3u) continue;
                 const uint32_t firstPrim = primBase[ai] + (uint32_t)nd[i].offset, count = nd[i].countAxis >> 2;
@@ -651,10 +653,13 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
                 }
             }
             int need = 0;
-            // (the walk's stack: LDS entries + the scene's deep-stack area; a tree that could need more keeps the binary walk)
-            if (!BuildWide(nd, g.nNodes, leafRefW.data(), &wide, &need) || need > HPRT_WIDE_STACK_MAX) { wide.clear(); leafBox.clear(); }
-        }
+            wideBase[ai] = (int32_t)wide.size();
+            if (!BuildWide(nd, g.nNodes, leafRefW.data(), &wide, &need)) wideOk = false;
+            if (ai == 0) wideNeedTop = need; else wideNeedObject = std::max(wideNeedObject, need);
+        } else wideOk = false;
     }
+    // (the wide walk's stack: LDS entries + the scene's deep-stack area; a scene that could need more keeps the binary walk)
+    if (!wideOk || wideNeedTop + (d->n_instances ? 1 + wideNeedObject : 0) > HPRT_WIDE_STACK_MAX || wideBase[0] != 0) { wide.clear(); leafBox.clear(); }
     if (topDepth + (d->n_instances ? 1 + objectDepth : 0) > HPRT_STACK_TOTAL)
         return SetError(HPRT_E_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack (accelerators/bvh.cpp:365 reserves the same)");
     std::vector<DevInstance> instances(d->n_instances);
@@ -668,6 +673,8 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
         bool ident = true;                                   // Transform::IsIdentity, core/transform.h:148-155
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) if (o.i2w.m[r][c] != (r == c ? 1.f : 0.f)) ident = false;
         o.identity = ident ? 1u : 0u; o.pad[0] = o.pad[1] = 0u;
+        // the entry into the wide records (k_walk4): the object's own tree, or its one primitive as a leaf "already reached" (no bounds test)
+        if (!wide.empty()) o.pad[0] = aggs[ai].nPrims > 1 ? (uint32_t)wideBase[ai] : ((~(uint32_t)primBase[ai]) & ~WIDE_LEAF_FIRST);
     }
     // Instance primitives of the top level: the transform moves next to the primitive (dev_scene.h, TAG_INST_INLINE / topEntry)
     std::vector<float4> topEntry;
@@ -686,6 +693,15 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
             topEntry[oi] = make_float4(m[0][3], m[1][3], m[2][3], u2f((uint32_t)in.root));
         }
     }
+    std::vector<float4> topEntryWide;
+    if (d->n_instances && !wide.empty()) {
+        topEntryWide = topEntry;
+        for (uint32_t oi = 0; oi < aggs[0].nPrims; ++oi) {
+            const size_t i = (size_t)primBase[0] + oi;
+            const uint32_t tag = f2u(tris[3 * i].w);
+            if ((tag & TAG_KIND_MASK) == TAG_INSTANCE && (tag & TAG_INST_INLINE)) topEntryWide[oi].w = u2f(instances[f2u(tris[3 * i + 2].w)].pad[0]);
+        }
+    }
     std::vector<int32_t> primes(PrimeTable().begin(), PrimeTable().end()), primeSums(PrimeSumTable().begin(), PrimeSumTable().end());
     std::vector<uint64_t> magic(primes.size());
     for (size_t i = 0; i < primes.size(); ++i) magic[i] = 0xffffffffffffffffull / (uint64_t)primes[i] + 1ull;
@@ -693,7 +709,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     HIP_TRY(upload(sc->nodes, pairs)); HIP_TRY(upload(sc->tris, tris)); HIP_TRY(upload(sc->primVtx, primVtx));
     HIP_TRY(upload(sc->primN, primN)); HIP_TRY(upload(sc->vUV, vUV)); HIP_TRY(upload(sc->vS, vS));
     HIP_TRY(upload(sc->shapes, shapes)); HIP_TRY(upload(sc->materials, mats)); HIP_TRY(upload(sc->lights, lights));
-    HIP_TRY(upload(sc->spheres, spheres)); HIP_TRY(upload(sc->instances, instances)); HIP_TRY(upload(sc->topEntry, topEntry)); HIP_TRY(upload(sc->lightFunc, func)); HIP_TRY(upload(sc->lightCdf, cdf));
+    HIP_TRY(upload(sc->spheres, spheres)); HIP_TRY(upload(sc->instances, instances)); HIP_TRY(upload(sc->topEntry, topEntry)); HIP_TRY(upload(sc->topEntryWide, topEntryWide)); HIP_TRY(upload(sc->lightFunc, func)); HIP_TRY(upload(sc->lightCdf, cdf));
     HIP_TRY(upload(sc->perms, perms)); HIP_TRY(upload(sc->primes, primes)); HIP_TRY(upload(sc->primeSums, primeSums));
     HIP_TRY(upload(sc->primeMagic, magic));
     HIP_TRY(upload(sc->textures, textures)); HIP_TRY(upload(sc->mipLevels, mipLevels)); HIP_TRY(upload(sc->texels, texels)); HIP_TRY(upload(sc->weightLut, weightLut));
@@ -718,6 +734,7 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
     dv.texels = sc->texels.as<float>(); dv.weightLut = sc->weightLut.as<float>();
     dv.instances = sc->instances.as<DevInstance>(); dv.nInstances = d->n_instances;
     dv.topEntry = topEntry.empty() ? nullptr : sc->topEntry.as<float4>(); dv.nTopPrims = (uint32_t)topEntry.size();
+    dv.topEntryWide = topEntryWide.empty() ? nullptr : sc->topEntryWide.as<float4>();
     dv.lightFunc = sc->lightFunc.as<float>(); dv.lightCdf = sc->lightCdf.as<float>(); dv.lightFuncInt = funcInt;
     dv.deepStack = sc->deepStack.as<uint2>();
     dv.perms = sc->perms.as<uint16_t>(); dv.primes = sc->primes.as<int32_t>(); dv.primeSums = sc->primeSums.as<int32_t>();

@@ -103,6 +103,7 @@ struct DevScene {
     // per top-level primitive (instanced scenes; null when there are none): {m03, m13, m23 of the instance's world-to-instance matrix, its
     // entry (DevInstance::root)}, fetched together with the primitive record so that entering an instance costs one memory round trip, not two
     const float4 *topEntry; uint32_t nTopPrims;
+    const float4 *topEntryWide;                                  // the same with the instance's entry into the WIDE records (k_walk4); DevInstance::pad[0] holds it too
     const float *lightFunc, *lightCdf; float lightFuncInt;      // Distribution1D (core/sampling.h:55-109): uniform or power strategy
     // SpatialLightDistribution (core/lightdistrib.cpp:77-300), computed for every voxel at scene creation: per voxel v the
     // Distribution1D's func[nLights] at voxFunc + v * nLights, cdf[nLights + 1] at voxCdf + v * (nLights + 1), funcInt at voxFuncInt[v]

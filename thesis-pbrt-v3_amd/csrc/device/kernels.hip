@@ -658,6 +658,12 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
 #ifndef HPRT_WALK4_ANY_WAVES
 #define HPRT_WALK4_ANY_WAVES 6
 #endif
+#ifndef HPRT_WALK4_INST_CLOSEST_WAVES
+#define HPRT_WALK4_INST_CLOSEST_WAVES 5
+#endif
+#ifndef HPRT_WALK4_INST_ANY_WAVES
+#define HPRT_WALK4_INST_ANY_WAVES 6
+#endif
 // two slots (bytes sh / 8 and sh / 8 + 1 of the near / far words) of a wide record: entry and exit distance of the dequantised boxes
 __device__ __forceinline__ void wide_slab2(uint32_t nX, uint32_t fX, uint32_t nY, uint32_t fY, uint32_t nZ, uint32_t fZ, int sh, float sx, float sy, float sz,
                                            float ox, float oy, float oz, float rox, float roy, float roz, float ivx, float ivy, float ivz, float robust,
@@ -703,15 +709,23 @@ __device__ __forceinline__ void wide_slab4(uint32_t nX, uint32_t fX, uint32_t nY
 }
 
 // PROF (HPRT_TRACE_PROFILE=1, tools/trace_profile.py): phase cycles and lane counts into g_traceProf, as k_trace<., 2>; [11] leaves whose
-// box was tested, [12] leaves whose box passed (closest hit) or hits whose leaf was checked / confirmed (any hit)
-template <bool ANY_HIT, bool PROF>
-__global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_ANY_WAVES : HPRT_WALK4_CLOSEST_WAVES) void k_walk4(DevScene sc, const uint32_t *queue, const uint32_t *countPtr,
-                                                            uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ, uint32_t *workCounter, uint32_t chunk, TraceTune tune) {
+// box was tested, [12] leaves whose box passed (closest hit) or hits whose leaf was checked / confirmed (any hit).
+// INST: object instances (TransformedPrimitive::Intersect / IntersectP, core/primitive.cpp:77-102) as in k_trace — a lane that meets an
+// instance primitive transforms its ray, pushes the REF_EXIT sentinel and walks the object's own wide records on the same stack; the
+// world tMax of the moment waits in a register (instances do not nest).  The leaf that holds the instance is a leaf like any other: its
+// exact box (the instance's world bound) decides whether the reference's walk reaches it.
+// QUAD: quadrics, with k_trace's exact pre-test and batched interval-arithmetic test.
+template <bool ANY_HIT, bool PROF, bool INST, bool QUAD>
+__global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : QUAD ? (ANY_HIT ? HPRT_QUAD_ANY_WAVES : HPRT_QUAD_CLOSEST_WAVES) : INST ? (ANY_HIT ? HPRT_WALK4_INST_ANY_WAVES : HPRT_WALK4_INST_CLOSEST_WAVES) : ANY_HIT ? HPRT_WALK4_ANY_WAVES : HPRT_WALK4_CLOSEST_WAVES)
+void k_walk4(DevScene sc, const uint32_t *queue, const uint32_t *countPtr, uint32_t countImm, RayStream rays, HitStream hits, uint8_t *occ, uint32_t *workCounter, uint32_t chunk, TraceTune tune) {
     constexpr int LDS_N = ANY_HIT ? HPRT_WIDE_LDS_ANY : HPRT_WIDE_LDS_CLOSEST;
     // [entry][thread]; closest hit: {ref, entry distance of the dequantised box}; any hit: the reference alone
     __shared__ uint32_t stackMem[(ANY_HIT ? 1 : 2) * LDS_N * HPRT_TRACE_BLOCK];
     uint32_t *const ldsRef = &stackMem[threadIdx.x];
     uint32_t *const ldsT = &stackMem[(ANY_HIT ? 0 : LDS_N * HPRT_TRACE_BLOCK) + threadIdx.x];
+    // INST: the world-space ray stays in LDS ([component][thread]) while the lane walks an instance with the transformed one
+    __shared__ float worldRayMem[INST ? 6 * HPRT_TRACE_BLOCK : 1];
+    float *const worldRay = &worldRayMem[INST ? threadIdx.x : 0];
     const uint32_t n = countPtr ? *countPtr : countImm;
     const uint32_t lane = __lane_id();
     unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -720,6 +734,8 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_A
     const auto wideRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.wide, 0, (int)(sc.nWide * 64u), 0x00020000);
     const auto triRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.tris, 0, (int)(sc.nPrims * 48u), 0x00020000);
     const auto boxRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.leafBox, 0, (int)(sc.nPrims * 32u), 0x00020000);
+    // INST: translation and wide entry of the instance a top-level primitive stands for (dev_scene.h, topEntryWide)
+    const auto entryRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(INST ? sc.topEntryWide : nullptr), 0, (int)(INST ? sc.nTopPrims * 16u : 0u), 0x00020000);
     const float robust = 1 + 2 * gamma_n(3);
     bool active = false, hit = false;
     uint32_t slot = 0;
@@ -729,6 +745,11 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_A
     bool ngX = false, ngY = false, ngZ = false;
     uint32_t negMask = 0u;
     int sp = 0, cur = REF_NONE;
+    uint32_t wait = 0u, waitInfo = 0u;      // QUAD: a quadric waits for the batched test (k_trace)
+    int inst = -1;                        // INST: instance being walked
+    bool instHit = false;                 // a hit was recorded inside the instance being walked
+    uint32_t instPrim = 0u;               // top-level ordered index of that instance's primitive | bit 31 "last of its leaf"
+    float savedTMax = 0.f;                // world tMax at the moment the instance was entered
     auto deepSlot = [&](int entry) -> volatile unsigned long long * {
         return (volatile unsigned long long *)sc.deepStack + (size_t)(entry - LDS_N) * HPRT_DEEP_THREADS + (blockIdx.x * HPRT_TRACE_BLOCK + threadIdx.x);
     };
@@ -744,9 +765,25 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_A
             uint32_t r, t;
             if (sp < LDS_N) { r = ldsRef[sp * HPRT_TRACE_BLOCK]; t = ANY_HIT ? 0u : ldsT[sp * HPRT_TRACE_BLOCK]; }
             else { const unsigned long long w = *deepSlot(sp); r = (uint32_t)w; t = (uint32_t)(w >> 32); }
+            if (INST && (int)r == REF_EXIT) return REF_EXIT;      // the instance's walk is over
             if (ANY_HIT || !(__uint_as_float(t) >= rayTMax)) return (int)r;
         }
         return REF_NONE;
+    };
+    auto set_ray = [&](vec3 o, vec3 d) {
+        ro = o;
+        invDir = vec3(1 / d.x, 1 / d.y, 1 / d.z);
+        ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
+        negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
+        shear = ray_shear(d, invDir);
+    };
+    // the ray's direction in the space being walked (not kept in registers: the walk needs 1 / d and the shear, the quadric tests d)
+    auto ray_dir = [&]() -> vec3 {
+        vec3 d;
+        if (INST) d = vec3(worldRay[3 * HPRT_TRACE_BLOCK], worldRay[4 * HPRT_TRACE_BLOCK], worldRay[5 * HPRT_TRACE_BLOCK]);
+        else { const float4 rb = rays.b[slot]; d = vec3(rb.x, rb.y, rb.z); }
+        if (INST && inst >= 0) d = xf_vector(sc.instances[inst].w2i, d);
+        return d;
     };
     bool moreWork = n > 0;
     uint32_t localNext = 0u, localEnd = 0u;
@@ -782,14 +819,13 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_A
                     if (idx < localEnd) {
                         slot = queue ? slotW : idx;
                         const float4 ra = rays.a[slot], rb = rays.b[slot];
-                        ro = vec3(ra.x, ra.y, ra.z);
-                        const vec3 rd(rb.x, rb.y, rb.z);
                         rayTMax = ra.w;
-                        invDir = vec3(1 / rd.x, 1 / rd.y, 1 / rd.z);
-                        ngX = invDir.x < 0; ngY = invDir.y < 0; ngZ = invDir.z < 0;
-                        negMask = (ngX ? 1u : 0u) | (ngY ? 2u : 0u) | (ngZ ? 4u : 0u);
-                        shear = ray_shear(rd, invDir);
-                        sp = 0; cur = 0; hit = false;
+                        set_ray(vec3(ra.x, ra.y, ra.z), vec3(rb.x, rb.y, rb.z));
+                        sp = 0; cur = 0; hit = false; wait = 0u; inst = -1; instHit = false;
+                        if (INST) {
+                            worldRay[0] = ra.x; worldRay[HPRT_TRACE_BLOCK] = ra.y; worldRay[2 * HPRT_TRACE_BLOCK] = ra.z;
+                            worldRay[3 * HPRT_TRACE_BLOCK] = rb.x; worldRay[4 * HPRT_TRACE_BLOCK] = rb.y; worldRay[5 * HPRT_TRACE_BLOCK] = rb.z;
+                        }
                         active = true;
                     }
                 }
@@ -851,72 +887,179 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, PROF ? 4 : ANY_HIT ? HPRT_WALK4_A
                     if (cur == WIDE_NONE) cur = pop();
                 }
                 ++steps;
-                if (steps >= tune.stepLimit || __popcll(__ballot(active && is_parked(cur))) >= tune.parkLimit) break;
+                if (steps >= tune.stepLimit || __popcll(__ballot(active && (INST ? wants_prim_phase(cur) : is_parked(cur)) && wait == 0u)) >= tune.parkLimit) break;
             }
             const unsigned long long pfT2 = PROF ? clock64() : 0ull;
             if (PROF) pf[2] += pfT2 - pfT1;
-            // phase 2: the parked leaves
+            unsigned long long pfSphere = 0ull;
+            // phase 2: the parked leaves (and, INST, lanes that leave an instance)
             while (true) {
-                const bool todo = active && is_parked(cur);
+                const bool todo = active && (INST ? wants_prim_phase(cur) : is_parked(cur)) && wait == 0u;
                 const int nPending = __popcll(__ballot(todo));
-                if (nPending == 0) break;
-                if (nPending < tune.primMin && __ballot(active && cur >= 0) != 0ull) break;
-                if (PROF) { pf[7] += 1; pf[8] += nPending; }
-                if (todo) {
-                    const uint32_t c = (uint32_t)cur;
-                    const uint32_t pi = ~(c | (WIDE_LEAF_BOXED | WIDE_LEAF_FIRST));
-                    const bool entrySingle = (c & (WIDE_LEAF_BOXED | WIDE_LEAF_FIRST)) == (WIDE_LEAF_BOXED | WIDE_LEAF_FIRST), entryBoxed = (c & WIDE_LEAF_BOXED) == 0u;
-                    u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48, 0, 0);
-                    u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 16, 0, 0);
-                    u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 32, 0, 0);
-                    u32x4 x0 = {0u, 0u, 0u, 0u}, x1 = {0u, 0u, 0u, 0u};
-                    if (!ANY_HIT && entryBoxed) { x0 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32, 0, 0); x1 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32 + 16, 0, 0); }
-                    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(x0), "+v"(x1));
-                    const uint32_t tag = v0.w;
-                    const vec3 p0(__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z)), p1(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
-                               p2(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z));
-                    // the leaf's own box, exactly: Bounds3::IntersectP as the reference evaluates it for this node (slab_test + tMin < tMax)
-                    auto leaf_reached = [&](bool fromVertices, u32x4 b0, u32x4 b1) -> bool {
-                        float lx = __uint_as_float(b0.x), ly = __uint_as_float(b0.y), lz = __uint_as_float(b0.z), hx = __uint_as_float(b0.w), hy = __uint_as_float(b1.x), hz = __uint_as_float(b1.y);
-                        if (fromVertices) {
-                            lx = fminf(fminf(p0.x, p1.x), p2.x); ly = fminf(fminf(p0.y, p1.y), p2.y); lz = fminf(fminf(p0.z, p1.z), p2.z);
-                            hx = fmaxf(fmaxf(p0.x, p1.x), p2.x); hy = fmaxf(fmaxf(p0.y, p1.y), p2.y); hz = fmaxf(fmaxf(p0.z, p1.z), p2.z);
-                        }
-                        float tEn;
-                        return slab_test(lx, hx, ly, hy, lz, hz, ro, invDir, ngX, ngY, ngZ, robust, &tEn) && tEn < rayTMax;
-                    };
-                    bool leave = false;      // done with this leaf: next pending slot
-                    if (!ANY_HIT) {
-                        const bool reached = (entrySingle || entryBoxed) ? leaf_reached(entrySingle, x0, x1) : true;
-                        if (PROF && (entrySingle || entryBoxed)) { ++pfLeaf; if (reached) ++pfLeafOk; }
-                        if (!reached) leave = true;
-                        else {
-                            float b0, b1, b2, t;
-                            if ((tag & TAG_KIND_MASK) == 0u && tri_test(p0, p1, p2, ro, rayTMax, shear, &b0, &b1, &b2, &t) && !(tag & TAG_BOGUS)) {
-                                // the record goes out now (a closer hit overwrites it): four registers fewer to carry through the walk, which is
-                                // what lets this kernel run six waves per SIMD; a ray that ends without a hit writes its miss record when it retires
-                                hit = true; rayTMax = t;
-                                hits.a[slot] = make_float4(t, __int_as_float((int32_t)(pi | ((tag & TAG_BIN_MASK) << 24))), b0, b1);
-                                if (hits.b) hits.b[slot] = make_float2(b2, __int_as_float(-1));
-                            }
-                            if (tag & TAG_LAST) leave = true;
-                            else cur = (int)((~(pi + 1u)) & ~WIDE_LEAF_FIRST);
-                        }
-                    } else {
-                        float b0, b1, b2, t;
-                        if ((tag & TAG_KIND_MASK) == 0u && tri_test(p0, p1, p2, ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
-                            // a hit counts if the reference's walk reaches this leaf; if it does not, none of the leaf's primitives is ever tested
-                            if (!entrySingle) { x0 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32, 0, 0); x1 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32 + 16, 0, 0); }
-                            if (PROF) ++pfLeaf;
-                            if (leaf_reached(entrySingle, x0, x1)) { hit = true; cur = REF_NONE; if (PROF) ++pfLeafOk; }
-                            else leave = true;
-                        } else if (tag & TAG_LAST) leave = true;
-                        else cur = (int)((~(pi + 1u)) & ~WIDE_LEAF_FIRST);
+                if (nPending != 0 && nPending < tune.primMin && __ballot(active && cur >= 0) != 0ull) break;
+                if (nPending != 0) {
+                    if (PROF) { pf[7] += 1; pf[8] += nPending; }
+                    if (INST && todo && cur == REF_EXIT) {
+                        // the instance's walk is over, back to world space: r.tMax = ray.tMax only if the instance was hit
+                        // (core/primitive.cpp:85-86); continue with the top-level leaf the instance belongs to
+                        const float worldT = instHit ? rayTMax : savedTMax;
+                        set_ray(vec3(worldRay[0], worldRay[HPRT_TRACE_BLOCK], worldRay[2 * HPRT_TRACE_BLOCK]),
+                                vec3(worldRay[3 * HPRT_TRACE_BLOCK], worldRay[4 * HPRT_TRACE_BLOCK], worldRay[5 * HPRT_TRACE_BLOCK]));
+                        rayTMax = worldT;
+                        inst = -1; instHit = false;
+                        if (instPrim & 0x80000000u) cur = pop();
+                        else cur = (int)((~((instPrim & 0x7fffffffu) + 1u)) & ~WIDE_LEAF_FIRST);
                     }
-                    if (leave) cur = pop();
+                    const bool pending = todo && is_parked(cur);      // (a lane that just left an instance may be at its next primitive)
+                    if (pending) {
+                        const uint32_t c = (uint32_t)cur;
+                        const uint32_t pi = ~(c | (WIDE_LEAF_BOXED | WIDE_LEAF_FIRST));
+                        const bool entrySingle = (c & (WIDE_LEAF_BOXED | WIDE_LEAF_FIRST)) == (WIDE_LEAF_BOXED | WIDE_LEAF_FIRST), entryBoxed = (c & WIDE_LEAF_BOXED) == 0u;
+                        u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48, 0, 0);
+                        u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 16, 0, 0);
+                        u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(triRsrc, pi * 48 + 32, 0, 0);
+                        u32x4 x0 = {0u, 0u, 0u, 0u}, x1 = {0u, 0u, 0u, 0u}, ve = {0u, 0u, 0u, 0u};
+                        // closest hit: the leaf's box decides before anything in it is tested; any hit: only a reported hit asks for it — except for
+                        // quadrics and instances, whose tests are worth skipping (and an instance must not be entered at all if the walk never gets there)
+                        if (entryBoxed && (!ANY_HIT || INST || QUAD)) { x0 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32, 0, 0); x1 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32 + 16, 0, 0); }
+                        if (INST && inst < 0) ve = __builtin_amdgcn_raw_buffer_load_b128(entryRsrc, pi * 16, 0, 0);
+                        if (INST) asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(x0), "+v"(x1), "+v"(ve));
+                        else asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(x0), "+v"(x1));
+                        const uint32_t tag = v0.w;
+                        const vec3 p0(__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z)), p1(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z)),
+                                   p2(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z));
+                        // the leaf's own box, exactly: Bounds3::IntersectP as the reference evaluates it for this node (slab_test + tMin < tMax)
+                        auto leaf_reached = [&](bool fromVertices, u32x4 b0, u32x4 b1) -> bool {
+                            float lx = __uint_as_float(b0.x), ly = __uint_as_float(b0.y), lz = __uint_as_float(b0.z), hx = __uint_as_float(b0.w), hy = __uint_as_float(b1.x), hz = __uint_as_float(b1.y);
+                            if (fromVertices) {
+                                lx = fminf(fminf(p0.x, p1.x), p2.x); ly = fminf(fminf(p0.y, p1.y), p2.y); lz = fminf(fminf(p0.z, p1.z), p2.z);
+                                hx = fmaxf(fmaxf(p0.x, p1.x), p2.x); hy = fmaxf(fmaxf(p0.y, p1.y), p2.y); hz = fmaxf(fmaxf(p0.z, p1.z), p2.z);
+                            }
+                            float tEn;
+                            return slab_test(lx, hx, ly, hy, lz, hz, ro, invDir, ngX, ngY, ngZ, robust, &tEn) && tEn < rayTMax;
+                        };
+                        const bool isTri = (tag & TAG_KIND_MASK) == 0u;
+                        bool leave = false;      // done with this leaf: next pending slot
+                        // the entry test of the leaf: always for closest-hit rays; for any-hit rays up front only where it saves an expensive test
+                        bool reached = true;
+                        if ((entrySingle || entryBoxed) && (!ANY_HIT || ((INST || QUAD) && entryBoxed && !isTri))) {
+                            reached = leaf_reached(entrySingle, x0, x1);
+                            if (PROF) { ++pfLeaf; if (reached) ++pfLeafOk; }
+                        }
+                        // any-hit rays: has the box of the leaf this primitive belongs to been tested (and passed)?
+                        const bool boxKnown = !ANY_HIT || ((INST || QUAD) && entryBoxed && !isTri);
+                        if (!reached) leave = true;
+                        else if (isTri) {
+                            float b0, b1, b2, t;
+                            if (tri_test(p0, p1, p2, ro, rayTMax, shear, &b0, &b1, &b2, &t)) {
+                                if (!ANY_HIT) {
+                                    if (!(tag & TAG_BOGUS)) {
+                                        // the record goes out now (a closer hit overwrites it): four registers fewer to carry through the walk, which is
+                                        // what lets this kernel run six waves per SIMD; a ray that ends without a hit writes its miss record when it retires
+                                        hit = true; rayTMax = t;
+                                        hits.a[slot] = make_float4(t, __int_as_float((int32_t)(pi | ((tag & TAG_BIN_MASK) << 24))), b0, b1);
+                                        if (hits.b) hits.b[slot] = make_float2(b2, __int_as_float(INST ? inst : -1));
+                                        if (INST) instHit = inst >= 0;
+                                    }
+                                    if (tag & TAG_LAST) leave = true; else cur = (int)((~(pi + 1u)) & ~WIDE_LEAF_FIRST);
+                                } else {
+                                    // a hit counts if the reference's walk reaches this leaf; if it does not, none of the leaf's primitives is ever tested
+                                    bool ok = true;
+                                    if (c & WIDE_LEAF_FIRST) {      // (a later primitive of a leaf is only ever reached through a tested box: see below)
+                                        if (!entrySingle) { x0 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32, 0, 0); x1 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32 + 16, 0, 0); }
+                                        if (PROF) ++pfLeaf;
+                                        ok = leaf_reached(entrySingle, x0, x1);
+                                        if (PROF && ok) ++pfLeafOk;
+                                    }
+                                    if (ok) { hit = true; cur = REF_NONE; } else leave = true;
+                                }
+                            } else if (tag & TAG_LAST) leave = true;
+                            else if (!ANY_HIT) cur = (int)((~(pi + 1u)) & ~WIDE_LEAF_FIRST);
+                            else {
+                                // any hit, a leaf of several primitives whose first one missed: the box has not been asked yet; the next primitive keeps
+                                // the "entry" state (boxed), so that a hit on it still checks the leaf's box
+                                cur = (int)((~(pi + 1u)) & ~WIDE_LEAF_BOXED);
+                            }
+                        } else if (INST && (tag & TAG_KIND_MASK) == TAG_INSTANCE) {
+                            // TransformedPrimitive::Intersect: Ray ray = Inverse(InterpolatedPrimToWorld)(r), i.e.
+                            // Transform::operator()(const Ray &) (core/transform.h:251-264); then walk the object's aggregate
+                            inst = (int)v2.w;
+                            instPrim = pi | ((tag & TAG_LAST) ? 0x80000000u : 0u);
+                            instHit = false;
+                            mat4 W;
+                            int root;
+                            if (tag & TAG_INST_INLINE) {      // affine: the matrix came with the primitive
+                                W.m[0][0] = __uint_as_float(v0.x); W.m[0][1] = __uint_as_float(v0.y); W.m[0][2] = __uint_as_float(v0.z); W.m[0][3] = __uint_as_float(ve.x);
+                                W.m[1][0] = __uint_as_float(v1.x); W.m[1][1] = __uint_as_float(v1.y); W.m[1][2] = __uint_as_float(v1.z); W.m[1][3] = __uint_as_float(ve.y);
+                                W.m[2][0] = __uint_as_float(v2.x); W.m[2][1] = __uint_as_float(v2.y); W.m[2][2] = __uint_as_float(v2.z); W.m[2][3] = __uint_as_float(ve.z);
+                                W.m[3][0] = 0.f; W.m[3][1] = 0.f; W.m[3][2] = 0.f; W.m[3][3] = 1.f;
+                                root = (int)ve.w;
+                            } else { const DevInstance &in = sc.instances[inst]; W = in.w2i; root = (int)in.pad[0]; }      // (pad[0]: the object's wide entry)
+                            vec3 oErr;
+                            vec3 o2 = xf_point_err(W, ro, &oErr);
+                            const vec3 d2 = xf_vector(W, vec3(worldRay[3 * HPRT_TRACE_BLOCK], worldRay[4 * HPRT_TRACE_BLOCK], worldRay[5 * HPRT_TRACE_BLOCK]));
+                            const float lengthSquared = d2.x * d2.x + d2.y * d2.y + d2.z * d2.z;
+                            float tm = rayTMax;
+                            if (lengthSquared > 0) {
+                                const float dt = dot(vabs(d2), oErr) / lengthSquared;
+                                o2 = o2 + d2 * dt;
+                                tm -= dt;
+                            }
+                            savedTMax = rayTMax;
+                            push(REF_EXIT, 0.f);
+                            rayTMax = tm;
+                            set_ray(o2, d2);
+                            cur = root;
+                        } else if (QUAD) {
+                            // a quadric: the cheap exact pre-test (dev_intersect.h) settles most of them here; the rest wait for
+                            // the batched interval-arithmetic test
+                            DRay rr; rr.o = ro; rr.tMax = rayTMax; rr.d = ray_dir();
+                            const bool maybe = sphere_may_hit(sc.spheres[v2.w], rr);
+                            if (maybe) { wait = 1u; waitInfo = v2.w | ((tag & TAG_LAST) ? 0x80000000u : 0u) | ((tag & TAG_BIN_MASK) == (BIN_TEXTURED << TAG_BIN_SHIFT) ? 0x40000000u : 0u) | (boxKnown ? 0x20000000u : 0u); }
+                            else if (tag & TAG_LAST) leave = true;
+                            else cur = (int)((~(pi + 1u)) & ~(boxKnown ? WIDE_LEAF_FIRST : WIDE_LEAF_BOXED));
+                        }
+                        if (leave) cur = pop();
+                    }
+                    continue;
                 }
+                if (!QUAD) break;
+                const bool slow = active && wait != 0u;
+                const int nWait = __popcll(__ballot(slow));
+                if (nWait == 0) break;
+                const bool canWalk = __ballot(active && cur >= 0) != 0ull;
+                if (nWait < tune.sphereLimit && canWalk) break;      // keep waiting, let the others walk
+                const unsigned long long pfT3 = PROF ? clock64() : 0ull;
+                if (wait == 1u) {
+                    const uint32_t pi = ~((uint32_t)cur | (WIDE_LEAF_BOXED | WIDE_LEAF_FIRST));
+                    wait = 0u;
+                    DRay rr; rr.o = ro; rr.tMax = rayTMax; rr.d = ray_dir();
+                    DRay robj; vec3 ph; float phi, t;
+                    bool done = false, leave = false;
+                    if (sphere_test(sc.spheres[waitInfo & 0x1fffffffu], rr, &robj, &ph, &phi, &t)) {
+                        bool ok = true;
+                        if (ANY_HIT && !(waitInfo & 0x20000000u)) {      // the leaf's box has not been asked yet
+                            const u32x4 x0 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32, 0, 0), x1 = __builtin_amdgcn_raw_buffer_load_b128(boxRsrc, pi * 32 + 16, 0, 0);
+                            float tEn;
+                            ok = slab_test(__uint_as_float(x0.x), __uint_as_float(x0.w), __uint_as_float(x0.y), __uint_as_float(x1.x), __uint_as_float(x0.z), __uint_as_float(x1.y),
+                                           ro, invDir, ngX, ngY, ngZ, robust, &tEn) && tEn < rayTMax;
+                        }
+                        if (!ok) leave = true;
+                        else if (ANY_HIT) { hit = true; done = true; }
+                        else {
+                            hit = true; rayTMax = t;
+                            hits.a[slot] = make_float4(t, __int_as_float((int32_t)(pi | (((waitInfo & 0x40000000u) ? BIN_TEXTURED : BIN_GENERIC) << HIT_BIN_SHIFT))), 0.f, 0.f);
+                            if (hits.b) hits.b[slot] = make_float2(0.f, __int_as_float(INST ? inst : -1));
+                            if (INST) instHit = inst >= 0;
+                        }
+                    }
+                    if (done) cur = REF_NONE;
+                    else if (leave || (waitInfo & 0x80000000u)) cur = pop();
+                    else cur = (int)((~(pi + 1u)) & ~(((waitInfo & 0x20000000u) || !ANY_HIT) ? WIDE_LEAF_FIRST : WIDE_LEAF_BOXED));
+                }
+                if (PROF) pfSphere += clock64() - pfT3;
             }
-            if (PROF) pf[3] += clock64() - pfT2;
+            if (PROF) { pf[3] += clock64() - pfT2 - pfSphere; pf[4] += pfSphere; }
             // retire finished rays
             if (active && cur == REF_NONE) {
                 if (ANY_HIT) occ[slot] = hit ? 1 : 0;
@@ -1722,21 +1865,27 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     if (inst && anyHit && !tuneAnyFromEnv) { tune.refillBelow = 48; tune.parkLimit = 32; tune.stepLimit = 10; tune.primMin = 6; }
     // Plain renders of scenes that have the four-wide structure take the leaf-exact walk (k_walk4; HPRT_WIDE_WALK=0 or
     // hprt_debug_wide_walk(0) keep the binary walk: A/B runs and the tests that hold the two against each other)
-    if (!count && sc.wide != nullptr && !inst && !quad && WideWalkEnabled()) {
+    if (!count && sc.wide != nullptr && WideWalkEnabled()) {
         static const uint32_t wClosestPerCu = [] { const char *e = getenv("HPRT_WALK4_CLOSEST_PER_CU"); return e ? (uint32_t)std::min((int)HPRT_WALK4_CLOSEST_WAVES, std::max(1, atoi(e))) : (uint32_t)HPRT_WALK4_CLOSEST_WAVES; }();
         static const uint32_t wAnyPerCu = [] { const char *e = getenv("HPRT_WALK4_ANY_PER_CU"); return e ? (uint32_t)std::min((int)HPRT_WALK4_ANY_WAVES, std::max(1, atoi(e))) : (uint32_t)HPRT_WALK4_ANY_WAVES; }();
         static const TraceTune wTuneClosest = [] { TraceTune t{52, 32, 8, 4, 12}; if (const char *e = getenv("HPRT_WALK4_TUNE")) sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin); return t; }();
-        static const TraceTune wTuneAny = [] { TraceTune t{40, 24, 6, 4, 3}; if (const char *e = getenv("HPRT_WALK4_TUNE_ANY")) sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin); return t; }();
-        const uint32_t wBlocks = std::min(256u * (profile ? 4u : anyHit ? wAnyPerCu : wClosestPerCu), blockCap);
+        static const TraceTune wTuneAny = [] { TraceTune t{48, 24, 6, 4, 3}; if (const char *e = getenv("HPRT_WALK4_TUNE_ANY")) sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin); return t; }();
+        // workgroups per CU = waves per SIMD the variant is compiled for
+        const uint32_t wPerCu = profile ? 4u : quad ? (anyHit ? (uint32_t)HPRT_QUAD_ANY_WAVES : (uint32_t)HPRT_QUAD_CLOSEST_WAVES) : inst ? (anyHit ? (uint32_t)HPRT_WALK4_INST_ANY_WAVES : (uint32_t)HPRT_WALK4_INST_CLOSEST_WAVES) : anyHit ? wAnyPerCu : wClosestPerCu;
+        const uint32_t wBlocks = std::min(256u * wPerCu, blockCap);
         dim3 wGrid(std::min(blocks_for(gridItems, HPRT_TRACE_BLOCK), wBlocks));
         const uint32_t wWaves = wGrid.x * (HPRT_TRACE_BLOCK / 64);
         uint32_t wChunk = gridItems / (wWaves * chunkDiv);
         wChunk = std::max(64u, std::min(chunkMax, wChunk)) & ~63u;
-        if (profile) {
-            if (anyHit) hipLaunchKernelGGL((k_walk4<true, true>), wGrid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, workCounter, wChunk, wTuneAny);
-            else hipLaunchKernelGGL((k_walk4<false, true>), wGrid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, workCounter, wChunk, wTuneClosest);
-        } else if (anyHit) hipLaunchKernelGGL((k_walk4<true, false>), wGrid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, workCounter, wChunk, wTuneAny);
-        else hipLaunchKernelGGL((k_walk4<false, false>), wGrid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, workCounter, wChunk, wTuneClosest);
+        const TraceTune wTune = anyHit ? wTuneAny : wTuneClosest;
+#define HPRT_WALK4_LAUNCH(A, P, I, Q) hipLaunchKernelGGL((k_walk4<A, P, I, Q>), wGrid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, workCounter, wChunk, wTune)
+        // (the profiling variant exists with the quadric code only)
+#define HPRT_WALK4_PICK(A) do { if (profile) { if (inst) HPRT_WALK4_LAUNCH(A, true, true, true); else HPRT_WALK4_LAUNCH(A, true, false, true); } \
+                                else if (inst) { if (quad) HPRT_WALK4_LAUNCH(A, false, true, true); else HPRT_WALK4_LAUNCH(A, false, true, false); } \
+                                else { if (quad) HPRT_WALK4_LAUNCH(A, false, false, true); else HPRT_WALK4_LAUNCH(A, false, false, false); } } while (0)
+        if (anyHit) HPRT_WALK4_PICK(true); else HPRT_WALK4_PICK(false);
+#undef HPRT_WALK4_PICK
+#undef HPRT_WALK4_LAUNCH
         return;
     }
 #define HPRT_TRACE_LAUNCH(A, M, I, Q) hipLaunchKernelGGL((k_trace<A, M, I, Q>), grid, block, 0, st, sc, queue, countPtr, countImm, rays, hits, occ, counters, rayStats, workCounter, chunk, tune)

@@ -60,7 +60,7 @@ struct HprtScene {
     hipEvent_t lastUse = nullptr; bool lastUsePending = false;
     hprt::DevScene dev;
     hprt::DevBuf textures, mipLevels, texels, weightLut;
-    hprt::DevBuf nodes, tris, primVtx, primN, vUV, vS, shapes, materials, lights, spheres, instances, topEntry, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
+    hprt::DevBuf nodes, tris, primVtx, primN, vUV, vS, shapes, materials, lights, spheres, instances, topEntry, topEntryWide, lightFunc, lightCdf, perms, primes, primeSums, primeMagic;
     hprt::DevBuf envLights, envData;      // infinite lights: DevEnvLight table and their Distribution2D tables
     hprt::DevBuf wide, leafBox;           // the leaf-exact walk structure (wide_bvh.h)
     hprt::DevBuf counters, workCounter, deepStack;

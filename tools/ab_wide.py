@@ -24,6 +24,13 @@ if args.scene == "atrium":
     text, _ = scene_gen.atrium(1.0)
     path = os.path.join(tempfile.mkdtemp(), "atrium.pbrt"); open(path, "w").write(text)
     model = hprt.Model.parse(path)
+elif args.scene == "instanced-10m":
+    import scene_gen
+    text, _ = scene_gen.instanced_killeroo(os.path.join(ROOT, "tests", "golden", "killeroo.hprt"))
+    path = os.path.join(tempfile.mkdtemp(), "instanced10m.pbrt"); open(path, "w").write(text)
+    model = hprt.Model.parse(path)
+elif args.scene == "killeroo-simple":
+    model = hprt.Model.load(os.path.join(ROOT, "tests", "golden", "killeroo_simple.hprt"))
 elif args.scene == "living-room":
     model = hprt.Model.load(os.path.join(ROOT, "tests", "golden", "living_room.hprt"))
 else:
@@ -45,7 +52,10 @@ tmax = np.full(n, np.inf, np.float32); tmax[n // 2:] = rng.uniform(0, np.linalg.
 res = {}
 for wide in (0, 1):
     lib.hprt_debug_wide_walk(wide)
-    t, p, b = scene.intersect(o, d, tmax)
+    if args.scene == "instanced-10m":
+        t, p, inst_, b = scene.intersect_instanced(o, d, tmax); b = np.concatenate([b, inst_[:, None].astype(np.float32)], axis=1)
+    else:
+        t, p, b = scene.intersect(o, d, tmax)
     occ = scene.occluded(o, d, tmax)
     res[wide] = (t.copy(), p.copy(), b.copy(), occ.copy())
 same = all(np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b_).view(np.uint8)) for a, b_ in zip(res[0], res[1]))
