@@ -36,7 +36,7 @@ def _trace(kernels, any_hit, mode, inst, quad):
 
 def test_the_library_is_built_for_gfx950_with_every_kernel(kernels):
     names = " ".join(kernels)
-    for k in ("k_trace", "k_shade", "k_bin", "k_resolve", "k_generate", "k_store_radiance", "k_find_irregular", "k_film_own", "k_film_foreign",
+    for k in ("k_trace", "k_walk4", "k_shade", "k_bin", "k_resolve", "k_generate", "k_store_radiance", "k_find_irregular", "k_film_own", "k_film_foreign",
               "k_film_foreign_export", "k_film_apply_records", "k_voxel_contrib", "k_voxel_dist"):
         assert k in names, k
 
@@ -72,3 +72,23 @@ def test_shading_variants_keep_their_occupancy(kernels, mode, tex, max_vgpr, max
         assert k[".vgpr_count"] <= max_vgpr and k[".private_segment_fixed_size"] <= max_scratch, (key, k[".vgpr_count"], k[".private_segment_fixed_size"])
         if mode != 2:
             assert k[".vgpr_spill_count"] == 0, key
+
+
+@pytest.mark.parametrize("any_hit,inst,quad,max_vgpr,lds", [
+    (0, 0, 0, 80, 12 * 256 * 8),                  # closest hit: six waves per SIMD (512 / 6 -> 80 registers), 24 KB of {ref, distance} stack
+    (1, 0, 0, 80, 20 * 256 * 4),                  # any hit: six, 20 KB of bare references
+    (0, 1, 0, 96, 12 * 256 * 8 + 6 * 256 * 4),    # two-level scenes: the world ray waits in 6 KB of LDS; closest five waves
+    (1, 1, 0, 80, 20 * 256 * 4 + 6 * 256 * 4),    # ... any hit six (26,624 B x 6 is the whole 160 KB of a CU, not a byte to spare)
+    (0, 0, 1, 128, 12 * 256 * 8),                 # with the quadric code: four
+    (1, 0, 1, 96, 20 * 256 * 4),                  # ... five
+])
+def test_wide_walk_kernels_fit_their_occupancy(kernels, any_hit, inst, quad, max_vgpr, lds):
+    """k_walk4<any hit, profiling, instances, quadrics> (the leaf-exact walk of plain renders): the launch code sizes its grids for these
+    occupancies (kernels.hip, LaunchTrace), and none of the variants may spill inside the walk."""
+    key = "k_walk4ILb%dELb0ELb%dELb%dE" % (any_hit, inst, quad)
+    found = [v for n, v in kernels.items() if key in n]
+    assert len(found) == 1, key
+    k = found[0]
+    assert k[".vgpr_count"] <= max_vgpr and k[".vgpr_spill_count"] == 0, (key, k[".vgpr_count"], k[".vgpr_spill_count"])
+    assert lds <= k[".group_segment_fixed_size"] <= lds + 64, k[".group_segment_fixed_size"]
+    assert k[".group_segment_fixed_size"] * (6 if max_vgpr == 80 else 5 if max_vgpr == 96 else 4) <= 160 * 1024
