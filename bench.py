@@ -480,8 +480,42 @@ def main():
         # The contract's model figure: algorithmic bytes / kernel time.  The BVH is served by L2 / MALL, so it is a
         # request rate, not an HBM utilisation, and it is NOT what `frac` reports: `frac` is filled from the measured HBM traffic
         # of the counter summary below (and stays null when there is none for this build).
+        # which walk the timed steps took, and — for the leaf-exact wide walk (k_walk4) — what it fetched: one untimed render of the
+        # phase-profile variant counts the lane-steps (one 64-byte wide record each: four 16-byte requests) and the leaf iterations
+        # (one 48-byte primitive record each: three requests; leaves that are not one triangle add their 32-byte box)
+        import ctypes as C
+        wide = False
+        try:
+            fn = hprt.lib.hprt_debug_scene_walk; fn.argtypes = [C.c_void_p]; fn.restype = C.c_int
+            wide = bool(fn(w.scene._h))
+        except Exception:
+            wide = False
+        walk = None
+        if wide:
+            try:
+                mode = hprt.lib.hprt_debug_trace_profile_mode; mode.argtypes = [C.c_int]; mode.restype = C.c_int
+                prof = hprt.lib.hprt_debug_trace_profile; prof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]; prof.restype = C.c_int
+                buf = (C.c_ulonglong * 32)()
+                mode(1); prof(buf, 1)
+                opt_save = w.opt.spp
+                w.opt.spp = max(1, min(opt_save, 16))      # (the per-ray averages do not depend on the sample count; the profile variants are slow)
+                st_p = w.render()
+                torch.cuda.synchronize(dev)
+                w.opt.spp = opt_save
+                prof(buf, 1); mode(-1)
+                v = [int(x) for x in buf]
+                nr = max(1, st_p["rays"])
+                walk = {"kernel": "k_walk4<closest>", "records_per_ray": round(v[6] / nr, 3), "leaf_iterations_per_ray": round(v[8] / nr, 3),
+                        "leaf_boxes_tested_per_ray": round(v[11] / nr, 3), "leaf_boxes_passed_per_ray": round(v[12] / nr, 3),
+                        "lanes_per_record_step": round(v[6] / max(1, v[5]), 1), "lanes_per_leaf_iteration": round(v[8] / max(1, v[7]), 1),
+                        "requests_per_ray": round((4.0 * v[6] + 3.0 * v[8]) / nr, 2),
+                        "any_hit": {"records_per_ray": round(v[16 + 6] / max(1, st_p["shadow_rays"]), 3), "leaf_iterations_per_ray": round(v[16 + 8] / max(1, st_p["shadow_rays"]), 3)},
+                        "what": "one untimed render of the phase-profile variant: 64-byte wide records stepped and primitive records tested per closest-hit ray; "
+                                "requests = 4 x records + 3 x leaf iterations (16 bytes each)"}
+            except Exception as e:
+                walk = {"error": repr(e)}
         roof = {
-            "bound": None, "kernel": "k_trace<closest>", "achieved": None, "peak": HBM_PEAK_GBS, "peak_measured": None, "unit": "GB/s",
+            "bound": None, "kernel": "k_walk4<closest>" if wide else "k_trace<closest>", "walk": walk, "achieved": None, "peak": HBM_PEAK_GBS, "peak_measured": None, "unit": "GB/s",
             "frac": None, "traffic": None,
             "algorithmic": {"bytes_per_ray": round(bytes_per_ray, 1), "nodes_fetched_per_ray": round(v_per_ray, 3), "prim_tests_per_ray": round(t_per_ray, 3),
                             "bytes_per_launch": round(ext_rays * bytes_per_ray / max(1, ext_launches)), "rate_gbs": round(achieved, 2),
@@ -541,12 +575,20 @@ def main():
             # what the traversal kernel is actually held against: the rate at which this GPU serves its access pattern.  A child-pair
             # record is 64 bytes (two nodes of V), a triangle 48 bytes (three of the four 16-byte requests of a record)
             a = roof["algorithmic"]
-            rec_per_ray = a["nodes_fetched_per_ray"] / 2.0 + 0.75 * a["prim_tests_per_ray"]
+            wk = roof.get("walk")
+            if wk and wk.get("requests_per_ray"):
+                # the wide walk: 16-byte requests counted by its own profile variant, in units of 64-byte records (four requests)
+                rec_per_ray = wk["requests_per_ray"] / 4.0
+                note = ("k_walk4<closest>: (4 x wide records stepped + 3 x primitive records tested) / 4 per ray x its ray rate, over the rate at which this GPU "
+                        "serves per-lane 64-byte gathers (four 16-byte requests) that all hit L1; the binary walk k_trace ran at 0.82 of it, the wide walk asks for half "
+                        "as many records per ray and is no longer held by this rate alone (the kernel's HBM fraction is `frac`)")
+            else:
+                rec_per_ray = a["nodes_fetched_per_ray"] / 2.0 + 0.75 * a["prim_tests_per_ray"]
+                note = ("child-pair records (V / 2) + triangle records (0.75 T) per ray x k_trace<closest>'s ray rate, over the rate at which this "
+                        "GPU serves per-lane 64-byte gathers that all hit L1 (the bound of this access pattern; the kernel's HBM fraction is `frac`)")
             ach = roof["kernel_mrays_per_s"] * 1e6 * rec_per_ray / 1e9
             roof["gather"] = {"achieved": round(ach, 1), "peak_measured": gather_peak, "unit": "Grecords/s", "frac": round(ach / gather_peak["best"], 4),
-                              "records_per_ray": round(rec_per_ray, 2),
-                              "note": "child-pair records (V / 2) + triangle records (0.75 T) per ray x k_trace<closest>'s ray rate, over the rate at which this "
-                                      "GPU serves per-lane 64-byte gathers that all hit L1 (the bound of this access pattern; the kernel's HBM fraction is `frac`)"}
+                              "records_per_ray": round(rec_per_ray, 2), "note": note}
             if workload == args.workload:      # (the BVH-sized probe was run for the headline's BVH)
                 roof["gather"]["over_bvh_like_model"] = round(ach / gather_peak["bvh_like"]["best"], 4)
             else:
@@ -567,7 +609,7 @@ def main():
             if not cj:
                 return
             k = cj["kernels"]
-            tc = k.get("k_trace<closest>") or k.get("k_trace<closest>[inst]")
+            tc = (k.get("k_walk4<closest>") or k.get("k_walk4<closest>[inst]")) if roof["kernel"].startswith("k_walk4") else (k.get("k_trace<closest>") or k.get("k_trace<closest>[inst]"))
             if tc and tc.get("hbm_bytes_per_launch") is not None:
                 roof["traffic"] = round(tc["hbm_bytes_per_launch"])
                 # per launch of THIS run: the summary's bytes per launch over this run's HIP-event launch time (the two runs launch

@@ -535,6 +535,9 @@ def test_bench_line_holds_fractions_of_measured_peaks():
     g = roof["gather"]
     assert 100 < g["peak_measured"]["best"] < 400 and 0 < g["frac"] <= 1 and g["peak_measured"]["bvh_like"]["best"] <= g["peak_measured"]["best"] * 1.02
     assert isinstance(roof["counters_stale"], bool) and roof["counters_code_object_sha256"] and roof["library_code_object_sha256"]
+    # plain renders take the leaf-exact wide walk, and the line says what it fetched per ray (counted by its own profile variant)
+    assert roof["kernel"] == "k_walk4<closest>" and 1 < roof["walk"]["records_per_ray"] < 100 and 0 < roof["walk"]["leaf_iterations_per_ray"] < 50
+    assert abs(roof["walk"]["requests_per_ray"] - (4 * roof["walk"]["records_per_ray"] + 3 * roof["walk"]["leaf_iterations_per_ray"])) < 0.05
     if roof["frac"] is not None:
         assert 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
         assert roof["bound"] in ("hbm", "valu_issue", "l1_gather") and all(0 < v <= 1 for v in roof["bound_candidates"].values())

@@ -35,7 +35,7 @@ def test_every_fraction_in_the_summary_is_one():
     assert {"atrium", "killeroo-simple", "living-room", "instanced-10m"} <= set(workloads)
     for w in workloads:
         assert 0 < j[w]["step_hbm_frac"] <= 1
-        assert any(k.startswith("k_trace<closest>") for k in j[w]["kernels"])
+        assert any(k.startswith("k_walk4<closest>") or k.startswith("k_trace<closest>") for k in j[w]["kernels"])      # (k_walk4: the leaf-exact wide walk of plain renders)
         for name, k in j[w]["kernels"].items():
             for f in ("hbm_frac", "valu_issue_frac", "lane_utilisation", "useful_lane_frac", "wait_frac", "l1_miss_rate", "l2_hit_rate", "l1_tagconflict_stall_frac"):
                 if k.get(f) is not None:

@@ -793,6 +793,8 @@ int hprt_scene_create(const HprtSceneDesc *d, int device, HprtScene **out) try {
 } catch (...) { return hprt::HandleException(); }
 
 // Diagnostics hook (not part of include/hprt.h): the 128 sample points of a voxel, RadicalInverse(0..4, i) as [5][128]
+// Diagnostics hook (not part of include/hprt.h): 1 when plain renders of this scene take the leaf-exact wide walk (k_walk4), 0 for the binary walk
+__attribute__((visibility("default"))) int hprt_debug_scene_walk(HprtScene *s) { return s && hprt::WideWalkInUse(s->dev) ? 1 : 0; }
 __attribute__((visibility("default"))) int hprt_debug_poison_workspace(HprtScene *s, int byte) { if (!s) return HPRT_E_INVALID; s->poisonByte = byte < 0 ? -1 : (byte & 255); return HPRT_OK; }
 // Diagnostics hook (not part of include/hprt.h): the first batch of the next hprt_render copies the rays that bounce `bounce` queues
 // (kind 0: the path segments entering bounce + 1, 1: its shadow rays, 2: its BSDF-sampled light rays) into d_out7 ([7][cap] planes:

@@ -77,6 +77,7 @@ struct FilmExtras {
 // film pixel `dest` of another tile
 struct FilmRecord { uint32_t dest, srcTile; float xyz[3]; float w; };
 
+bool WideWalkInUse(const DevScene &sc);      // plain renders of this scene take k_walk4 (the leaf-exact wide walk) rather than k_trace
 void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
                  uint32_t countImm, uint32_t gridItems, const RayStream &rays, const HitStream &hits, uint8_t *occ,
                  DevCounters *counters, uint32_t *workCounter, uint4 *rayStats = nullptr);

@@ -1823,6 +1823,16 @@ static bool WideWalkEnabled() {
     static const bool fromEnv = [] { const char *e = getenv("HPRT_WIDE_WALK"); return !(e && atoi(e) == 0); }();
     return g_wideWalk < 0 ? fromEnv : g_wideWalk != 0;
 }
+// HPRT_TRACE_PROFILE=1 in the environment, or hprt_debug_trace_profile_mode(1): the traversal kernels run their phase-profile
+// variants (g_traceProf; bench.py reads the wide walk's records per ray from one such render)
+static int g_traceProfileMode = -1;
+static bool TraceProfileEnabled() {
+    static const bool fromEnv = getenv("HPRT_TRACE_PROFILE") != nullptr;
+    return g_traceProfileMode < 0 ? fromEnv : g_traceProfileMode != 0;
+}
+extern "C" __attribute__((visibility("default"))) int hprt_debug_trace_profile_mode(int on) { const int was = TraceProfileEnabled() ? 1 : 0; g_traceProfileMode = on; return was; }
+// which walk a plain render of this scene takes: 1 the leaf-exact wide walk (k_walk4), 0 the binary walk (k_trace)
+bool WideWalkInUse(const DevScene &sc) { return sc.wide != nullptr && WideWalkEnabled(); }
 extern "C" __attribute__((visibility("default"))) int hprt_debug_wide_walk(int on) { const int was = WideWalkEnabled() ? 1 : 0; g_wideWalk = on; return was; }
 void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, const uint32_t *queue, const uint32_t *countPtr,
                  uint32_t countImm, uint32_t gridItems, const RayStream &rays, const HitStream &hits, uint8_t *occ,
@@ -1835,7 +1845,8 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     // workgroups per CU: five (LDS stack 32 KB, or four by registers in the kernels with the quadric code); seven for the plain
     // any-hit kernel of triangle-only scenes (66 registers, 20 KB)
     static const uint32_t anyPerCu = [] { const char *e = getenv("HPRT_TRACE_ANY_PER_CU"); return e ? (uint32_t)std::min((int)(HPRT_DEEP_THREADS / (256u * HPRT_TRACE_BLOCK)), std::max(1, atoi(e))) : (uint32_t)HPRT_ANY_WAVES; }();      // (the deep-stack area is laid out for that many workgroups per CU)
-    const bool plain = !count && getenv("HPRT_TRACE_PROFILE") == nullptr;
+    const bool profile = TraceProfileEnabled();
+    const bool plain = !count && !profile;
     const bool hasQuad = sc.nSpheres != 0u;
     static const uint32_t closestPerCu = [] { const char *e = getenv("HPRT_TRACE_CLOSEST_PER_CU"); return e ? (uint32_t)std::min(7, std::max(1, atoi(e))) : (uint32_t)HPRT_CLOSEST_WAVES; }();
     // workgroups per CU = waves per SIMD the variant is compiled for (instanced scenes included: their LDS stacks are shorter)
@@ -1856,7 +1867,6 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
     // 20 in killeroo-simple): a longer pair phase pays there (+2-3 % on the living room and the atrium, -1 % on killeroo)
     static const bool tuneFromEnv = getenv("HPRT_TRACE_TUNE") != nullptr;
     if (!anyHit && !tuneFromEnv && sc.nPairs > 100000u) { tune.parkLimit = 32; tune.stepLimit = 14; tune.primMin = 12; }      // (round-2 sweep, tools/sweep_tune.sh: atrium +3.6 %, living room +-0)
-    static const bool profile = getenv("HPRT_TRACE_PROFILE") != nullptr;
     const bool inst = sc.nInstances != 0u, quad = sc.nSpheres != 0u;
     // two-level scenes: a primitive-phase iteration that enters an instance costs two dependent memory round trips (the primitive, then
     // the instance's transform), so fewer, fuller iterations pay (tools/sweep_inst_tune.sh on instanced-10m: closest +7.6 %, any hit +5 %)

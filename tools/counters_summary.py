@@ -20,9 +20,9 @@ def short(name):
     if m:
         base = "k_trace<%s>" % ("any" if m.group(1) == "true" else "closest")
         return base + ("" if m.group(2) == "0" else "[mode %s]" % m.group(2)) + ("[inst]" if m.group(3) == "true" else "")
-    m = re.match(r"k_walk4<(false|true), (false|true)>", n)      # the leaf-exact wide walk <any hit, profiling>
+    m = re.match(r"k_walk4<(false|true), (false|true), (false|true), (false|true)>", n)      # the leaf-exact wide walk <any hit, profiling, instancing, quadrics>
     if m:
-        return "k_walk4<%s>" % ("any" if m.group(1) == "true" else "closest") + ("[prof]" if m.group(2) == "true" else "")
+        return "k_walk4<%s>" % ("any" if m.group(1) == "true" else "closest") + ("[prof]" if m.group(2) == "true" else "") + ("[inst]" if m.group(3) == "true" else "")
     m = re.match(r"k_shade<(\d), (\d+)(, (false|true))?(, (false|true))?>", n)      # <variant, workgroup, textures, instance transform>
     if m:
         return "k_shade<%s>" % {"0": "matte", "1": "plastic", "2": "generic", "3": "substrate"}[m.group(1)] + ("[tex]" if m.group(4) == "true" else "") + ("[inst]" if m.group(6) == "true" else "")
