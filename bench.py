@@ -26,17 +26,21 @@ the number of distinct devices the ranks sit on, and `config.film_merge` says wh
 Rays = closest-hit + shadow rays, as the reference counts them (core/scene.cpp:40-55), TRACED rays only.
 
 Extra objects in the line:
-  roofline      dominant kernel = k_trace<closest>.  `frac` = MEASURED HBM traffic of that kernel (FETCH_SIZE / WRITE_SIZE PMC passes of
+  roofline      dominant kernel = the closest-hit walk that ran (`kernel`): k_walk4<closest>, the leaf-exact four-wide walk of plain renders
+                (DESIGN.md section 4), or k_trace<closest>, the binary walk (HPRT_WIDE_WALK=0).  `walk` = what k_walk4 fetched per ray, counted by ONE
+                untimed render of its own phase-profile variant: 64-byte wide records stepped, primitive records tested, 16-byte requests.
+                `frac` = MEASURED HBM traffic of that kernel (FETCH_SIZE / WRITE_SIZE PMC passes of
                 the committed summary profiles/rNN_counters.json, per launch) / this run's HIP-event launch time / the 8 TB/s HBM3E
                 peak: at most 1 by construction; `peak_measured` = a float4 stream copy run inside this process (what a stream kernel
                 reaches on THIS box) with `frac_of_measured_peak`.  `bound` names the largest of three measured fractions
                 (`bound_candidates`), each of a peak and so at most 1: "hbm" (`frac`); "valu_issue" = SQ_INSTS_VALU * 2 / (1,024 SIMDs *
                 kernel cycles), cycles = GRBM_GUI_ACTIVE / 8 — CDNA4's SIMD-32 issues one wave64 instruction per two clocks — with
-                `lane_utilisation` and `useful_lane_frac` = issue x lanes; "l1_gather" (`gather`) = the 64-byte child-pair and 48-byte
-                triangle records the kernel fetches per second (V / 2 + 0.75 T per ray, counted by the kernel, x its ray rate) over the
+                `lane_utilisation` and `useful_lane_frac` = issue x lanes; "l1_gather" (`gather`) = the 64-byte records the kernel
+                fetches per second (k_walk4: its 16-byte requests / 4, from `walk`; k_trace: V / 2 + 0.75 T per ray from the counting pass; x its ray rate) over the
                 rate at which THIS GPU serves dependent per-lane 64-byte gathers that all hit L1 (k_gather_probe, run inside this process
                 in k_trace's launch shape with no arithmetic at all: ~225 G records/s); the same probe over a table of the BVH's size with
-                a BVH-like pick rides along (`bvh_like`, ~186 G on the atrium: the walk, at 180 G, equals that model).  This is what binds.
+                a BVH-like pick rides along (`bvh_like`, ~186 G on the atrium).  The binary walk ran at 0.82 of that ceiling; the wide walk asks for half the records
+                and sits at 0.56, with VALU issue at 0.47 and HBM at 0.35: `bound` is the largest of the three, none of them a wall by itself.
                 The summary is stamped with the sha256 of the code objects it was measured on; `counters_stale` says when the loaded
                 library's differ (then `frac` falls back to the summary's own launch time and the flag tells).  The contract's model
                 figure — algorithmic bytes (32 B per BVH node fetched + 48 B per primitive test + 28 B ray + 20 B hit; V
