@@ -863,7 +863,8 @@ void k_walk4(DevScene sc, const uint32_t *queue, const uint32_t *countPtr, uint3
                                f32x2{ro.x, ro.y}, ro.z, f32x2{invDir.x, invDir.y}, invDir.z, robust, tE, tX);
 #endif
                     int r[4] = {(int)q3.x, (int)q3.y, (int)q3.z, (int)q3.w};
-                    // the reference's rejections, each as "not provably outside": a NaN (0 * inf on a grid plane) never culls
+                    // the reference's rejections, each as "not provably outside": a NaN (0 * inf on a grid plane) never culls.  (One comparison
+                    // instead of three — max(tE, 0) > min(tX, tMax), a superset of what the reference passes — was measured 2-4 % slower.)
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if ((tE[k] > tX[k]) || (tX[k] <= 0.f) || (tE[k] >= rayTMax)) r[k] = WIDE_NONE;
@@ -880,9 +881,19 @@ void k_walk4(DevScene sc, const uint32_t *queue, const uint32_t *countPtr, uint3
                     }
                     const bool v0 = r[0] != WIDE_NONE, v1 = r[1] != WIDE_NONE, v2 = r[2] != WIDE_NONE, v3 = r[3] != WIDE_NONE;
                     // the first slot hit is walked now, the others wait, the next one on top
-                    if (v3 && (v0 || v1 || v2)) push(r[3], tE[3]);
-                    if (v2 && (v0 || v1)) push(r[2], tE[2]);
-                    if (v1 && v0) push(r[1], tE[1]);
+                    if (sp + 3 <= LDS_N) {
+                        // the usual case: all three fit the LDS entries.  No branches: every candidate is written at the top, and the top only
+                        // moves past the ones that count (what lies above the top is never read)
+                        const int p3 = (v3 && (v0 || v1 || v2)) ? 1 : 0, p2 = (v2 && (v0 || v1)) ? 1 : 0, p1 = (v1 && v0) ? 1 : 0;
+                        ldsRef[sp * HPRT_TRACE_BLOCK] = (uint32_t)r[3]; if (!ANY_HIT) ldsT[sp * HPRT_TRACE_BLOCK] = __float_as_uint(tE[3]); sp += p3;
+                        ldsRef[sp * HPRT_TRACE_BLOCK] = (uint32_t)r[2]; if (!ANY_HIT) ldsT[sp * HPRT_TRACE_BLOCK] = __float_as_uint(tE[2]); sp += p2;
+                        ldsRef[sp * HPRT_TRACE_BLOCK] = (uint32_t)r[1]; if (!ANY_HIT) ldsT[sp * HPRT_TRACE_BLOCK] = __float_as_uint(tE[1]); sp += p1;
+                        if (PROF) pfPush += (unsigned)(p3 + p2 + p1);
+                    } else {
+                        if (v3 && (v0 || v1 || v2)) push(r[3], tE[3]);
+                        if (v2 && (v0 || v1)) push(r[2], tE[2]);
+                        if (v1 && v0) push(r[1], tE[1]);
+                    }
                     cur = v0 ? r[0] : v1 ? r[1] : v2 ? r[2] : r[3];
                     if (cur == WIDE_NONE) cur = pop();
                 }
