@@ -1890,7 +1890,7 @@ void LaunchTrace(hipStream_t st, const DevScene &sc, bool anyHit, bool count, co
         static const uint32_t wClosestPerCu = [] { const char *e = getenv("HPRT_WALK4_CLOSEST_PER_CU"); return e ? (uint32_t)std::min((int)HPRT_WALK4_CLOSEST_WAVES, std::max(1, atoi(e))) : (uint32_t)HPRT_WALK4_CLOSEST_WAVES; }();
         static const uint32_t wAnyPerCu = [] { const char *e = getenv("HPRT_WALK4_ANY_PER_CU"); return e ? (uint32_t)std::min((int)HPRT_WALK4_ANY_WAVES, std::max(1, atoi(e))) : (uint32_t)HPRT_WALK4_ANY_WAVES; }();
         static const TraceTune wTuneClosest = [] { TraceTune t{52, 32, 8, 4, 12}; if (const char *e = getenv("HPRT_WALK4_TUNE")) sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin); return t; }();
-        static const TraceTune wTuneAny = [] { TraceTune t{48, 24, 6, 4, 3}; if (const char *e = getenv("HPRT_WALK4_TUNE_ANY")) sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin); return t; }();
+        static const TraceTune wTuneAny = [] { TraceTune t{52, 28, 6, 4, 4}; if (const char *e = getenv("HPRT_WALK4_TUNE_ANY")) sscanf(e, "%d,%d,%d,%d,%d", &t.refillBelow, &t.parkLimit, &t.stepLimit, &t.sphereLimit, &t.primMin); return t; }();
         // workgroups per CU = waves per SIMD the variant is compiled for
         const uint32_t wPerCu = profile ? 4u : quad ? (anyHit ? (uint32_t)HPRT_QUAD_ANY_WAVES : (uint32_t)HPRT_QUAD_CLOSEST_WAVES) : inst ? (anyHit ? (uint32_t)HPRT_WALK4_INST_ANY_WAVES : (uint32_t)HPRT_WALK4_INST_CLOSEST_WAVES) : anyHit ? wAnyPerCu : wClosestPerCu;
         const uint32_t wBlocks = std::min(256u * wPerCu, blockCap);
