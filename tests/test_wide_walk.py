@@ -200,3 +200,25 @@ def test_the_wide_walk_reaches_the_same_leaves_in_the_same_order(tree):
         assert got == want, (o, d, tmax)
         longest = max(longest, len(want))
     assert longest >= 3
+
+
+def test_a_tree_that_does_not_fit_the_grid_keeps_the_binary_walk(hprt, tree):
+    """BuildWide refuses what it cannot bound conservatively; hprt_scene_create then uploads no wide records and every call takes k_trace."""
+    nodes, _, _ = tree
+    fn = hprt.lib.hprt_debug_wide_build
+    n_out, need = C.c_size_t(0), C.c_int(0)
+    leaf = int(np.nonzero((nodes[:, 7] & 3) == 3)[0][5])
+    for value in (np.inf, np.nan):
+        bad = nodes.copy()
+        bad[leaf, 4] = np.array([value], np.float32).view(np.uint32)[0]      # one leaf's upper y bound
+        assert fn(bad.ctypes.data, bad.shape[0], None, 0, C.byref(n_out), C.byref(need)) == hprt.E_UNSUPPORTED
+    # an inverted box (lower bound above the upper one: nothing the builder produces) is refused too; any finite extent fits the grid
+    # (255 steps of 2^127 cover the float range)
+    inv = nodes.copy()
+    inv[leaf, 1], inv[leaf, 4] = nodes[leaf, 4], nodes[leaf, 1]
+    if nodes[leaf, 1] != nodes[leaf, 4]:
+        assert fn(inv.ctypes.data, inv.shape[0], None, 0, C.byref(n_out), C.byref(need)) == hprt.E_UNSUPPORTED
+    wide_span = nodes.copy()
+    lo = wide_span[:, 0:3].view(f32); hi = wide_span[:, 3:6].view(f32)
+    lo[1, 0] = f32(-3e38); hi[int(wide_span[0, 6]), 0] = f32(3e38)
+    assert fn(wide_span.ctypes.data, wide_span.shape[0], None, 0, C.byref(n_out), C.byref(need)) == 0

@@ -80,7 +80,9 @@ struct DevSphere { mat4 o2w, w2o; float radius, zMin, zMax, thetaMin, thetaMax, 
 // margCdf[nv + 1]; margFuncInt here.
 struct DevEnvLight { mat4 l2w, w2l; int32_t tex; int32_t nu, nv; uint32_t off; float margFuncInt; float pad[3]; };
 // ObjectInstance: the wrapped aggregate's entry (pair index, or ~primitive when the object holds a
-// single primitive: no aggregate, no bounds test) and the static instance transform
+// single primitive: no aggregate, no bounds test) and the static instance transform.  pad[0]: the same entry
+// into the WIDE records (k_walk4): first wide record of the object's tree, or that one primitive as a leaf reference
+// in the "box already passed" state
 struct DevInstance { mat4 i2w, w2i; int32_t root; uint32_t identity; uint32_t pad[2]; };
 
 struct DevScene {
