@@ -115,6 +115,9 @@ def slot_nodes(nodes, wide):
     leaf = (nodes[:, 7] & 3) == 3
     ref = wide[:, 12:16].view(np.int32)
     of = np.full((wide.shape[0], 4), -1, np.int64)
+    if leaf[0]:      # a one-leaf tree: one record whose only slot is that leaf
+        of[0, 0] = 0
+        return of
     todo = [(0, 0)]
     while todo:
         n, w = todo.pop()
@@ -222,3 +225,31 @@ def test_a_tree_that_does_not_fit_the_grid_keeps_the_binary_walk(hprt, tree):
     lo = wide_span[:, 0:3].view(f32); hi = wide_span[:, 3:6].view(f32)
     lo[1, 0] = f32(-3e38); hi[int(wide_span[0, 6]), 0] = f32(3e38)
     assert fn(wide_span.ctypes.data, wide_span.shape[0], None, 0, C.byref(n_out), C.byref(need)) == 0
+
+
+@pytest.mark.parametrize("seed,scale,offset", [(1, 1.0, 0.0), (2, 1e-30, 0.0), (3, 1e25, 0.0), (4, 1e-3, 1e6), (5, 1.0, -3e30)])
+def test_enclosure_holds_on_random_trees_at_extreme_scales(hprt, seed, scale, offset):
+    """BuildWide on trees of random boxes — flat and point-sized boxes among them, coordinates from the denormal range to 1e30, small
+    extents far from the origin (where one grid step is below the float spacing): every dequantised slot still contains its node's box."""
+    rng = np.random.default_rng(seed)
+    n = 3000
+    c = rng.uniform(-1, 1, (n, 3)); h = rng.uniform(0, 0.05, (n, 3))
+    h[rng.integers(0, n, n // 5), rng.integers(0, 3, n // 5)] = 0.0      # flat boxes
+    h[rng.integers(0, n, n // 20)] = 0.0                                 # points
+    lo_d = (c - h) * scale + offset; hi_d = (c + h) * scale + offset
+    bmin = lo_d.astype(f32); bmax = np.maximum(hi_d.astype(f32), bmin)
+    nodes, _ = hprt.Bvh.from_bounds(bmin, bmax).arrays()
+    fn = hprt.lib.hprt_debug_wide_build
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+    n_out, need = C.c_size_t(0), C.c_int(0)
+    wide = np.zeros((nodes.shape[0], 16), np.uint32)
+    assert fn(nodes.ctypes.data, nodes.shape[0], wide.ctypes.data, wide.shape[0], C.byref(n_out), C.byref(need)) == 0
+    wide = wide[:n_out.value]
+    lo = nodes[:, 0:3].view(f32); hi = nodes[:, 3:6].view(f32)
+    of = slot_nodes(nodes, wide)
+    qlo, qhi = dequant(wide)
+    m = of >= 0
+    assert np.isfinite(qlo[m]).all() and np.isfinite(qhi[m]).all()
+    assert (qlo[m] <= lo[of[m]]).all() and (qhi[m] >= hi[of[m]]).all()
+    assert np.array_equal(np.sort(of[m & (wide[:, 12:16].view(np.int32) < 0)]), np.nonzero((nodes[:, 7] & 3) == 3)[0])
