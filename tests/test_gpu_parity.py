@@ -565,23 +565,49 @@ def _hard_rays(nodes, n, seed):
     return o, d, tmax
 
 
-@pytest.mark.parametrize("fixture", ["killeroo.hprt", "living_room.hprt", "killeroo_simple.hprt", "simple_instanced.hprt"])
+def _far_small_scene_text():
+    """2,000 small triangles (0.01-0.5 units) in a unit cube 1e5 units from the origin: the wide records' grid steps are below the float
+    spacing of the coordinates there, so the outward rounding of the quantised boxes is what keeps every leaf reachable."""
+    rng = np.random.default_rng(23)
+    c = rng.uniform(0, 1, (2000, 1, 3)); e = rng.normal(size=(2000, 3, 3)) * rng.uniform(0.01, 0.5, (2000, 1, 1))
+    P = (c + e + np.array([1e5, -3e4, 7e4])).astype(np.float32).reshape(-1, 3)
+    pts = " ".join("%.9g" % v for v in P.ravel()); idx = " ".join(str(i) for i in range(P.shape[0]))
+    return ('LookAt 100003 -30000 70000  100000 -30000 70000  0 0 1\nCamera "perspective" "float fov" [40]\nSampler "halton" "integer pixelsamples" [2]\n'
+            'Integrator "path" "integer maxdepth" [3]\nFilm "image" "integer xresolution" [64] "integer yresolution" [64] "string filename" ["x.pfm"]\n'
+            'Accelerator "bvh"\nWorldBegin\nLightSource "point" "point from" [100002 -29999 70002] "color I" [30 30 30]\nMaterial "matte" "color Kd" [.5 .5 .5]\n'
+            'Shape "trianglemesh" "integer indices" [%s] "point P" [%s]\nWorldEnd\n' % (idx, pts))
+
+
+@pytest.mark.parametrize("fixture", ["killeroo.hprt", "living_room.hprt", "killeroo_simple.hprt", "simple_instanced.hprt", "far_small"])
 def test_wide_and_binary_walks_agree(hprt, orc, fixture):
     """Plain calls take the leaf-exact four-wide walk (k_walk4, csrc/wide_bvh.h); hprt_debug_wide_walk(0) keeps the binary walk
     (k_trace).  Both must return the oracle's hits bit for bit — also for rays on which the bounds test meets inf and NaN."""
     import ctypes as C
     import os
     from conftest import GOLDEN
-    path = os.path.join(GOLDEN, fixture)
-    model = hprt.Model.load(path)
+    import tempfile
+    if fixture == "far_small":
+        d_ = tempfile.mkdtemp()
+        open(os.path.join(d_, "far.pbrt"), "w").write(_far_small_scene_text())
+        model = hprt.Model.parse(os.path.join(d_, "far.pbrt"))
+        path = os.path.join(d_, "far.hprt"); model.save(path)
+    else:
+        path = os.path.join(GOLDEN, fixture)
+        model = hprt.Model.load(path)
     if fixture == "living_room.hprt":      # the oracle reads finished pyramids only (DESIGN.md section 6)
-        import tempfile
         path = os.path.join(tempfile.mkdtemp(), "expanded.hprt"); model.save(path)
     bvh = hprt.Bvh(model)
     scene = hprt.Scene(model, bvh)
     oracle = orc.OracleScene(path)
     nodes, _ = bvh.arrays()
     n = 400000 if fixture == "killeroo.hprt" else 150000
+    if fixture == "far_small":      # (and the frame: plain render = wide walk, counting render = binary walk, both against the oracle)
+        oracle.set_film(spp=2)
+        _, film0, c0, _, _ = oracle.render(spp=2, threads=4)
+        film1, _ = scene.render(model.options)
+        film2, st2 = scene.render(model.options, count_work=True)
+        assert np.array_equal(film0.view(np.uint32), film1.view(np.uint32)) and np.array_equal(film0.view(np.uint32), film2.view(np.uint32))
+        assert st2["nodes_fetched"] == c0["nodes_fetched"] and float(film0[..., :3].max()) > 0
     o, d, tmax = _hard_rays(nodes, n, 17)
     instanced = fixture == "simple_instanced.hprt"      # (spheres in an object instance: the two-level walk and the quadric tests)
     if instanced:
