@@ -5,6 +5,7 @@
 // BSDFs (core/reflection.cpp, core/microfacet.cpp), point/distant/sphere-area lights
 // (lights/*.cpp, shapes/sphere.cpp:217-306) and ray spawning (core/interaction.h:64-78).
 #pragma once
+#include <cstddef>
 #include "dev_intersect.h"
 
 namespace hprt {
@@ -92,7 +93,7 @@ __device__ __forceinline__ float radical_inverse_base(uint32_t base, uint64_t M,
 // permutation lookups of the digit loops are served from LDS instead of L2.
 #define HPRT_HALTON_LDS_DIMS 64
 #define HPRT_HALTON_LDS_PERMS 8893
-struct HaltonLds {
+struct alignas(16) HaltonLds {
     uint64_t magic[HPRT_HALTON_LDS_DIMS];
     uint32_t magic32[HPRT_HALTON_LDS_DIMS];      // floor(2^32 / prime)
     int32_t prime[HPRT_HALTON_LDS_DIMS];
@@ -108,7 +109,12 @@ __device__ __forceinline__ void halton_lds_load(const DevScene &sc, HaltonLds *h
         h->invBase[i] = invBase;
         h->tail[i] = invBase * (float)sc.perms[sc.primeSums[i]] / (1 - invBase);   // invBase * perm[0] / (1 - invBase)
     }
-    for (int i = threadIdx.x; i < HPRT_HALTON_LDS_PERMS; i += blockDim.x) h->perm[i] = sc.perms[i];
+    // the digit permutations as 16-byte words (1,112 of them: two or three loads per thread instead of seventeen 2-byte ones — this prologue
+    // runs once per workgroup of 512 vertices, in front of everything)
+    static_assert(((HPRT_HALTON_LDS_PERMS + 3) * sizeof(uint16_t)) % 16 == 0 && offsetof(HaltonLds, perm) % 16 == 0, "perm[] is copied as uint4");
+    const uint4 *src = (const uint4 *)sc.perms;
+    uint4 *dst = (uint4 *)h->perm;
+    for (int i = threadIdx.x; i < (int)((HPRT_HALTON_LDS_PERMS + 3) * sizeof(uint16_t) / 16); i += blockDim.x) dst[i] = src[i];
     __syncthreads();
 }
 // HaltonSampler::SampleDimension, samplers/halton.cpp:119-127

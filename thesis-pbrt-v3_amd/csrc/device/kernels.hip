@@ -1275,7 +1275,6 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
     constexpr int RETRY = BIN == (int)BIN_TEXTURED ? 1 : 0;      // voxel misses of the other bins are shaded again by the generic variant, the textured bin's by its own
     const uint32_t n = retryPass ? bins.count[(6 + RETRY) * BIN_STRIDE] : bins.count[BIN * BIN_STRIDE];
     if (blockIdx.x * blockDim.x >= n) return;      // whole block beyond the bin (grids are sized for the upper bound)
-    halton_lds_load(sc, &hl);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 #ifdef HPRT_SHADE_PROF
     unsigned long long spT[8] = {0, 0, 0, 0, 0, 0, 0, 0}, spLast = clock64();
@@ -1284,6 +1283,9 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
     bool wantNext = false, wantShadow = false, wantMis = false, wantResolve = false, defer = false, voxelMiss = false;
     uint32_t slot = 0;          // index in the input streams
     uint32_t j = 0;             // index in the output streams
+    // The vertex's queue entry and path words are requested BEFORE the Halton tables are staged: the staging (20 KB per workgroup and a
+    // barrier, in front of everything) and the first two round trips of the vertex's own dependent chain then overlap.
+    float4 rayA = make_float4(0.f, 0.f, 0.f, 0.f), rayB = rayA, hitA = rayA, beta4 = rayA, L4 = rayA;
     if (i < n) {
         if (retryPass) { const uint2 e = bins.retry[RETRY][i]; slot = e.x; j = e.y; }
         else {
@@ -1294,10 +1296,13 @@ __global__ __launch_bounds__(BS, MODE == 0 ? HPRT_SHADE_WAVES_MATTE : MODE == 1 
              : bins.count[0] + bins.count[BIN_STRIDE] + bins.count[4 * BIN_STRIDE] + bins.count[5 * BIN_STRIDE]) + i;
         if (BIN == (int)BIN_GENERIC && i >= bins.count[5 * BIN_STRIDE]) j = bins.aux[i];       // deferred by a specialised variant: keeps that variant's index
         }
-        const float4 rayA = in.ray.a[slot], rayB = in.ray.b[slot], hitA = hit.a[slot];
+        rayA = in.ray.a[slot]; rayB = in.ray.b[slot]; hitA = hit.a[slot];
         // a fresh path's throughput and radiance are constants (k_generate does not store them)
-        const float4 beta4 = firstBounce ? make_float4(1.f, 1.f, 1.f, __uint_as_float(slot)) : in.beta[slot];
-        const float4 L4 = firstBounce ? make_float4(0.f, 0.f, 0.f, 1.f) : in.L[slot];
+        beta4 = firstBounce ? make_float4(1.f, 1.f, 1.f, __uint_as_float(slot)) : in.beta[slot];
+        L4 = firstBounce ? make_float4(0.f, 0.f, 0.f, 1.f) : in.L[slot];
+    }
+    halton_lds_load(sc, &hl);
+    if (i < n) {
         SP_MARK(6);      // queue entry + path streams
         const uint32_t st = __float_as_uint(rayB.w);
         int dim = (int)(st & 0xffffu);
