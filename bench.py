@@ -40,7 +40,7 @@ Extra objects in the line:
                 rate at which THIS GPU serves dependent per-lane 64-byte gathers that all hit L1 (k_gather_probe, run inside this process
                 in k_trace's launch shape with no arithmetic at all: ~225 G records/s); the same probe over a table of the BVH's size with
                 a BVH-like pick rides along (`bvh_like`, ~186 G on the atrium).  The binary walk ran at 0.82 of that ceiling; the wide walk asks for half the records
-                and sits at 0.58, with VALU issue at 0.49 and HBM at 0.37: `bound` is the largest of the three, none of them a wall by itself.
+                and sits at 0.58, with VALU issue at 0.50 and HBM at 0.36: `bound` is the largest of the three, none of them a wall by itself.
                 The summary is stamped with the sha256 of the code objects it was measured on; `counters_stale` says when the loaded
                 library's differ (then `frac` falls back to the summary's own launch time and the flag tells).  The contract's model
                 figure — algorithmic bytes (32 B per BVH node fetched + 48 B per primitive test + 28 B ray + 20 B hit; V
