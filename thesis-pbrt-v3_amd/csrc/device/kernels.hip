@@ -664,28 +664,9 @@ __global__ __launch_bounds__(HPRT_TRACE_BLOCK, MODE == 0 ? (QUAD ? (ANY_HIT ? HP
 #ifndef HPRT_WALK4_INST_ANY_WAVES
 #define HPRT_WALK4_INST_ANY_WAVES 6
 #endif
-// two slots (bytes sh / 8 and sh / 8 + 1 of the near / far words) of a wide record: entry and exit distance of the dequantised boxes
-__device__ __forceinline__ void wide_slab2(uint32_t nX, uint32_t fX, uint32_t nY, uint32_t fY, uint32_t nZ, uint32_t fZ, int sh, float sx, float sy, float sz,
-                                           float ox, float oy, float oz, float rox, float roy, float roz, float ivx, float ivy, float ivz, float robust,
-                                           float *tE0, float *tX0, float *tE1, float *tX1) {
-    const f32x2 qnx = {(float)((nX >> sh) & 0xffu), (float)((nX >> (sh + 8)) & 0xffu)}, qfx = {(float)((fX >> sh) & 0xffu), (float)((fX >> (sh + 8)) & 0xffu)};
-    const f32x2 qny = {(float)((nY >> sh) & 0xffu), (float)((nY >> (sh + 8)) & 0xffu)}, qfy = {(float)((fY >> sh) & 0xffu), (float)((fY >> (sh + 8)) & 0xffu)};
-    const f32x2 qnz = {(float)((nZ >> sh) & 0xffu), (float)((nZ >> (sh + 8)) & 0xffu)}, qfz = {(float)((fZ >> sh) & 0xffu), (float)((fZ >> (sh + 8)) & 0xffu)};
-    // grid coordinate -> float: q * step is exact, so the fused form is origin + q * step with its one rounding (what the host rounded outwards against)
-    const f32x2 vsx = {sx, sx}, vsy = {sy, sy}, vsz = {sz, sz}, vox = {ox, ox}, voy = {oy, oy}, voz = {oz, oz};
-    const f32x2 bnx = __builtin_elementwise_fma(qnx, vsx, vox), bfx = __builtin_elementwise_fma(qfx, vsx, vox);
-    const f32x2 bny = __builtin_elementwise_fma(qny, vsy, voy), bfy = __builtin_elementwise_fma(qfy, vsy, voy);
-    const f32x2 bnz = __builtin_elementwise_fma(qnz, vsz, voz), bfz = __builtin_elementwise_fma(qfz, vsz, voz);
-    const f32x2 tnx = (bnx - rox) * ivx, tny = (bny - roy) * ivy, tnz = (bnz - roz) * ivz;
-    f32x2 tfx = (bfx - rox) * ivx, tfy = (bfy - roy) * ivy, tfz = (bfz - roz) * ivz;
-    tfx = tfx * robust; tfy = tfy * robust; tfz = tfz * robust;
-    *tE0 = fmaxf(fmaxf(tnx.x, tny.x), tnz.x); *tE1 = fmaxf(fmaxf(tnx.y, tny.y), tnz.y);
-    *tX0 = fminf(fminf(tfx.x, tfy.x), tfz.x); *tX1 = fminf(fminf(tfx.y, tfy.y), tfz.y);
-}
-
-// The same for the four slots of a record, packed so that the ray's operands are pairs it holds anyway: x and y of one slot share an
-// instruction ({x, y} of the origin, the reciprocal direction, the grid), z takes two slots at a time.  (wide_slab2's {slot, slot}
-// pairs made hipcc keep every ray operand twice, {v, v}: six registers for nothing.)
+// Entry and exit distances of the four dequantised slot boxes of a wide record: the operations of Bounds3::IntersectP, packed so that the
+// ray's operands are pairs it holds anyway — x and y of one slot share an instruction ({x, y} of the origin, the reciprocal direction, the
+// grid), z takes two slots at a time.  (A first version paired {slot, slot}: hipcc then kept every ray operand twice, {v, v}: six registers for nothing.)
 __device__ __forceinline__ void wide_slab4(uint32_t nX, uint32_t fX, uint32_t nY, uint32_t fY, uint32_t nZ, uint32_t fZ, f32x2 sxy, float sz, f32x2 oxy, float oz,
                                            f32x2 roxy, float roz, f32x2 ivxy, float ivz, float robust, float tE[4], float tX[4]) {
     f32x2 tn[4], tf[4];
@@ -853,15 +834,8 @@ void k_walk4(DevScene sc, const uint32_t *queue, const uint32_t *countPtr, uint3
                     const uint32_t nX = ngX ? q1.y : q1.x, fX = ngX ? q1.x : q1.y, nY = ngY ? q1.w : q1.z, fY = ngY ? q1.z : q1.w;
                     const uint32_t nZ = ngZ ? q2.y : q2.x, fZ = ngZ ? q2.x : q2.y;
                     float tE[4], tX[4];
-#ifdef HPRT_WALK4_SLOT_PAIRS
-                    wide_slab2(nX, fX, nY, fY, nZ, fZ, 0, sx, sy, sz, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), ro.x, ro.y, ro.z,
-                               invDir.x, invDir.y, invDir.z, robust, &tE[0], &tX[0], &tE[1], &tX[1]);
-                    wide_slab2(nX, fX, nY, fY, nZ, fZ, 16, sx, sy, sz, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), ro.x, ro.y, ro.z,
-                               invDir.x, invDir.y, invDir.z, robust, &tE[2], &tX[2], &tE[3], &tX[3]);
-#else
                     wide_slab4(nX, fX, nY, fY, nZ, fZ, f32x2{sx, sy}, sz, f32x2{__uint_as_float(q0.x), __uint_as_float(q0.y)}, __uint_as_float(q0.z),
                                f32x2{ro.x, ro.y}, ro.z, f32x2{invDir.x, invDir.y}, invDir.z, robust, tE, tX);
-#endif
                     int r[4] = {(int)q3.x, (int)q3.y, (int)q3.z, (int)q3.w};
                     // the reference's rejections, each as "not provably outside": a NaN (0 * inf on a grid plane) never culls.  (One comparison
                     // instead of three — max(tE, 0) > min(tX, tMax), a superset of what the reference passes — was measured 2-4 % slower.)
