@@ -631,3 +631,55 @@ def test_wide_and_binary_walks_agree(hprt, orc, fixture):
     finally:
         hprt.lib.hprt_debug_wide_walk(-1)
     assert 0.02 < (p0 >= 0).mean() < 0.98 and 0.02 < occ0.mean() < 0.98
+
+
+def test_walks_agree_when_leaf_boxes_do_not_contain_their_triangles(hprt):
+    """What decides whether a primitive is tested is its LEAF'S box as the tree holds it, not the primitive's extent.  A caller-filled
+    HprtSceneDesc whose BVH was built over bounds shrunk to 40 % of every triangle's extent (legal input: hprt_scene_create takes the node
+    array as given) makes that visible: most hits of the plain geometry are now outside their leaf's box, and both walks must drop exactly
+    those — the binary walk at the parent's child test, the wide walk at the leaf's own exact test (closest hit: before the triangles count;
+    any hit: when a triangle reports a hit, the path a consistent tree almost never takes).  No oracle here: the two product walks against
+    each other, and against the unshrunk tree as evidence that the boxes did bite."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    n_tri = 3000
+    c = rng.uniform(-1, 1, (n_tri, 1, 3)); e = rng.normal(size=(n_tri, 3, 3)) * rng.uniform(0.02, 0.25, (n_tri, 1, 1))
+    P = (c + e).astype(np.float32).reshape(-1, 3); idx = np.arange(3 * n_tri, dtype=np.int32).reshape(-1, 3)
+    tri = P[idx]
+    lo, hi = tri.min(axis=1), tri.max(axis=1)
+    mid = (lo + hi) * np.float32(0.5)
+    shrink = lambda f: ((mid + (lo - mid) * np.float32(f)).astype(np.float32), (mid + (hi - mid) * np.float32(f)).astype(np.float32))
+    sh = hprt.ShapeDesc(); sh.kind = 0; sh.material = 0; sh.area_light = -1
+    sh.n_tris = n_tri; sh.n_verts = 3 * n_tri; sh.indices = idx.ctypes.data; sh.P = P.ctypes.data
+    mat = hprt.MaterialDesc(); mat.type = 0; mat.Kd[:] = [.5, .5, .5]; mat.kd_texture = mat.ks_texture = -1
+    n = 300000
+    o = rng.uniform(-1.6, 1.6, (n, 3)).astype(np.float32); d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[: n // 10, 0] = 0.0; d[n // 10: n // 5, 2] = -0.0
+    tmax = np.full(n, np.inf, np.float32); tmax[n // 2:] = rng.uniform(0.1, 3.0, n - n // 2).astype(np.float32)
+    hprt.lib.hprt_debug_wide_walk.argtypes = [C.c_int]
+    res = {}
+    try:
+        for f in (1.0, 0.4):
+            bmin, bmax = shrink(f)
+            bvh = hprt.Bvh.from_bounds(bmin, bmax)
+            nodes, order = bvh.arrays()
+            desc = hprt.SceneDesc()
+            desc.nodes = nodes.ctypes.data; desc.n_nodes = nodes.shape[0]; desc.prim_order = order.ctypes.data; desc.n_prims = order.shape[0]
+            shapes = (hprt.ShapeDesc * 1)(sh); mats = (hprt.MaterialDesc * 1)(mat)
+            desc.shapes = shapes; desc.n_shapes = 1; desc.materials = mats; desc.n_materials = 1
+            scene = hprt.Scene.from_desc(desc)
+            for wide in (1, 0):
+                hprt.lib.hprt_debug_wide_walk(wide)
+                t, p, b = scene.intersect(o, d, tmax)
+                creation = np.where(p >= 0, order.astype(np.int64)[np.maximum(p, 0)], -1)      # (creation-order triangle numbers: the two trees order differently)
+                res[(f, wide)] = (t, creation, b, scene.occluded(o, d, tmax))
+            del scene
+    finally:
+        hprt.lib.hprt_debug_wide_walk(-1)
+    for f in (1.0, 0.4):
+        for a, b_ in zip(res[(f, 1)], res[(f, 0)]):
+            assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b_).view(np.uint8)), f
+    full, cut = res[(1.0, 1)], res[(0.4, 1)]
+    assert (full[1] >= 0).mean() > 0.3
+    assert (cut[1] >= 0).sum() < 0.8 * (full[1] >= 0).sum() and cut[3].sum() < 0.8 * full[3].sum()      # the shrunk boxes hide hits the geometry has
+    assert not (cut[3] & ~full[3]).any()                                                                  # and never add one
